@@ -1,0 +1,227 @@
+/*
+ * seedx_hip.h — C-ABI of libseedx_hip.so: the hand-written gfx950 (MI355X / CDNA4) kernels behind the
+ * SEED-X inference hot path (ViT visual encoder → Llama-style LLM prefill/decode → SDXL-adapter UNet loop).
+ *
+ * The reference (AILab-CVC/SEED-X) has NO native layer: every op below replaces a stock
+ * PyTorch / xformers / diffusers call made from the reference's Python modules. Each entry cites the
+ * reference call site (file:line under the reference tree) it stands in for. The Python host in
+ * `seed-x_amd/` binds these with ctypes (INTEGRATION.md shows the stub a reference maintainer would add).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; all pointers are DEVICE pointers unless a name ends in `_host`
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); every call only ENQUEUES work
+ *   - return value: 0 (SX_OK) on success; non-zero on error, message via sx_last_error()
+ *   - 16-bit activations/weights are fp16 or bf16 selected by `dtype`; accumulation is always fp32
+ *   - row-major everywhere; weights are [N][K] (torch nn.Linear layout), conv weights [Cout][3][3][Cin]
+ */
+#ifndef SEEDX_HIP_H
+#define SEEDX_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SX_OK 0
+#define SX_ERR_INVALID 1
+#define SX_ERR_HIP 2
+
+/* element types */
+#define SX_F16 0
+#define SX_BF16 1
+#define SX_F32 2
+
+/* epilogue activations */
+#define SX_ACT_NONE 0
+#define SX_ACT_GELU 1 /* exact erf GELU  == torch.nn.GELU()            (qwen_visual.py:253-255) */
+#define SX_ACT_SILU 2 /* x*sigmoid(x)   == ACT2FN["silu"]             (modeling_llama_xformer.py:152-167) */
+
+/* A-operand addressing modes of sx_gemm */
+#define SX_A_LINEAR 0  /* A is [M][K] row-major                                                   */
+#define SX_A_CONV3X3 1 /* A is an NHWC image, implicit im2col of a 3x3 / pad 1 convolution        */
+
+const char* sx_last_error(void);
+int sx_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * GEMM / implicit-GEMM conv on MFMA:  C[M][N] = epilogue( A[M][K] · W[N][K]^T )
+ * replaces: nn.Linear everywhere on the path (qwen_visual.py:176-177,253-255,115;
+ *           modeling_llama_xformer.py:160-167,184-187,707; resampler.py:12-15,42-44,237,257-258),
+ *           nn.Conv2d 3x3 inside diffusers UNet2DConditionModel [ext] (call site
+ *           pipeline_stable_diffusion_xl_t2i_edit.py:915-922), F.interpolate(nearest 2x)+conv and the
+ *           stride-2 Downsample2D conv of the same UNet.
+ * epilogue order: v = acc; v += bias[n]; v += bias2d[(m / bias2d_rows)][n]; if(glu) v = first*act(second)
+ *                 else v = act(v); v += residual[(res_mod? m % res_mod : m)][n_out]; store as out_dtype.
+ * glu: W rows are packed in 32-row groups [16 "linear" rows | 16 "gate" rows]; output has N/2 columns.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct sx_gemm_args {
+  const void* A;         /* 16-bit, LINEAR: [M][K]; CONV3X3: [B][Hin][Win][Cin]                    */
+  const void* W;         /* 16-bit, [N][K]   (CONV3X3: K = 9*Cin ordered (ky,kx,cin))              */
+  void* C;               /* [M][N_out] of out_dtype, row stride ldc elements                        */
+  const float* bias;     /* [N] fp32 or NULL                                                        */
+  const float* bias2d;   /* [M / bias2d_rows][N] fp32 or NULL  (per-sample time-embedding add)      */
+  const float* residual; /* fp32 [.][N_out] row stride ldr, or NULL                                 */
+  int32_t M, N, K;
+  int32_t ldc, ldr;
+  int32_t n_valid;     /* 0 = all; else only output columns < n_valid are stored (multiple of 4)    */
+  int32_t res_mod;     /* 0 = residual row m; >0 = residual row m % res_mod (pos-embed broadcast)    */
+  int32_t bias2d_rows; /* rows of C per bias2d row                                                   */
+  int32_t dtype;       /* SX_F16 / SX_BF16 : type of A and W                                         */
+  int32_t out_dtype;   /* SX_F16 / SX_BF16 / SX_F32                                                  */
+  int32_t act;         /* SX_ACT_*                                                                   */
+  int32_t glu;         /* 0/1                                                                        */
+  int32_t a_mode;      /* SX_A_*                                                                     */
+  /* conv geometry (a_mode == SX_A_CONV3X3): M = B*Hout*Wout, K = 9*Cin */
+  int32_t B, Hin, Win, Cin, Hout, Wout;
+  int32_t stride;   /* 1 or 2 (pad is always 1)                                                      */
+  int32_t upsample; /* 1 = input is nearest-2x upsampled on the fly (Hout = 2*Hin)                   */
+} sx_gemm_args;
+int sx_gemm(const sx_gemm_args* args, void* stream);
+
+/* batch-1..8 row GEMV for single-token decode (HBM-bound weight streaming, no MFMA).
+ * replaces: the same nn.Linear calls at q_len == 1 (modeling_llama_xformer.py:204-206,239,166-167,707).
+ * y[m][n_out] = epi( x[m][K] · W[N][K]^T ), x 16-bit, y out_dtype, residual fp32. glu packing as above. */
+typedef struct sx_gemv_args {
+  const void* x;
+  const void* W;
+  void* y;
+  const float* residual;
+  int32_t M, N, K;
+  int32_t dtype, out_dtype, act, glu;
+} sx_gemv_args;
+int sx_gemv(const sx_gemv_args* args, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Normalisations (row reductions with wave shuffles, fp32 statistics)
+ * ------------------------------------------------------------------------------------------------ */
+/* LayerNorm over the last dim. replaces nn.LayerNorm (qwen_visual.py:246,250,361,384,122-123;
+ * resampler.py:11,38-39,240) and diffusers BasicTransformerBlock.norm1/2/3 [ext].
+ * rms != 0 → LlamaRMSNorm (modeling_llama_xformer.py:95,286,301,595): y = x * rsqrt(mean(x^2)+eps) * gamma */
+int sx_layernorm(const void* x, int in_dtype, void* y, int out_dtype, const float* gamma, const float* beta,
+                 int rows, int cols, float eps, int rms, void* stream);
+
+/* GroupNorm(+SiLU) over NHWC activations x[B][HW][C] (fp32 in). replaces diffusers
+ * ResnetBlock2D.norm1/norm2 + nonlinearity, Transformer2DModel.norm, conv_norm_out [ext].
+ * stats: scratch fp64 [B][groups][2] (zeroed by the call). y: 16-bit normalised output.
+ * raw16: optional 16-bit un-normalised copy of x (feeds the 1x1 shortcut conv), may be NULL. */
+int sx_groupnorm(const float* x, void* y, void* raw16, int out_dtype, const float* gamma, const float* beta,
+                 double* stats, int B, int HW, int C, int groups, float eps, int silu, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Attention
+ * ------------------------------------------------------------------------------------------------ */
+/* Vt[b][h][d][kv] (kv padded to kv_pad, zero filled) = V[b][kv][h][d]; pre-pass for sx_attention. */
+int sx_transpose_v(const void* V, void* Vt, int B, int H, int Skv, int D, int kv_pad, int64_t v_batch_stride,
+                   int64_t v_row_stride, int64_t v_head_stride, void* stream);
+
+/* Flash-style fused attention on MFMA (online softmax in fp32, LDS-staged K / V^T tiles).
+ * replaces: bmm→softmax→bmm (qwen_visual.py:204-215), nn.MultiheadAttention core (qwen_visual.py:145),
+ *           xformers memory_efficient_attention (modeling_llama_xformer.py:221-238),
+ *           torch SDPA in diffusers AttnProcessor2_0 [ext].
+ * Q[b][sq][h][D], K[b][skv][h][D] addressed with element strides; Vt from sx_transpose_v.
+ * O[b][sq][h][D] (o_row_stride = elements between consecutive sq; heads packed at h*D).
+ * causal: key j visible to query i iff j <= i + (Skv - Sq)  (bottom-right aligned; prefill and chunked decode).
+ * D must be a multiple of 8 and <= 128 (104 is padded to 128 in LDS/registers only). */
+typedef struct sx_attn_args {
+  const void* Q;
+  const void* K;
+  const void* Vt;
+  void* O;
+  int32_t B, H, Sq, Skv, D, kv_pad;
+  int64_t q_batch_stride, q_row_stride, q_head_stride;
+  int64_t k_batch_stride, k_row_stride, k_head_stride;
+  int64_t o_batch_stride, o_row_stride;
+  float scale;
+  int32_t causal;
+  int32_t dtype;
+} sx_attn_args;
+int sx_attention(const sx_attn_args* args, void* stream);
+
+/* Small generic attention (any D <= 256, VALU, one wave per query row). Used where FLOPs are negligible:
+ * Resampler MHA with head_dim 160 (agent_seed_x_i.yaml:2-7), AttentionPool2d (resampler.py:89-116),
+ * PerceiverAttention (resampler.py:46-75). V is in natural [b][skv][h][D] layout. */
+typedef struct sx_attn_small_args {
+  const void* Q;
+  const void* K;
+  const void* V;
+  void* O;
+  int32_t B, H, Sq, Skv, D;
+  int64_t q_batch_stride, q_row_stride, q_head_stride;
+  int64_t k_batch_stride, k_row_stride, k_head_stride;
+  int64_t v_batch_stride, v_row_stride, v_head_stride;
+  int64_t o_batch_stride, o_row_stride;
+  float scale;
+  int32_t dtype;
+} sx_attn_small_args;
+int sx_attention_small(const sx_attn_small_args* args, void* stream);
+
+/* Single-token decode attention over the KV cache (split-KV flash-decoding, HBM-bound).
+ * replaces memory_efficient_attention at q_len == 1 (modeling_llama_xformer.py:231-237).
+ * q[H][D] 16-bit; kcache/vcache [H][Tmax][D]; ctx_len read from DEVICE memory (graph-replay friendly);
+ * scratch: fp32 [H][nsplit][D+2]; out[H*D] 16-bit. */
+int sx_attn_decode(const void* q, const void* kcache, const void* vcache, void* out, float* scratch,
+                   const int32_t* ctx_len_dev, int H, int D, int Tmax, int nsplit, float scale, int dtype,
+                   void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * LLM glue kernels
+ * ------------------------------------------------------------------------------------------------ */
+/* RoPE (HF rotate-half, tables rounded to the activation dtype first — modeling_llama_xformer.py:128-149)
+ * applied in place to the q part of qkv[T][3*H*D] and written, with v, into the caches at pos0+t.
+ * pos0 read from device memory. */
+int sx_rope_kv_append(void* qkv, void* kcache, void* vcache, const float* cos_tab, const float* sin_tab,
+                      const int32_t* pos0_dev, int T, int H, int D, int Tmax, int dtype, void* stream);
+/* out[t][:] = table[ids[t]][:]   (embed_tokens, seed_x.py:158) ; out fp32 */
+int sx_embedding(const int32_t* ids, const void* table, float* out, int T, int dim, int dtype, void* stream);
+/* dst[rows[i]][:] = src[i][:] fp32 (input_embeds[ids_cmp_mask] = ..., seed_x.py:173) */
+int sx_scatter_rows(const float* src, const int32_t* rows, float* dst, int n, int dim, void* stream);
+/* Greedy step with the AutoImageTokenGenerationProcessor rule fused (generation.py:19-31):
+ * prev = *prev_id_dev; if prev in img_ids[0..n_img-2] → next = img_ids[idx+1] (the "max+10" rule) else
+ * logits[img_ids[1..]] = 0.0 (in place, as the reference does) then argmax (first maximal index).
+ * Writes next to *next_id_dev (may alias prev_id_dev) and, if out_ids != NULL, to out_ids[*step_dev]. */
+int sx_greedy_next(float* logits, int vocab, const int32_t* img_ids_dev, int n_img, const int32_t* prev_id_dev,
+                   int32_t* next_id_dev, int32_t* out_ids, const int32_t* step_dev, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Elementwise / layout helpers
+ * ------------------------------------------------------------------------------------------------ */
+int sx_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, void* stream);
+/* strided 2-D copy of fp32 rows: dst[r][dst_off + c] = src[r][c]  (channel concat of skip connections) */
+int sx_copy2d_f32(const float* src, int64_t src_ld, float* dst, int64_t dst_ld, int64_t rows, int cols,
+                  void* stream);
+/* y = a + b (fp32), n elements */
+int sx_add_f32(const float* a, const float* b, float* y, int64_t n, void* stream);
+/* ViT patchify: img[B][3][S][S] (fp32) → patches[B*(S/P)^2][Kpad] 16-bit, k = c*P*P + py*P + px, zero padded
+ * (conv1 as a GEMM, qwen_visual.py:352,393-396) */
+int sx_patchify(const float* img, void* patches, int B, int S, int P, int Kpad, int dtype, void* stream);
+/* generic 3x3/pad1 im2col for tiny Cin (UNet conv_in, Cin = 4|8): x[B][H][W][Cin] fp32 → [B*H*W][Kpad] */
+int sx_im2col3x3_small(const float* x, void* out, int B, int H, int W, int Cin, int Kpad, int dtype,
+                       void* stream);
+/* avg_pool1d(k=4,s=4) over tokens: x[B][L][D] → y[B][L/4][D] fp32 (adapter_modules.py:112-115) */
+int sx_avgpool_tokens(const float* x, float* y, int B, int L, int D, int k, void* stream);
+/* sinusoidal timestep embedding, flip_sin_to_cos=True, shift 0 (diffusers Timesteps [ext]):
+ * out[i][:] = [cos(t_i*f_j) | sin(t_i*f_j)], f_j = exp(-ln(10000) * j / half); t_i = t[i], or t[*idx_dev] for every
+ * row when idx_dev != NULL (denoise-step counter kept on the device so the step is graph-replayable) */
+int sx_timestep_embedding(const float* t, const int32_t* idx_dev, void* out, int n, int dim, int dtype, void* stream);
+/* NCHW fp32 ↔ NHWC fp32 for the 4/8-channel latents; ld = channel stride of the NHWC side */
+int sx_nchw_to_nhwc(const float* src, float* dst, int ld, int B, int C, int HW, void* stream);
+int sx_nhwc_to_nchw(const float* src, int ld, float* dst, int B, int C, int HW, void* stream);
+/* *p += delta on the device (step / position counters of graph-replayed loops) */
+int sx_add_i32(int32_t* p, int delta, void* stream);
+
+/* Fused classifier-free guidance + Euler step on fp32 latents (NHWC [1][HW][C], n = HW*C; eps [nb][HW][C]).
+ * mode 0 (t2i, StableDiffusionXLPipeline.__call__ [ext]; order [uncond, text]):
+ *     eps = e0 + gs*(e1 - e0);  lat += eps * (sigma_next - sigma)
+ * mode 1 (edit, pipeline_stable_diffusion_xl_t2i_edit.py:926-953; order [text, image, uncond]):
+ *     x0_k = lat - sigma*e_k;  x0 = x0_u + gs*(x0_t - x0_i) + igs*(x0_i - x0_u);
+ *     eps = (x0 - lat)/(-sigma);  lat += eps * (sigma_next - sigma)
+ * Also writes the next step's scaled model input: scaled[k][hw][c] = lat_new / sqrt(sigma_next^2 + 1), k < nb,
+ * into an NHWC buffer with channel stride ld_scaled (8 for the edit UNet: channels 4..7 hold the image latents).
+ * sigmas live on the device (sigmas_dev[step], sigmas_dev[step+1]); step read from *step_dev. */
+int sx_cfg_euler_step(const float* eps, float* latents, float* scaled_next, const float* sigmas_dev,
+                      const int32_t* step_dev, int nb, int64_t n, int C, int ld_scaled, float gs, float igs, int mode,
+                      void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEEDX_HIP_H */

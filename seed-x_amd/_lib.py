@@ -1,0 +1,106 @@
+"""ctypes binding of libseedx_hip.so (C-ABI in include/seedx_hip.h).
+
+The product path FAILS LOUDLY when the HIP library is missing: there is no CPU / eager fallback here.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libseedx_hip.so")
+
+SX_F16, SX_BF16, SX_F32 = 0, 1, 2
+SX_ACT_NONE, SX_ACT_GELU, SX_ACT_SILU = 0, 1, 2
+SX_A_LINEAR, SX_A_CONV3X3 = 0, 1
+
+c_i32, c_i64, c_f32, c_vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [("A", c_vp), ("W", c_vp), ("C", c_vp), ("bias", c_vp), ("bias2d", c_vp), ("residual", c_vp),
+                ("M", c_i32), ("N", c_i32), ("K", c_i32), ("ldc", c_i32), ("ldr", c_i32), ("n_valid", c_i32),
+                ("res_mod", c_i32), ("bias2d_rows", c_i32), ("dtype", c_i32), ("out_dtype", c_i32),
+                ("act", c_i32), ("glu", c_i32), ("a_mode", c_i32),
+                ("B", c_i32), ("Hin", c_i32), ("Win", c_i32), ("Cin", c_i32), ("Hout", c_i32), ("Wout", c_i32),
+                ("stride", c_i32), ("upsample", c_i32)]
+
+
+class GemvArgs(C.Structure):
+    _fields_ = [("x", c_vp), ("W", c_vp), ("y", c_vp), ("residual", c_vp),
+                ("M", c_i32), ("N", c_i32), ("K", c_i32),
+                ("dtype", c_i32), ("out_dtype", c_i32), ("act", c_i32), ("glu", c_i32)]
+
+
+class AttnArgs(C.Structure):
+    _fields_ = [("Q", c_vp), ("K", c_vp), ("Vt", c_vp), ("O", c_vp),
+                ("B", c_i32), ("H", c_i32), ("Sq", c_i32), ("Skv", c_i32), ("D", c_i32), ("kv_pad", c_i32),
+                ("q_batch_stride", c_i64), ("q_row_stride", c_i64), ("q_head_stride", c_i64),
+                ("k_batch_stride", c_i64), ("k_row_stride", c_i64), ("k_head_stride", c_i64),
+                ("o_batch_stride", c_i64), ("o_row_stride", c_i64),
+                ("scale", c_f32), ("causal", c_i32), ("dtype", c_i32)]
+
+
+class AttnSmallArgs(C.Structure):
+    _fields_ = [("Q", c_vp), ("K", c_vp), ("V", c_vp), ("O", c_vp),
+                ("B", c_i32), ("H", c_i32), ("Sq", c_i32), ("Skv", c_i32), ("D", c_i32),
+                ("q_batch_stride", c_i64), ("q_row_stride", c_i64), ("q_head_stride", c_i64),
+                ("k_batch_stride", c_i64), ("k_row_stride", c_i64), ("k_head_stride", c_i64),
+                ("v_batch_stride", c_i64), ("v_row_stride", c_i64), ("v_head_stride", c_i64),
+                ("o_batch_stride", c_i64), ("o_row_stride", c_i64),
+                ("scale", c_f32), ("dtype", c_i32)]
+
+
+# name -> argtypes (restype is always int unless noted). Mirrors include/seedx_hip.h one to one.
+SIGNATURES = {
+    "sx_version": [],
+    "sx_gemm": [C.POINTER(GemmArgs), c_vp],
+    "sx_gemv": [C.POINTER(GemvArgs), c_vp],
+    "sx_layernorm": [c_vp, c_i32, c_vp, c_i32, c_vp, c_vp, c_i32, c_i32, c_f32, c_i32, c_vp],
+    "sx_groupnorm": [c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_i32, c_vp],
+    "sx_transpose_v": [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64, c_i64, c_i64, c_vp],
+    "sx_attention": [C.POINTER(AttnArgs), c_vp],
+    "sx_attention_small": [C.POINTER(AttnSmallArgs), c_vp],
+    "sx_attn_decode": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_i32, c_vp],
+    "sx_rope_kv_append": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp],
+    "sx_embedding": [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp],
+    "sx_scatter_rows": [c_vp, c_vp, c_vp, c_i32, c_i32, c_vp],
+    "sx_greedy_next": [c_vp, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "sx_cast": [c_vp, c_i32, c_vp, c_i32, c_i64, c_vp],
+    "sx_copy2d_f32": [c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_vp],
+    "sx_add_f32": [c_vp, c_vp, c_vp, c_i64, c_vp],
+    "sx_patchify": [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp],
+    "sx_im2col3x3_small": [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp],
+    "sx_avgpool_tokens": [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp],
+    "sx_timestep_embedding": [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp],
+    "sx_nchw_to_nhwc": [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp],
+    "sx_nhwc_to_nchw": [c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp],
+    "sx_add_i32": [c_vp, c_i32, c_vp],
+    "sx_cfg_euler_step": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_i32, c_f32, c_f32, c_i32, c_vp],
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library and bind every declared symbol. Raises if the .so or a symbol is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"seedx_amd: {LIB_PATH} not found — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback for the product path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    lib.sx_last_error.argtypes = []
+    lib.sx_last_error.restype = C.c_char_p
+    _lib = lib
+    return lib
+
+
+def check(status, what):
+    if status != 0:
+        msg = load().sx_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{what} failed (status {status}): {msg}")

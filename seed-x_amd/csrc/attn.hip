@@ -1,0 +1,406 @@
+// Fused attention for gfx950 (MI355X): flash-style MFMA kernel + V^T pre-pass + small generic VALU kernel.
+//
+// MFMA kernel:
+//   * block = 4 waves, 128 query rows (32 per wave); KV tile = 64 keys; 2-stage LDS ring filled by
+//     `buffer_load_dwordx4 … lds` DMA (K tile [64][DP], V^T tile [DP][64]); one barrier per KV tile
+//   * S^T = K · Q^T with v_mfma_f32_32x32x16: the lane that owns query q = lane&31 holds 16 of the 32
+//     scores of a key block in registers → row max / row sum are lane-local plus ONE lane^32 exchange
+//   * O^T = V^T · P^T reuses the score registers directly as the MFMA B operand: the contraction order
+//     over keys is permuted (k-slot (hi,j) ↔ key 4*hi + {0..3, 8..11}[j]) identically on the V^T side, so
+//     no cross-lane shuffle / LDS round trip of P is needed
+//   * V is transposed once per call by sx_transpose_v (V^T rows are key-contiguous), so both MFMA
+//     operands are plain "k-contiguous" LDS rows read with ds_read_b128 / ds_read_b64, XOR-swizzled
+//   * head_dim 104 (ViT-G, qwen_visual.py:170) is zero-padded to 128 only in LDS/registers via the buffer
+//     range check — HBM layout stays [.., 104]
+#include "sx_common.h"
+
+namespace sxk_attn {
+
+struct AttnP {
+  const unsigned short* Q;
+  const unsigned short* K;
+  const unsigned short* Vt;
+  unsigned short* O;
+  int B, H, Sq, Skv, D, kv_pad, q_tiles, causal;
+  long long qbs, qrs, qhs, kbs, krs, khs, obs, ors;
+  float scale_log2;
+};
+
+template <typename TT, int DP>
+__global__ __launch_bounds__(256) void attn_kernel(const AttnP p) {
+#if defined(__HIP_DEVICE_COMPILE__)  // body uses gfx950-only builtins (LDS-DMA, MFMA); the host pass only needs the stub
+  typedef typename TT::vec8 vec8;
+  typedef typename TT::vec4 vec4;
+  constexpr int KROW = DP * 2;                 // bytes per K row in LDS (128 | 256)
+  constexpr int K_BYTES = 64 * KROW;           // K tile
+  constexpr int V_BYTES = DP * 128;            // V^T tile: DP rows x 64 keys
+  constexpr int STAGE = K_BYTES + V_BYTES;
+  constexpr int K_SLOTS = K_BYTES / 1024, V_SLOTS = V_BYTES / 1024;  // 1-KiB DMA slots
+  constexpr int KCH = KROW / 16;               // 16-B chunks per K row (8 | 16)
+  constexpr int KRPS = 1024 / KROW;            // K rows per slot (8 | 4)
+  constexpr int NKS = DP / 16;                 // k-steps of the S^T MFMA
+  constexpr int NDT = DP / 32;                 // 32-wide d tiles of O^T
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5, lq = lane & 31;
+
+  const int t = xcd_remap(blockIdx.x, gridDim.x);
+  const int qt = t % p.q_tiles, bh = t / p.q_tiles;
+  const int b = bh / p.H, h = bh % p.H;
+  const int q0 = qt * 128;
+  const int coff = p.Skv - p.Sq;  // causal: key j visible iff j <= q + coff
+
+  int nt = (p.Skv + 63) / 64;
+  if (p.causal) {
+    const int last = q0 + 127 + coff;  // largest visible key of this q block
+    const int ntc = last < 0 ? 0 : last / 64 + 1;
+    nt = ntc < nt ? ntc : nt;
+  }
+
+  const unsigned short* Kb = p.K + b * p.kbs + h * p.khs;
+  const unsigned short* Vb = p.Vt + ((long long)(b * p.H + h) * p.D) * p.kv_pad;
+  const int k_bytes = (int)(((long long)(p.Skv - 1) * p.krs + p.D) * 2);
+  const int v_bytes = p.D * p.kv_pad * 2;
+  __amdgpu_buffer_rsrc_t rK = __builtin_amdgcn_make_buffer_rsrc((void*)Kb, 0, k_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc((void*)Vb, 0, v_bytes, 0x00020000);
+
+  // ---- per-lane DMA sources -------------------------------------------------------------------
+  // K: slot s holds KRPS rows; lane -> (row_in_slot, chunk position); logical chunk = pos ^ key(row)
+  unsigned k_off[K_SLOTS / 4];
+  int k_row[K_SLOTS / 4];
+#pragma unroll
+  for (int i = 0; i < K_SLOTS / 4; ++i) {
+    const int slot = wave * (K_SLOTS / 4) + i;
+    const int r = slot * KRPS + lane / KCH;  // row within the 64-key tile
+    const int pos = lane % KCH;
+    const int key = (KCH == 16) ? (r & 15) : ((r >> 1) & 7);
+    const int c = pos ^ key;
+    k_row[i] = r;
+    k_off[i] = (c * 8 < p.D) ? (unsigned)(c * 16) : 0x80000000u;
+  }
+  // V^T: slot s holds 8 rows (d) of 128 B; lane -> (row_in_slot = lane>>3, pos = lane&7), key = (d>>1)&7
+  unsigned v_off[V_SLOTS / 4];
+#pragma unroll
+  for (int i = 0; i < V_SLOTS / 4; ++i) {
+    const int slot = wave * (V_SLOTS / 4) + i;
+    const int d = slot * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((d >> 1) & 7);
+    v_off[i] = (d < p.D) ? (unsigned)(d * p.kv_pad * 2 + c * 16) : 0x80000000u;
+  }
+
+  auto stage = [&](int buf, int kvt) {
+    unsigned char* sK = smem + buf * STAGE;
+    unsigned char* sV = sK + K_BYTES;
+    const int kv0 = kvt * 64;
+#pragma unroll
+    for (int i = 0; i < K_SLOTS / 4; ++i) {
+      const int kv = kv0 + k_row[i];
+      const unsigned voff = (kv < p.Skv) ? (unsigned)((long long)kv * p.krs * 2) + k_off[i] : 0x80000000u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rK, SX_LDS_PTR(sK + (wave * (K_SLOTS / 4) + i) * 1024), 16, voff, 0,
+                                               0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < V_SLOTS / 4; ++i) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rV, SX_LDS_PTR(sV + (wave * (V_SLOTS / 4) + i) * 1024), 16,
+                                               v_off[i] + (unsigned)kv0 * 2u, 0, 0, 0);
+    }
+  };
+
+  // ---- Q fragments (B operand of S^T = K·Q^T): lane (q = lane&31, hi) holds Q[q][16ks + 8hi .. +7] ------
+  const int qrow = q0 + wave * 32 + lq;
+  vec8 qf[NKS];
+  {
+    const unsigned short* Qr = p.Q + b * p.qbs + (long long)qrow * p.qrs + h * p.qhs;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      const int d = ks * 16 + hi * 8;
+      u32x4_t raw = {0u, 0u, 0u, 0u};
+      if (qrow < p.Sq && d < p.D) raw = *(const u32x4_t*)(Qr + d);
+      __builtin_memcpy(&qf[ks], &raw, 16);
+    }
+  }
+
+  f32x16_t o[NDT];
+#pragma unroll
+  for (int i = 0; i < NDT; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  // LDS read offsets
+  // K frag (A operand): row = 32jb + (lane&31), logical chunk = 2ks + hi
+  const int kkey = (KCH == 16) ? (lq & 15) : ((lq >> 1) & 7);
+  const unsigned k_rd = (unsigned)lq * KROW;
+  // V^T frag (A operand of O^T): row d = 32dt + (lane&31); 8-B reads at chunk (4jb+2s2), (4jb+2s2+1), half hi
+  const int vkey = (lq >> 1) & 7;
+  const unsigned v_rd = (unsigned)lq * 128u + (unsigned)hi * 8u;
+
+  if (nt > 0) stage(0, 0);
+  __syncthreads();
+  for (int kvt = 0; kvt < nt; ++kvt) {
+    const int cur = kvt & 1;
+    if (kvt + 1 < nt) stage(cur ^ 1, kvt + 1);
+    const unsigned char* sK = smem + cur * STAGE;
+    const unsigned char* sV = sK + K_BYTES;
+    const int kv0 = kvt * 64;
+
+    // ---- S^T = K · Q^T ---------------------------------------------------------------------------
+    f32x16_t s[2];
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[jb][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        const vec8 kf = *(const vec8*)(sK + jb * 32 * KROW + k_rd + (((2 * ks + hi) ^ kkey) << 4));
+        s[jb] = TT::mfma32(kf, qf[ks], s[jb]);
+      }
+    }
+    // ---- online softmax (log2 domain), lane owns query row qrow ------------------------------------
+    const int kmax = p.causal ? (qrow + coff) : 0x7fffffff;
+    float mloc = -INFINITY;
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kv = kv0 + 32 * jb + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        float v = s[jb][r] * p.scale_log2;
+        if (kv >= p.Skv || kv > kmax) v = -INFINITY;
+        s[jb][r] = v;
+        mloc = fmaxf(mloc, v);
+      }
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+    const float m_new = fmaxf(m_run, mloc);
+    const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
+    const float alpha = (m_run == -INFINITY) ? 0.f : exp2f(m_run - m_safe);
+    m_run = m_new;
+    float psum = 0.f;
+    vec8 pb[4];
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        unsigned w[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float p0 = exp2f(s[jb][8 * s2 + 2 * j] - m_safe);
+          const float p1 = exp2f(s[jb][8 * s2 + 2 * j + 1] - m_safe);
+          psum += p0 + p1;
+          w[j] = pack2<TT>(p0, p1);
+        }
+        __builtin_memcpy(&pb[2 * jb + s2], w, 16);
+      }
+    l_run = l_run * alpha + psum;
+#pragma unroll
+    for (int i = 0; i < NDT; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+
+    // ---- O^T += V^T · P^T ---------------------------------------------------------------------------
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) {
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {  // kk = 2jb + s2 : 16 keys
+        const unsigned char* vr = sV + dt * 32 * 128 + v_rd;
+        const u32x2_t lo = *(const u32x2_t*)(vr + (((2 * kk) ^ vkey) << 4));
+        const u32x2_t hh = *(const u32x2_t*)(vr + (((2 * kk + 1) ^ vkey) << 4));
+        u32x4_t raw = {lo[0], lo[1], hh[0], hh[1]};
+        vec8 vf;
+        __builtin_memcpy(&vf, &raw, 16);
+        o[dt] = TT::mfma32(vf, pb[kk], o[dt]);
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: O[q][d] = o / l ------------------------------------------------------------------------
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+  if (qrow < p.Sq) {
+    unsigned short* Or = p.O + b * p.obs + (long long)qrow * p.ors + (long long)h * p.D;
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = 32 * dt + 8 * g + 4 * hi;
+        if (d < p.D) {
+          u32x2_t w;
+          w[0] = pack2<TT>(o[dt][4 * g] * inv, o[dt][4 * g + 1] * inv);
+          w[1] = pack2<TT>(o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
+          *(u32x2_t*)(Or + d) = w;
+        }
+      }
+  }
+#endif
+}
+
+// V[b][kv][h][d] (strided) -> Vt[b][h][d][kv_pad], zero padded along kv
+__global__ __launch_bounds__(256) void transpose_v_kernel(const unsigned short* V, unsigned short* Vt, int H, int Skv,
+                                                          int D, int kv_pad, long long vbs, long long vrs,
+                                                          long long vhs) {
+  __shared__ unsigned short tile[64][258];
+  const int kv0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
+  const unsigned short* Vb = V + b * vbs + h * vhs;
+  for (int idx = threadIdx.x; idx < 64 * (D / 2); idx += 256) {
+    const int r = idx / (D / 2), c2 = idx % (D / 2);
+    unsigned v = 0;
+    if (kv0 + r < Skv) v = *(const unsigned*)(Vb + (long long)(kv0 + r) * vrs + 2 * c2);
+    tile[r][2 * c2] = (unsigned short)(v & 0xffff);
+    tile[r][2 * c2 + 1] = (unsigned short)(v >> 16);
+  }
+  __syncthreads();
+  unsigned short* Ob = Vt + ((long long)(b * H + h) * D) * kv_pad + kv0;
+  for (int idx = threadIdx.x; idx < D * 32; idx += 256) {
+    const int d = idx >> 5, kp = idx & 31;
+    const unsigned w = (unsigned)tile[2 * kp][d] | ((unsigned)tile[2 * kp + 1][d] << 16);
+    *(unsigned*)(Ob + (long long)d * kv_pad + 2 * kp) = w;
+  }
+}
+
+// ---- small generic attention: one wave per (b, h, q) row; scores staged in LDS ------------------------------
+struct AttnSmallP {
+  const unsigned short* Q;
+  const unsigned short* K;
+  const unsigned short* V;
+  unsigned short* O;
+  int B, H, Sq, Skv, D;
+  long long qbs, qrs, qhs, kbs, krs, khs, vbs, vrs, vhs, obs, ors;
+  float scale;
+};
+constexpr int SMALL_MAX_KV = 1536;
+constexpr int SMALL_MAX_D = 256;
+
+template <typename TT>
+__global__ __launch_bounds__(256) void attn_small_kernel(const AttnSmallP p) {
+  __shared__ float sc[4][SMALL_MAX_KV];
+  __shared__ float qs[4][SMALL_MAX_D];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const long long row = (long long)blockIdx.x * 4 + w;
+  const long long total = (long long)p.B * p.H * p.Sq;
+  if (row >= total) return;
+  const int q = (int)(row % p.Sq);
+  const int h = (int)((row / p.Sq) % p.H);
+  const int b = (int)(row / ((long long)p.Sq * p.H));
+  const unsigned short* Qr = p.Q + b * p.qbs + (long long)q * p.qrs + h * p.qhs;
+  for (int d = lane; d < p.D; d += 64) qs[w][d] = TT::to_f32(Qr[d]) * p.scale;
+  __builtin_amdgcn_wave_barrier();
+  const unsigned short* Kb = p.K + b * p.kbs + h * p.khs;
+  float mx = -INFINITY;
+  for (int kv = lane; kv < p.Skv; kv += 64) {
+    const unsigned short* Kr = Kb + (long long)kv * p.krs;
+    float acc = 0.f;
+    for (int d = 0; d < p.D; d += 8) {
+      const u32x4_t raw = *(const u32x4_t*)(Kr + d);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        acc += TT::to_f32(raw[e] & 0xffff) * qs[w][d + 2 * e];
+        acc += TT::to_f32(raw[e] >> 16) * qs[w][d + 2 * e + 1];
+      }
+    }
+    sc[w][kv] = acc;
+    mx = fmaxf(mx, acc);
+  }
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int kv = lane; kv < p.Skv; kv += 64) {
+    const float e = __expf(sc[w][kv] - mx);
+    sc[w][kv] = e;
+    sum += e;
+  }
+  sum = wave_sum(sum);
+  __builtin_amdgcn_wave_barrier();
+  const float inv = 1.0f / sum;
+  const unsigned short* Vb = p.V + b * p.vbs + h * p.vhs;
+  unsigned short* Or = p.O + b * p.obs + (long long)q * p.ors + (long long)h * p.D;
+  for (int d2 = lane; d2 < p.D / 2; d2 += 64) {
+    float a0 = 0.f, a1 = 0.f;
+    for (int kv = 0; kv < p.Skv; ++kv) {
+      const unsigned v = *(const unsigned*)(Vb + (long long)kv * p.vrs + 2 * d2);
+      const float pr = sc[w][kv];
+      a0 += pr * TT::to_f32(v & 0xffff);
+      a1 += pr * TT::to_f32(v >> 16);
+    }
+    *(unsigned*)(Or + 2 * d2) = pack2<TT>(a0 * inv, a1 * inv);
+  }
+}
+
+}  // namespace sxk_attn
+using namespace sxk_attn;
+
+extern "C" int sx_transpose_v(const void* V, void* Vt, int B, int H, int Skv, int D, int kv_pad,
+                              int64_t v_batch_stride, int64_t v_row_stride, int64_t v_head_stride, void* stream) {
+  SX_CHECK(V && Vt, "sx_transpose_v: null pointer");
+  SX_CHECK(D % 2 == 0 && D <= 256 && kv_pad % 64 == 0 && kv_pad >= Skv, "sx_transpose_v: D=%d kv_pad=%d Skv=%d", D,
+           kv_pad, Skv);
+  SX_CHECK(v_row_stride % 2 == 0 && v_head_stride % 2 == 0 && v_batch_stride % 2 == 0, "sx_transpose_v: odd stride");
+  hipLaunchKernelGGL(transpose_v_kernel, dim3(kv_pad / 64, H, B), dim3(256), 0, (hipStream_t)stream,
+                     (const unsigned short*)V, (unsigned short*)Vt, H, Skv, D, kv_pad, (long long)v_batch_stride,
+                     (long long)v_row_stride, (long long)v_head_stride);
+  SX_HIP_LAUNCH_CHECK();
+  return SX_OK;
+}
+
+extern "C" int sx_attention(const sx_attn_args* a, void* stream) {
+  SX_CHECK(a && a->Q && a->K && a->Vt && a->O, "sx_attention: null pointer");
+  SX_CHECK(a->dtype == SX_F16 || a->dtype == SX_BF16, "sx_attention: dtype");
+  SX_CHECK(a->D % 8 == 0 && a->D >= 8 && a->D <= 128, "sx_attention: head_dim %d unsupported", a->D);
+  SX_CHECK(a->Sq > 0 && a->Skv > 0 && a->B > 0 && a->H > 0, "sx_attention: empty problem");
+  SX_CHECK(a->kv_pad % 64 == 0 && a->kv_pad >= a->Skv, "sx_attention: kv_pad");
+  SX_CHECK(a->q_row_stride % 8 == 0 && a->q_head_stride % 8 == 0 && a->q_batch_stride % 8 == 0 &&
+               a->k_row_stride % 8 == 0 && a->k_head_stride % 8 == 0 && a->k_batch_stride % 8 == 0,
+           "sx_attention: Q/K strides must be multiples of 8 elements (16 B)");
+  SX_CHECK(a->o_row_stride % 4 == 0 && a->o_batch_stride % 4 == 0, "sx_attention: O strides");
+  SX_CHECK(!a->causal || a->Skv >= a->Sq, "sx_attention: causal needs Skv >= Sq");
+  SX_CHECK(((int64_t)(a->Skv - 1) * a->k_row_stride + a->D) * 2 < 0x7fffffffll, "sx_attention: K range too large");
+  AttnP p;
+  p.Q = (const unsigned short*)a->Q; p.K = (const unsigned short*)a->K; p.Vt = (const unsigned short*)a->Vt;
+  p.O = (unsigned short*)a->O;
+  p.B = a->B; p.H = a->H; p.Sq = a->Sq; p.Skv = a->Skv; p.D = a->D; p.kv_pad = a->kv_pad;
+  p.q_tiles = (a->Sq + 127) / 128;
+  p.causal = a->causal;
+  p.qbs = a->q_batch_stride; p.qrs = a->q_row_stride; p.qhs = a->q_head_stride;
+  p.kbs = a->k_batch_stride; p.krs = a->k_row_stride; p.khs = a->k_head_stride;
+  p.obs = a->o_batch_stride; p.ors = a->o_row_stride;
+  p.scale_log2 = a->scale * 1.4426950408889634f;
+  const int grid = a->B * a->H * p.q_tiles;
+  hipStream_t st = (hipStream_t)stream;
+  const int dp = a->D <= 64 ? 64 : 128;
+  const size_t lds = 2 * (size_t)(64 * dp * 2 + dp * 128);
+  if (a->dtype == SX_BF16) {
+    if (dp == 64) hipLaunchKernelGGL((attn_kernel<BF16, 64>), dim3(grid), dim3(256), lds, st, p);
+    else hipLaunchKernelGGL((attn_kernel<BF16, 128>), dim3(grid), dim3(256), lds, st, p);
+  } else {
+    if (dp == 64) hipLaunchKernelGGL((attn_kernel<F16, 64>), dim3(grid), dim3(256), lds, st, p);
+    else hipLaunchKernelGGL((attn_kernel<F16, 128>), dim3(grid), dim3(256), lds, st, p);
+  }
+  SX_HIP_LAUNCH_CHECK();
+  return SX_OK;
+}
+
+extern "C" int sx_attention_small(const sx_attn_small_args* a, void* stream) {
+  SX_CHECK(a && a->Q && a->K && a->V && a->O, "sx_attention_small: null pointer");
+  SX_CHECK(a->dtype == SX_F16 || a->dtype == SX_BF16, "sx_attention_small: dtype");
+  SX_CHECK(a->D % 8 == 0 && a->D <= SMALL_MAX_D, "sx_attention_small: head_dim %d", a->D);
+  SX_CHECK(a->Skv > 0 && a->Skv <= SMALL_MAX_KV, "sx_attention_small: Skv=%d exceeds %d", a->Skv, SMALL_MAX_KV);
+  SX_CHECK(a->k_row_stride % 8 == 0 && a->k_head_stride % 8 == 0 && a->k_batch_stride % 8 == 0,
+           "sx_attention_small: K strides must be multiples of 8");
+  SX_CHECK(a->v_row_stride % 2 == 0 && a->v_head_stride % 2 == 0 && a->o_row_stride % 2 == 0,
+           "sx_attention_small: V/O strides must be even");
+  AttnSmallP p;
+  p.Q = (const unsigned short*)a->Q; p.K = (const unsigned short*)a->K; p.V = (const unsigned short*)a->V;
+  p.O = (unsigned short*)a->O;
+  p.B = a->B; p.H = a->H; p.Sq = a->Sq; p.Skv = a->Skv; p.D = a->D;
+  p.qbs = a->q_batch_stride; p.qrs = a->q_row_stride; p.qhs = a->q_head_stride;
+  p.kbs = a->k_batch_stride; p.krs = a->k_row_stride; p.khs = a->k_head_stride;
+  p.vbs = a->v_batch_stride; p.vrs = a->v_row_stride; p.vhs = a->v_head_stride;
+  p.obs = a->o_batch_stride; p.ors = a->o_row_stride;
+  p.scale = a->scale;
+  const long long rows = (long long)a->B * a->H * a->Sq;
+  const dim3 grid((unsigned)((rows + 3) / 4));
+  if (a->dtype == SX_BF16) hipLaunchKernelGGL(attn_small_kernel<BF16>, grid, dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(attn_small_kernel<F16>, grid, dim3(256), 0, (hipStream_t)stream, p);
+  SX_HIP_LAUNCH_CHECK();
+  return SX_OK;
+}

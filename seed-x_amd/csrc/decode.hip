@@ -1,0 +1,400 @@
+// Single-token decode path of the Llama-style LLM on gfx950: HBM-bound weight-streaming GEMV, split-KV
+// decode attention, RoPE + KV-cache append, embedding gather/scatter and the fused greedy/logits-rule step.
+// All loop state (position, current token) lives in DEVICE memory so a whole token step is hipGraph-replayable
+// with zero host round trips (the reference syncs ≥45× per token).
+#include "sx_common.h"
+
+namespace sxk_decode {
+
+// ---- GEMV: one wave per 2 weight rows (or one GLU pair), 16-B weight loads, x re-read through L1/L2 ----------
+struct GemvP {
+  const unsigned short* x;
+  const unsigned short* W;
+  void* y;
+  const float* residual;
+  int M, N, K, out_dtype, act, glu;
+};
+
+template <typename TT, int MR>
+__global__ __launch_bounds__(256) void gemv_kernel(const GemvP p) {
+  const int lane = threadIdx.x & 63;
+  const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);  // wave id = pair index
+  int r0, r1, n_out;
+  if (p.glu) {
+    // 32-row groups [16 linear | 16 gate]; pair j of group g = rows (32g + j, 32g + 16 + j)
+    const int g = wid >> 4, j = wid & 15;
+    r0 = g * 32 + j;
+    r1 = r0 + 16;
+    n_out = g * 16 + j;
+  } else {
+    r0 = wid * 2;
+    r1 = r0 + 1;
+    n_out = r0;
+  }
+  if (r0 >= p.N) return;
+  const bool has1 = r1 < p.N;
+  const int nch = p.K >> 3;  // 16-B chunks per row
+  const u32x4_t* w0 = (const u32x4_t*)(p.W + (size_t)r0 * p.K);
+  const u32x4_t* w1 = (const u32x4_t*)(p.W + (size_t)(has1 ? r1 : r0) * p.K);
+  float acc0[MR], acc1[MR];
+#pragma unroll
+  for (int m = 0; m < MR; ++m) { acc0[m] = 0.f; acc1[m] = 0.f; }
+  for (int c = lane; c < nch; c += 64) {
+    const u32x4_t a = __builtin_nontemporal_load(w0 + c);
+    const u32x4_t b = __builtin_nontemporal_load(w1 + c);
+#pragma unroll
+    for (int m = 0; m < MR; ++m) {
+      const int mm = m < p.M ? m : p.M - 1;
+      const u32x4_t xv = *(const u32x4_t*)(p.x + (size_t)mm * p.K + (size_t)c * 8);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float x0 = TT::to_f32(xv[e] & 0xffff), x1 = TT::to_f32(xv[e] >> 16);
+        acc0[m] += TT::to_f32(a[e] & 0xffff) * x0 + TT::to_f32(a[e] >> 16) * x1;
+        acc1[m] += TT::to_f32(b[e] & 0xffff) * x0 + TT::to_f32(b[e] >> 16) * x1;
+      }
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < MR; ++m) {
+    acc0[m] = wave_sum(acc0[m]);
+    acc1[m] = wave_sum(acc1[m]);
+  }
+  if (lane == 0) {
+    const int ncols = p.glu ? p.N / 2 : p.N;
+#pragma unroll
+    for (int m = 0; m < MR; ++m) {
+      if (m >= p.M) break;
+      float v0, v1 = 0.f;
+      if (p.glu) {
+        v0 = acc0[m] * apply_act(acc1[m], p.act);
+      } else {
+        v0 = apply_act(acc0[m], p.act);
+        v1 = apply_act(acc1[m], p.act);
+      }
+      const size_t o = (size_t)m * ncols + n_out;
+      if (p.residual) {
+        v0 += p.residual[o];
+        if (!p.glu && has1) v1 += p.residual[o + 1];
+      }
+      if (p.out_dtype == SX_F32) {
+        ((float*)p.y)[o] = v0;
+        if (!p.glu && has1) ((float*)p.y)[o + 1] = v1;
+      } else {
+        unsigned short* yy = (unsigned short*)p.y;
+        yy[o] = p.out_dtype == SX_BF16 ? BF16::from_f32(v0) : F16::from_f32(v0);
+        if (!p.glu && has1) yy[o + 1] = p.out_dtype == SX_BF16 ? BF16::from_f32(v1) : F16::from_f32(v1);
+      }
+    }
+  }
+}
+
+// ---- decode attention: grid (H, nsplit); 16-lane groups own one key row per iteration ---------------------------
+template <typename TT>
+__global__ __launch_bounds__(256) void attn_decode_kernel(const unsigned short* q, const unsigned short* kc,
+                                                          const unsigned short* vc, float* scratch,
+                                                          const int* ctx_len_dev, int D, int Tmax, int nsplit,
+                                                          float scale) {
+  __shared__ float red[16][132];  // 16 lane-groups x (D<=128 outputs + m + l)
+  const int h = blockIdx.x, sp = blockIdx.y;
+  const int ctx = *ctx_len_dev;
+  const int chunk = (ctx + nsplit - 1) / nsplit;
+  const int t0 = sp * chunk, t1 = min(ctx, t0 + chunk);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int grp = wave * 4 + (lane >> 4);  // 0..15
+  const int dl = lane & 15;                // 16-B chunk of the head dim (8 elements); D = 128 → 16 chunks
+  const bool dvalid = dl * 8 < D;
+  float qv[8];
+  {
+    u32x4_t raw = {0u, 0u, 0u, 0u};
+    if (dvalid) raw = *(const u32x4_t*)(q + (size_t)h * D + dl * 8);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      qv[2 * e] = TT::to_f32(raw[e] & 0xffff) * scale;
+      qv[2 * e + 1] = TT::to_f32(raw[e] >> 16) * scale;
+    }
+  }
+  float m_run = -INFINITY, l_run = 0.f, o[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = 0.f;
+  const unsigned short* kh = kc + (size_t)h * Tmax * D;
+  const unsigned short* vh = vc + (size_t)h * Tmax * D;
+  for (int t = t0 + grp; t < t1; t += 16) {
+    u32x4_t kr = {0u, 0u, 0u, 0u}, vr = {0u, 0u, 0u, 0u};
+    if (dvalid) {
+      kr = *(const u32x4_t*)(kh + (size_t)t * D + dl * 8);
+      vr = *(const u32x4_t*)(vh + (size_t)t * D + dl * 8);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      s += TT::to_f32(kr[e] & 0xffff) * qv[2 * e] + TT::to_f32(kr[e] >> 16) * qv[2 * e + 1];
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    s += __shfl_xor(s, 4, 64);
+    s += __shfl_xor(s, 8, 64);
+    const float m_new = fmaxf(m_run, s);
+    const float alpha = __expf(m_run - m_new);  // exp(-inf) = 0 on the first key
+    const float pr = __expf(s - m_new);
+    l_run = l_run * alpha + pr;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      o[2 * e] = o[2 * e] * alpha + pr * TT::to_f32(vr[e] & 0xffff);
+      o[2 * e + 1] = o[2 * e + 1] * alpha + pr * TT::to_f32(vr[e] >> 16);
+    }
+    m_run = m_new;
+  }
+  if (dvalid) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[grp][dl * 8 + e] = o[e];
+  }
+  if (dl == 0) {
+    red[grp][128] = m_run;
+    red[grp][129] = l_run;
+  }
+  __syncthreads();
+  // combine the 16 groups: thread d < D
+  const int d = threadIdx.x;
+  float* out = scratch + ((size_t)h * nsplit + sp) * (D + 2);
+  float mg = -INFINITY;
+#pragma unroll
+  for (int g = 0; g < 16; ++g) mg = fmaxf(mg, red[g][128]);
+  if (d < D) {
+    float acc = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      const float mgk = red[g][128];
+      const float w = (mgk == -INFINITY) ? 0.f : __expf(mgk - mg);
+      acc += w * red[g][d];
+    }
+    out[d] = acc;
+  }
+  if (d == 0) {
+    float lsum = 0.f;
+    for (int g = 0; g < 16; ++g) {
+      const float mgk = red[g][128];
+      lsum += (mgk == -INFINITY) ? 0.f : __expf(mgk - mg) * red[g][129];
+    }
+    out[D] = mg;
+    out[D + 1] = lsum;
+  }
+}
+
+template <typename TT>
+__global__ void attn_decode_combine_kernel(const float* scratch, unsigned short* out, int D, int nsplit) {
+  const int h = blockIdx.x, d = threadIdx.x;
+  if (d >= D) return;
+  const float* base = scratch + (size_t)h * nsplit * (D + 2);
+  float mg = -INFINITY;
+  for (int s = 0; s < nsplit; ++s) mg = fmaxf(mg, base[(size_t)s * (D + 2) + D]);
+  float acc = 0.f, l = 0.f;
+  for (int s = 0; s < nsplit; ++s) {
+    const float ms = base[(size_t)s * (D + 2) + D];
+    const float w = (ms == -INFINITY) ? 0.f : __expf(ms - mg);
+    acc += w * base[(size_t)s * (D + 2) + d];
+    l += w * base[(size_t)s * (D + 2) + D + 1];
+  }
+  out[(size_t)h * D + d] = TT::from_f32(l > 0.f ? acc / l : 0.f);
+}
+
+// ---- RoPE + KV append ----------------------------------------------------------------------------------------------
+template <typename TT>
+__global__ void rope_kv_append_kernel(unsigned short* qkv, unsigned short* kc, unsigned short* vc, const float* cos_t,
+                                      const float* sin_t, const int* pos0_dev, int T, int H, int D, int Tmax) {
+  const int half = D / 2;
+  const int pos0 = *pos0_dev;
+  const int64_t total = (int64_t)T * H * half;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int j = (int)(i % half);
+    const int h = (int)((i / half) % H);
+    const int t = (int)(i / ((int64_t)half * H));
+    const int pos = pos0 + t;
+    // tables are rounded to the activation dtype before use (modeling_llama_xformer.py:128-131)
+    const float c = TT::to_f32(TT::from_f32(cos_t[(size_t)pos * half + j]));
+    const float s = TT::to_f32(TT::from_f32(sin_t[(size_t)pos * half + j]));
+    unsigned short* row = qkv + (size_t)t * 3 * H * D;
+    unsigned short* qh = row + (size_t)h * D;
+    const unsigned short* kh = row + (size_t)(H + h) * D;
+    const unsigned short* vh = row + (size_t)(2 * H + h) * D;
+    const float q1 = TT::to_f32(qh[j]), q2 = TT::to_f32(qh[j + half]);
+    qh[j] = TT::from_f32(q1 * c - q2 * s);
+    qh[j + half] = TT::from_f32(q2 * c + q1 * s);
+    const float k1 = TT::to_f32(kh[j]), k2 = TT::to_f32(kh[j + half]);
+    unsigned short* kd = kc + ((size_t)h * Tmax + pos) * D;
+    unsigned short* vd = vc + ((size_t)h * Tmax + pos) * D;
+    kd[j] = TT::from_f32(k1 * c - k2 * s);
+    kd[j + half] = TT::from_f32(k2 * c + k1 * s);
+    vd[j] = vh[j];
+    vd[j + half] = vh[j + half];
+  }
+}
+
+template <typename TT>
+__global__ void embedding_kernel(const int* ids, const unsigned short* table, float* out, int T, int dim) {
+  const int64_t total = (int64_t)T * dim;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int t = (int)(i / dim), d = (int)(i % dim);
+    out[i] = TT::to_f32(table[(size_t)ids[t] * dim + d]);
+  }
+}
+
+__global__ void scatter_rows_kernel(const float* src, const int* rows, float* dst, int n, int dim) {
+  const int64_t total = (int64_t)n * dim;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / dim), d = (int)(i % dim);
+    dst[(size_t)rows[r] * dim + d] = src[i];
+  }
+}
+
+// ---- greedy next token with the AutoImageTokenGenerationProcessor rule (generation.py:19-31) ------------------------
+__global__ __launch_bounds__(1024) void greedy_next_kernel(float* logits, int vocab, const int* img_ids, int n_img,
+                                                           const int* prev_id, int* next_id, int* out_ids,
+                                                           const int* step_dev) {
+  __shared__ float smax[16];
+  __shared__ int sidx[16];
+  __shared__ int forced;
+  const int prev = *prev_id;
+  if (threadIdx.x == 0) forced = -1;
+  __syncthreads();
+  // prev in img_ids[:-1] → force the next id of the chain (scores[next] = max + 10 in the reference)
+  if ((int)threadIdx.x < n_img - 1 && img_ids[threadIdx.x] == prev) atomicMax(&forced, (int)threadIdx.x);
+  __syncthreads();
+  int result;
+  if (forced >= 0) {
+    // list.index() returns the FIRST match; ids are unique so max == first
+    result = img_ids[forced + 1];
+  } else {
+    if ((int)threadIdx.x < n_img - 1) logits[img_ids[1 + threadIdx.x]] = 0.0f;
+    __syncthreads();
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = threadIdx.x; i < vocab; i += 1024) {
+      const float v = logits[i];
+      if (v > best || (v == best && i < bi)) { best = v; bi = i; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(best, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if ((threadIdx.x & 63) == 0) { smax[threadIdx.x >> 6] = best; sidx[threadIdx.x >> 6] = bi; }
+    __syncthreads();
+    best = smax[0];
+    bi = sidx[0];
+    for (int w = 1; w < 16; ++w)
+      if (smax[w] > best || (smax[w] == best && sidx[w] < bi)) { best = smax[w]; bi = sidx[w]; }
+    result = bi;
+  }
+  if (threadIdx.x == 0) {
+    *next_id = result;
+    if (out_ids) out_ids[*step_dev] = result;
+  }
+}
+
+inline dim3 gs_grid(int64_t n) {
+  int64_t b = (n + 255) / 256;
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  return dim3((unsigned)b);
+}
+
+}  // namespace sxk_decode
+using namespace sxk_decode;
+
+#define ST ((hipStream_t)stream)
+
+extern "C" int sx_gemv(const sx_gemv_args* a, void* stream) {
+  SX_CHECK(a && a->x && a->W && a->y, "sx_gemv: null pointer");
+  SX_CHECK(a->dtype == SX_F16 || a->dtype == SX_BF16, "sx_gemv: dtype");
+  SX_CHECK(a->M >= 1 && a->M <= 8, "sx_gemv: M=%d must be 1..8", a->M);
+  SX_CHECK(a->K % 8 == 0 && a->N > 0, "sx_gemv: K %% 8");
+  SX_CHECK(!a->glu || a->N % 32 == 0, "sx_gemv: glu needs N %% 32 == 0");
+  GemvP p;
+  p.x = (const unsigned short*)a->x; p.W = (const unsigned short*)a->W; p.y = a->y; p.residual = a->residual;
+  p.M = a->M; p.N = a->N; p.K = a->K; p.out_dtype = a->out_dtype; p.act = a->act; p.glu = a->glu;
+  const int pairs = (a->N + 1) / 2;
+  const dim3 grid((pairs + 3) / 4), block(256);
+  const int mr = a->M == 1 ? 1 : (a->M == 2 ? 2 : (a->M <= 4 ? 4 : 8));
+#define SX_GEMV_GO(TT)                                                                          \
+  switch (mr) {                                                                                 \
+    case 1: hipLaunchKernelGGL((gemv_kernel<TT, 1>), grid, block, 0, ST, p); break;             \
+    case 2: hipLaunchKernelGGL((gemv_kernel<TT, 2>), grid, block, 0, ST, p); break;             \
+    case 4: hipLaunchKernelGGL((gemv_kernel<TT, 4>), grid, block, 0, ST, p); break;             \
+    default: hipLaunchKernelGGL((gemv_kernel<TT, 8>), grid, block, 0, ST, p); break;            \
+  }
+  if (a->dtype == SX_BF16) { SX_GEMV_GO(BF16) } else { SX_GEMV_GO(F16) }
+#undef SX_GEMV_GO
+  SX_HIP_LAUNCH_CHECK();
+  return SX_OK;
+}
+
+extern "C" int sx_attn_decode(const void* q, const void* kcache, const void* vcache, void* out, float* scratch,
+                              const int32_t* ctx_len_dev, int H, int D, int Tmax, int nsplit, float scale, int dtype,
+                              void* stream) {
+  SX_CHECK(q && kcache && vcache && out && scratch && ctx_len_dev, "sx_attn_decode: null pointer");
+  SX_CHECK(D % 8 == 0 && D <= 128, "sx_attn_decode: head_dim %d", D);
+  SX_CHECK(nsplit >= 1 && nsplit <= 64, "sx_attn_decode: nsplit");
+  if (dtype == SX_BF16) {
+    hipLaunchKernelGGL(attn_decode_kernel<BF16>, dim3(H, nsplit), dim3(256), 0, ST, (const unsigned short*)q,
+                       (const unsigned short*)kcache, (const unsigned short*)vcache, scratch, ctx_len_dev, D, Tmax,
+                       nsplit, scale);
+    hipLaunchKernelGGL(attn_decode_combine_kernel<BF16>, dim3(H), dim3(128), 0, ST, scratch, (unsigned short*)out, D,
+                       nsplit);
+  } else {
+    hipLaunchKernelGGL(attn_decode_kernel<F16>, dim3(H, nsplit), dim3(256), 0, ST, (const unsigned short*)q,
+                       (const unsigned short*)kcache, (const unsigned short*)vcache, scratch, ctx_len_dev, D, Tmax,
+                       nsplit, scale);
+    hipLaunchKernelGGL(attn_decode_combine_kernel<F16>, dim3(H), dim3(128), 0, ST, scratch, (unsigned short*)out, D,
+                       nsplit);
+  }
+  SX_HIP_LAUNCH_CHECK();
+  return SX_OK;
+}
+
+extern "C" int sx_rope_kv_append(void* qkv, void* kcache, void* vcache, const float* cos_tab, const float* sin_tab,
+                                 const int32_t* pos0_dev, int T, int H, int D, int Tmax, int dtype, void* stream) {
+  SX_CHECK(qkv && kcache && vcache && cos_tab && sin_tab && pos0_dev, "sx_rope_kv_append: null pointer");
+  SX_CHECK(D % 2 == 0, "sx_rope_kv_append: D");
+  const int64_t n = (int64_t)T * H * (D / 2);
+  if (dtype == SX_BF16)
+    hipLaunchKernelGGL(rope_kv_append_kernel<BF16>, gs_grid(n), dim3(256), 0, ST, (unsigned short*)qkv,
+                       (unsigned short*)kcache, (unsigned short*)vcache, cos_tab, sin_tab, pos0_dev, T, H, D, Tmax);
+  else
+    hipLaunchKernelGGL(rope_kv_append_kernel<F16>, gs_grid(n), dim3(256), 0, ST, (unsigned short*)qkv,
+                       (unsigned short*)kcache, (unsigned short*)vcache, cos_tab, sin_tab, pos0_dev, T, H, D, Tmax);
+  SX_HIP_LAUNCH_CHECK();
+  return SX_OK;
+}
+
+extern "C" int sx_embedding(const int32_t* ids, const void* table, float* out, int T, int dim, int dtype,
+                            void* stream) {
+  SX_CHECK(ids && table && out, "sx_embedding: null pointer");
+  if (dtype == SX_BF16)
+    hipLaunchKernelGGL(embedding_kernel<BF16>, gs_grid((int64_t)T * dim), dim3(256), 0, ST, ids,
+                       (const unsigned short*)table, out, T, dim);
+  else
+    hipLaunchKernelGGL(embedding_kernel<F16>, gs_grid((int64_t)T * dim), dim3(256), 0, ST, ids,
+                       (const unsigned short*)table, out, T, dim);
+  SX_HIP_LAUNCH_CHECK();
+  return SX_OK;
+}
+
+extern "C" int sx_scatter_rows(const float* src, const int32_t* rows, float* dst, int n, int dim, void* stream) {
+  SX_CHECK(src && rows && dst, "sx_scatter_rows: null pointer");
+  if (n == 0) return SX_OK;
+  hipLaunchKernelGGL(scatter_rows_kernel, gs_grid((int64_t)n * dim), dim3(256), 0, ST, src, rows, dst, n, dim);
+  SX_HIP_LAUNCH_CHECK();
+  return SX_OK;
+}
+
+extern "C" int sx_greedy_next(float* logits, int vocab, const int32_t* img_ids_dev, int n_img,
+                              const int32_t* prev_id_dev, int32_t* next_id_dev, int32_t* out_ids,
+                              const int32_t* step_dev, void* stream) {
+  SX_CHECK(logits && img_ids_dev && prev_id_dev && next_id_dev, "sx_greedy_next: null pointer");
+  SX_CHECK(n_img >= 2 && n_img <= 1024, "sx_greedy_next: n_img=%d", n_img);
+  SX_CHECK(!out_ids || step_dev, "sx_greedy_next: out_ids needs step_dev");
+  hipLaunchKernelGGL(greedy_next_kernel, dim3(1), dim3(1024), 0, ST, logits, vocab, img_ids_dev, n_img, prev_id_dev,
+                     next_id_dev, out_ids, step_dev);
+  SX_HIP_LAUNCH_CHECK();
+  return SX_OK;
+}

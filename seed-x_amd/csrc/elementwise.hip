@@ -1,0 +1,266 @@
+// Elementwise / layout kernels (HBM-bound; vectorised 8–16 B per lane, grid-stride).
+#include <stdarg.h>
+#include "sx_common.h"
+
+// ---- error plumbing (shared by all translation units) -----------------------------------------------
+static thread_local char g_err[512] = "";
+void sx_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* sx_last_error(void) { return g_err; }
+extern "C" int sx_version(void) { return 1; }
+
+namespace sxk_elementwise {
+
+inline dim3 grid_for(int64_t n, int per_thread = 1) {
+  int64_t blocks = (n + (int64_t)256 * per_thread - 1) / ((int64_t)256 * per_thread);
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  return dim3((unsigned)blocks);
+}
+
+__device__ __forceinline__ float ld_as_f32(const void* p, int dt, int64_t i) {
+  if (dt == SX_F32) return ((const float*)p)[i];
+  const unsigned short u = ((const unsigned short*)p)[i];
+  return dt == SX_BF16 ? BF16::to_f32(u) : F16::to_f32(u);
+}
+__device__ __forceinline__ void st_from_f32(void* p, int dt, int64_t i, float v) {
+  if (dt == SX_F32) ((float*)p)[i] = v;
+  else ((unsigned short*)p)[i] = dt == SX_BF16 ? BF16::from_f32(v) : F16::from_f32(v);
+}
+
+__global__ void cast_kernel(const void* src, int sdt, void* dst, int ddt, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t n4 = n >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) st_from_f32(dst, ddt, 4 * i + e, ld_as_f32(src, sdt, 4 * i + e));
+  }
+  for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    st_from_f32(dst, ddt, i, ld_as_f32(src, sdt, i));
+}
+
+__global__ void copy2d_kernel(const float* src, int64_t sld, float* dst, int64_t dld, int64_t rows, int cols4) {
+  const int64_t total = rows * cols4;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int64_t r = i / cols4;
+    const int c = (int)(i - r * cols4);
+    *(f32x4_t*)(dst + r * dld + 4 * c) = *(const f32x4_t*)(src + r * sld + 4 * c);
+  }
+}
+
+__global__ void add_kernel(const float* a, const float* b, float* y, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) y[i] = a[i] + b[i];
+}
+
+// img[B][3][S][S] fp32 -> patches[B*G*G][Kpad], k = c*P*P + py*P + px (conv1 weight [width][3][P][P] flattened)
+template <typename TT>
+__global__ void patchify_kernel(const float* img, unsigned short* out, int B, int S, int P, int Kpad) {
+  const int G = S / P, K = 3 * P * P;
+  const int64_t total = (int64_t)B * G * G * Kpad;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int k = (int)(i % Kpad);
+    const int64_t row = i / Kpad;
+    float v = 0.f;
+    if (k < K) {
+      const int gx = (int)(row % G), gy = (int)((row / G) % G), b = (int)(row / ((int64_t)G * G));
+      const int c = k / (P * P), rem = k % (P * P), py = rem / P, px = rem % P;
+      v = img[(((int64_t)b * 3 + c) * S + (gy * P + py)) * S + gx * P + px];
+    }
+    out[i] = TT::from_f32(v);
+  }
+}
+
+// x[B][H][W][Cin] fp32 -> out[B*H*W][Kpad], k = (ky*3 + kx)*Cin + c, zero padding outside the image
+template <typename TT>
+__global__ void im2col3x3_kernel(const float* x, unsigned short* out, int B, int H, int W, int Cin, int Kpad) {
+  const int K = 9 * Cin;
+  const int64_t total = (int64_t)B * H * W * Kpad;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int k = (int)(i % Kpad);
+    const int64_t row = i / Kpad;
+    float v = 0.f;
+    if (k < K) {
+      const int ox = (int)(row % W), oy = (int)((row / W) % H), b = (int)(row / ((int64_t)W * H));
+      const int tap = k / Cin, c = k % Cin, iy = oy + tap / 3 - 1, ix = ox + tap % 3 - 1;
+      if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = x[(((int64_t)b * H + iy) * W + ix) * Cin + c];
+    }
+    out[i] = TT::from_f32(v);
+  }
+}
+
+__global__ void avgpool_tokens_kernel(const float* x, float* y, int B, int L, int D, int k) {
+  const int Lo = L / k;
+  const int64_t total = (int64_t)B * Lo * D;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const float inv = 1.0f / (float)k;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int d = (int)(i % D);
+    const int64_t t = i / D;
+    const int lo = (int)(t % Lo), b = (int)(t / Lo);
+    float s = 0.f;
+    for (int j = 0; j < k; ++j) s += x[((int64_t)b * L + lo * k + j) * D + d];
+    y[i] = s * inv;
+  }
+}
+
+__global__ void timestep_embedding_kernel(const float* t, const int* idx_dev, void* out, int n, int dim, int dt) {
+  const int half = dim / 2;
+  const int fixed = idx_dev ? *idx_dev : -1;
+  const int total = n * half;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int j = i % half, r = i / half;
+    const float f = expf(-9.210340371976184f * (float)j / (float)half);  // ln(10000)
+    const float a = (fixed >= 0 ? t[fixed] : t[r]) * f;
+    st_from_f32(out, dt, (int64_t)r * dim + j, cosf(a));          // flip_sin_to_cos: cos first
+    st_from_f32(out, dt, (int64_t)r * dim + half + j, sinf(a));
+  }
+}
+
+__global__ void nchw_to_nhwc_kernel(const float* src, float* dst, int ld, int B, int C, int HW) {
+  const int64_t total = (int64_t)B * C * HW;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int c = (int)(i % C);
+    const int64_t t = i / C;
+    const int hw = (int)(t % HW), b = (int)(t / HW);
+    dst[((int64_t)b * HW + hw) * ld + c] = src[((int64_t)b * C + c) * HW + hw];
+  }
+}
+__global__ void nhwc_to_nchw_kernel(const float* src, int ld, float* dst, int B, int C, int HW) {
+  const int64_t total = (int64_t)B * C * HW;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int hw = (int)(i % HW);
+    const int64_t t = i / HW;
+    const int c = (int)(t % C), b = (int)(t / C);
+    dst[i] = src[((int64_t)b * HW + hw) * ld + c];
+  }
+}
+
+__global__ void cfg_euler_kernel(const float* eps, float* lat, float* scaled_next, const float* sigmas,
+                                 const int* step_dev, int nb, int64_t n, int C, int ld, float gs, float igs,
+                                 int mode) {
+  const int step = *step_dev;
+  const float sigma = sigmas[step], sigma_next = sigmas[step + 1];
+  const float inv_next = rsqrtf(sigma_next * sigma_next + 1.0f);
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float x = lat[i];
+    float e;
+    if (mode == 0) {
+      const float eu = eps[i], et = eps[n + i];
+      e = eu + gs * (et - eu);
+    } else {
+      const float x0t = x - sigma * eps[i], x0i = x - sigma * eps[n + i], x0u = x - sigma * eps[2 * n + i];
+      const float x0 = x0u + gs * (x0t - x0i) + igs * (x0i - x0u);
+      e = (x0 - x) / (-sigma);
+    }
+    const float xn = x + e * (sigma_next - sigma);
+    lat[i] = xn;
+    if (scaled_next) {
+      const float sv = xn * inv_next;
+      const int64_t hw = i / C;
+      const int c = (int)(i - hw * C);
+      const int64_t HW = n / C;
+      for (int k = 0; k < nb; ++k) scaled_next[((int64_t)k * HW + hw) * ld + c] = sv;
+    }
+  }
+}
+
+__global__ void add_i32_kernel(int* p, int delta) { *p += delta; }
+
+}  // namespace sxk_elementwise
+using namespace sxk_elementwise;
+
+#define ST ((hipStream_t)stream)
+
+extern "C" int sx_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, void* stream) {
+  SX_CHECK(src && dst && n >= 0, "sx_cast: bad args");
+  if (n == 0) return SX_OK;
+  hipLaunchKernelGGL(cast_kernel, grid_for(n, 4), dim3(256), 0, ST, src, src_dtype, dst, dst_dtype, n);
+  SX_HIP_LAUNCH_CHECK();
+  return SX_OK;
+}
+extern "C" int sx_copy2d_f32(const float* src, int64_t src_ld, float* dst, int64_t dst_ld, int64_t rows, int cols,
+                             void* stream) {
+  SX_CHECK(src && dst && cols % 4 == 0 && src_ld % 4 == 0 && dst_ld % 4 == 0, "sx_copy2d_f32: need multiples of 4");
+  hipLaunchKernelGGL(copy2d_kernel, grid_for(rows * (cols / 4)), dim3(256), 0, ST, src, src_ld, dst, dst_ld, rows,
+                     cols / 4);
+  SX_HIP_LAUNCH_CHECK();
+  return SX_OK;
+}
+extern "C" int sx_add_f32(const float* a, const float* b, float* y, int64_t n, void* stream) {
+  SX_CHECK(a && b && y, "sx_add_f32: null");
+  hipLaunchKernelGGL(add_kernel, grid_for(n), dim3(256), 0, ST, a, b, y, n);
+  SX_HIP_LAUNCH_CHECK();
+  return SX_OK;
+}
+extern "C" int sx_patchify(const float* img, void* patches, int B, int S, int P, int Kpad, int dtype, void* stream) {
+  SX_CHECK(img && patches && S % P == 0 && Kpad >= 3 * P * P, "sx_patchify: bad geometry");
+  const int64_t n = (int64_t)B * (S / P) * (S / P) * Kpad;
+  if (dtype == SX_BF16)
+    hipLaunchKernelGGL(patchify_kernel<BF16>, grid_for(n), dim3(256), 0, ST, img, (unsigned short*)patches, B, S, P, Kpad);
+  else
+    hipLaunchKernelGGL(patchify_kernel<F16>, grid_for(n), dim3(256), 0, ST, img, (unsigned short*)patches, B, S, P, Kpad);
+  SX_HIP_LAUNCH_CHECK();
+  return SX_OK;
+}
+extern "C" int sx_im2col3x3_small(const float* x, void* out, int B, int H, int W, int Cin, int Kpad, int dtype,
+                                  void* stream) {
+  SX_CHECK(x && out && Kpad >= 9 * Cin, "sx_im2col3x3_small: Kpad too small");
+  const int64_t n = (int64_t)B * H * W * Kpad;
+  if (dtype == SX_BF16)
+    hipLaunchKernelGGL(im2col3x3_kernel<BF16>, grid_for(n), dim3(256), 0, ST, x, (unsigned short*)out, B, H, W, Cin, Kpad);
+  else
+    hipLaunchKernelGGL(im2col3x3_kernel<F16>, grid_for(n), dim3(256), 0, ST, x, (unsigned short*)out, B, H, W, Cin, Kpad);
+  SX_HIP_LAUNCH_CHECK();
+  return SX_OK;
+}
+extern "C" int sx_avgpool_tokens(const float* x, float* y, int B, int L, int D, int k, void* stream) {
+  SX_CHECK(x && y && k > 0 && L % k == 0, "sx_avgpool_tokens: L %% k != 0");
+  hipLaunchKernelGGL(avgpool_tokens_kernel, grid_for((int64_t)B * (L / k) * D), dim3(256), 0, ST, x, y, B, L, D, k);
+  SX_HIP_LAUNCH_CHECK();
+  return SX_OK;
+}
+extern "C" int sx_timestep_embedding(const float* t, const int32_t* idx_dev, void* out, int n, int dim, int dtype,
+                                     void* stream) {
+  SX_CHECK(t && out && dim % 2 == 0, "sx_timestep_embedding: dim must be even");
+  hipLaunchKernelGGL(timestep_embedding_kernel, grid_for((int64_t)n * dim / 2), dim3(256), 0, ST, t, idx_dev, out, n, dim, dtype);
+  SX_HIP_LAUNCH_CHECK();
+  return SX_OK;
+}
+extern "C" int sx_nchw_to_nhwc(const float* src, float* dst, int ld, int B, int C, int HW, void* stream) {
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, grid_for((int64_t)B * C * HW), dim3(256), 0, ST, src, dst, ld, B, C, HW);
+  SX_HIP_LAUNCH_CHECK();
+  return SX_OK;
+}
+extern "C" int sx_nhwc_to_nchw(const float* src, int ld, float* dst, int B, int C, int HW, void* stream) {
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, grid_for((int64_t)B * C * HW), dim3(256), 0, ST, src, ld, dst, B, C, HW);
+  SX_HIP_LAUNCH_CHECK();
+  return SX_OK;
+}
+extern "C" int sx_cfg_euler_step(const float* eps, float* latents, float* scaled_next, const float* sigmas_dev,
+                                 const int32_t* step_dev, int nb, int64_t n, int C, int ld_scaled, float gs,
+                                 float igs, int mode, void* stream) {
+  SX_CHECK(eps && latents && sigmas_dev && step_dev, "sx_cfg_euler_step: null pointer");
+  SX_CHECK((mode == 0 && nb == 2) || (mode == 1 && nb == 3), "sx_cfg_euler_step: mode/nb mismatch");
+  SX_CHECK(C > 0 && n % C == 0 && ld_scaled >= C, "sx_cfg_euler_step: C/ld");
+  hipLaunchKernelGGL(cfg_euler_kernel, grid_for(n), dim3(256), 0, ST, eps, latents, scaled_next, sigmas_dev, step_dev,
+                     nb, n, C, ld_scaled, gs, igs, mode);
+  SX_HIP_LAUNCH_CHECK();
+  return SX_OK;
+}
+extern "C" int sx_add_i32(int32_t* p, int delta, void* stream) {
+  SX_CHECK(p, "sx_add_i32: null");
+  hipLaunchKernelGGL(add_i32_kernel, dim3(1), dim3(1), 0, ST, p, delta);
+  SX_HIP_LAUNCH_CHECK();
+  return SX_OK;
+}

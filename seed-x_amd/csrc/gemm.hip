@@ -1,0 +1,314 @@
+// MFMA GEMM / implicit-GEMM 3x3 convolution for gfx950 (MI355X).
+//
+//   C[M][N] = epilogue( A[M][K] · W[N][K]^T ),  16-bit inputs (fp16 | bf16), fp32 accumulate.
+//
+// Replaces every nn.Linear / nn.Conv2d(3x3) on the SEED-X hot path (see include/seedx_hip.h for the
+// reference call sites). Design:
+//   * block = 4 waves (2x2), tile BM x BN x 64; each wave owns (BM/2)x(BN/2) as 16x16x32 MFMA fragments
+//   * A and W tiles are DMA'd HBM→LDS with `buffer_load_dwordx4 … lds` (no VGPR round trip); rows
+//     beyond M / N and zero-padding taps of the convolution use the buffer descriptor's range check
+//     (offset >= num_records returns 0), so there is no edge code in the main loop
+//   * LDS rows are 128 B (64 k-elements); the 16-B chunk index is XOR-swizzled with (row & 7). The DMA
+//     destination is lane-linear, so the swizzle is applied to the per-lane SOURCE address and again on
+//     the ds_read_b128 side (same involution) → conflict-free fragment reads
+//   * 2-stage LDS ring, one barrier per k-tile: next tile's DMA is issued before the MFMAs of the current
+//   * operands are swapped in the MFMA (D = Wfrag · Afrag^T) so a lane ends up with 4 CONSECUTIVE output
+//     columns of one row → vector bias/residual loads and 8/16-byte stores in the fused epilogue
+//   * 1-D grid with a bijective XCD remap: consecutive tiles (same W panel) share one XCD's L2
+#include "sx_common.h"
+
+namespace sxk_gemm {
+
+struct GemmP {
+  const void* A;
+  const void* W;
+  void* C;
+  const float* bias;
+  const float* bias2d;
+  const float* residual;
+  int M, N, K, ldc, ldr, n_valid, res_mod, bias2d_rows, out_dtype, act, glu;
+  int Hin, Win, Cin, Hout, Wout, stride, upsample;
+  int tiles_m, tiles_n;
+  unsigned a_bytes, w_bytes;
+};
+
+template <typename TT, int BM, int BN, int AMODE>
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
+#if defined(__HIP_DEVICE_COMPILE__)  // body uses gfx950-only builtins (LDS-DMA, MFMA); the host pass only needs the stub
+  typedef typename TT::vec8 vec8;
+  constexpr int FM = BM / 32, FN = BN / 32;  // 16x16 fragments per wave along m / n
+  constexpr int A_PER_WAVE = BM / 32;        // 1-KiB DMA slots (8 rows x 128 B) per wave per k-tile
+  constexpr int B_PER_WAVE = BN / 32;
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const int t = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_m = t % p.tiles_m, tile_n = t / p.tiles_m;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)p.a_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, (int)p.w_bytes, 0x00020000);
+
+  // ---- per-lane DMA source descriptors (fixed over the k loop) ---------------------------------
+  const int rl = lane >> 3;                         // row within the 8-row slot
+  const unsigned gchunk = ((lane & 7) ^ rl) << 4;   // swizzled 16-B chunk this lane fetches
+  unsigned a_off[A_PER_WAVE];                       // LINEAR: byte offset of the row; CONV: unused
+  int a_b[A_PER_WAVE], a_y[A_PER_WAVE], a_x[A_PER_WAVE];
+  unsigned w_off[B_PER_WAVE];
+#pragma unroll
+  for (int i = 0; i < A_PER_WAVE; ++i) {
+    const int row = m0 + (wave * A_PER_WAVE + i) * 8 + rl;
+    if (AMODE == SX_A_LINEAR) {
+      a_off[i] = (row < p.M) ? (unsigned)row * (unsigned)p.K * 2u + gchunk : 0x80000000u;
+      a_b[i] = a_y[i] = a_x[i] = 0;
+    } else {
+      const int hw = p.Hout * p.Wout;
+      const int b = row / hw, rem = row - b * hw;
+      const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
+      a_b[i] = (row < p.M) ? b * p.Hin : -(1 << 28);  // invalid rows fail the range test below
+      a_y[i] = oy * p.stride - 1;
+      a_x[i] = ox * p.stride - 1;
+      a_off[i] = 0;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < B_PER_WAVE; ++i) {
+    const int row = n0 + (wave * B_PER_WAVE + i) * 8 + rl;
+    w_off[i] = (row < p.N) ? (unsigned)row * (unsigned)p.K * 2u + gchunk : 0x80000000u;
+  }
+  const int Hv = p.upsample ? 2 * p.Hin : p.Hin, Wv = p.upsample ? 2 * p.Win : p.Win;
+  const int cpt = (AMODE == SX_A_CONV3X3) ? p.Cin / 64 : 1;  // k-tiles per filter tap
+
+  auto stage = [&](int buf, int kt) {
+    unsigned char* sA = smem + buf * STAGE;
+    unsigned char* sB = sA + A_BYTES;
+    int dy = 0, dx = 0, cc = 0;
+    if (AMODE == SX_A_CONV3X3) {
+      const int tap = kt / cpt;
+      cc = kt - tap * cpt;
+      dy = tap / 3;
+      dx = tap - dy * 3;
+    }
+#pragma unroll
+    for (int i = 0; i < A_PER_WAVE; ++i) {
+      unsigned voff;
+      if (AMODE == SX_A_LINEAR) {
+        voff = a_off[i] + (unsigned)kt * 128u;
+      } else {
+        int iy = a_y[i] + dy, ix = a_x[i] + dx;
+        const bool ok = (a_b[i] >= 0) && iy >= 0 && iy < Hv && ix >= 0 && ix < Wv;
+        if (p.upsample) { iy >>= 1; ix >>= 1; }
+        voff = ok ? (unsigned)(((a_b[i] + iy) * p.Win + ix) * p.Cin) * 2u + (unsigned)cc * 128u + gchunk
+                  : 0x80000000u;
+      }
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, SX_LDS_PTR(sA + (wave * A_PER_WAVE + i) * 1024), 16, voff, 0, 0,
+                                               0);
+    }
+#pragma unroll
+    for (int i = 0; i < B_PER_WAVE; ++i) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, SX_LDS_PTR(sB + (wave * B_PER_WAVE + i) * 1024), 16,
+                                               w_off[i] + (unsigned)kt * 128u, 0, 0, 0);
+    }
+  };
+
+  f32x4_t acc[FN][FM];
+#pragma unroll
+  for (int i = 0; i < FN; ++i)
+#pragma unroll
+    for (int j = 0; j < FM; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  // fragment read offsets: row = base + (lane & 15), logical chunk = ks*4 + (lane >> 4), key = lane & 7
+  const unsigned frag_row = (unsigned)(lane & 15) * 128u;
+  unsigned frag_sw[2];
+  frag_sw[0] = (unsigned)(((lane >> 4)) ^ (lane & 7)) << 4;
+  frag_sw[1] = (unsigned)((4 + (lane >> 4)) ^ (lane & 7)) << 4;
+
+  const int nkt = p.K / 64;
+  stage(0, 0);
+  __syncthreads();
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nkt) stage(cur ^ 1, kt + 1);
+    const unsigned char* sA = smem + cur * STAGE + (wm * (BM / 2)) * 128;
+    const unsigned char* sB = smem + cur * STAGE + A_BYTES + (wn * (BN / 2)) * 128;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      vec8 af[FM], wf[FN];
+#pragma unroll
+      for (int j = 0; j < FM; ++j) af[j] = *(const vec8*)(sA + j * 2048 + frag_row + frag_sw[ks]);
+#pragma unroll
+      for (int i = 0; i < FN; ++i) wf[i] = *(const vec8*)(sB + i * 2048 + frag_row + frag_sw[ks]);
+#pragma unroll
+      for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j) acc[i][j] = TT::mfma16(wf[i], af[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+
+  // ---- fused epilogue: lane holds C[m][n .. n+3], m = ..+(lane&15), n = ..+(lane>>4)*4 ----------
+  // Loads are issued unconditionally on clamped addresses and batched per phase (bias once, then per
+  // m-fragment: bias2d + residual for all n-fragments) so they overlap instead of serialising on vmcnt(0).
+  const int lq = (lane >> 4) * 4;
+  int ncol[FN], nout[FN];
+  bool nok[FN];
+  f32x4_t bv[FN];
+#pragma unroll
+  for (int i = 0; i < FN; ++i) {
+    const int nb = n0 + wn * (BN / 2) + i * 16;
+    ncol[i] = nb + lq;
+    nout[i] = p.glu ? (nb >> 1) + lq : ncol[i];
+    nok[i] = ncol[i] < p.N && nout[i] < p.n_valid && !(p.glu && (i & 1));
+    if (ncol[i] >= p.N) ncol[i] = p.N - 4;
+    if (nout[i] + 4 > p.ldc) nout[i] = 0;  // clamped lanes never store
+    bv[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  }
+  if (p.bias) {
+#pragma unroll
+    for (int i = 0; i < FN; ++i) bv[i] = *(const f32x4_t*)(p.bias + ncol[i]);
+  }
+#pragma unroll
+  for (int j = 0; j < FM; ++j) {
+    const int m = m0 + wm * (BM / 2) + j * 16 + (lane & 15);
+    const bool mok = m < p.M;
+    const int mc = mok ? m : p.M - 1;
+    f32x4_t v[FN], rv[FN];
+#pragma unroll
+    for (int i = 0; i < FN; ++i) {
+      v[i] = acc[i][j] + bv[i];
+      rv[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    }
+    if (p.bias2d) {
+      const float* b2 = p.bias2d + (size_t)(mc / p.bias2d_rows) * p.N;
+#pragma unroll
+      for (int i = 0; i < FN; ++i) v[i] += *(const f32x4_t*)(b2 + ncol[i]);
+    }
+    if (p.residual) {
+      const float* rr = p.residual + (size_t)(p.res_mod ? (mc % p.res_mod) : mc) * p.ldr;
+#pragma unroll
+      for (int i = 0; i < FN; ++i) {
+        const int c = (nout[i] + 4 <= p.ldr) ? nout[i] : 0;
+        rv[i] = *(const f32x4_t*)(rr + c);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < FN; ++i) {
+      if (p.glu) {
+        if (i & 1) continue;
+        const f32x4_t g = v[(i + 1) < FN ? (i + 1) : i];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[i][r] = v[i][r] * apply_act(g[r], p.act);
+      } else if (p.act != SX_ACT_NONE) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[i][r] = apply_act(v[i][r], p.act);
+      }
+      const f32x4_t o4 = v[i] + rv[i];
+      if (!(mok && nok[i])) continue;
+      if (p.out_dtype == SX_F32) {
+        *(f32x4_t*)((float*)p.C + (size_t)m * p.ldc + nout[i]) = o4;
+      } else {
+        u32x2_t o;
+        if (p.out_dtype == SX_BF16) {
+          o[0] = pack2<BF16>(o4[0], o4[1]);
+          o[1] = pack2<BF16>(o4[2], o4[3]);
+        } else {
+          o[0] = pack2<F16>(o4[0], o4[1]);
+          o[1] = pack2<F16>(o4[2], o4[3]);
+        }
+        *(u32x2_t*)((unsigned short*)p.C + (size_t)m * p.ldc + nout[i]) = o;
+      }
+    }
+  }
+#endif
+}
+
+template <typename TT, int BM, int BN>
+int launch_cfg(const GemmP& p0, int a_mode, hipStream_t st) {
+  GemmP p = p0;
+  p.tiles_m = (p.M + BM - 1) / BM;
+  p.tiles_n = (p.N + BN - 1) / BN;
+  const int grid = p.tiles_m * p.tiles_n;
+  const size_t lds = 2 * (size_t)(BM + BN) * 128;
+  if (a_mode == SX_A_LINEAR)
+    hipLaunchKernelGGL((gemm_kernel<TT, BM, BN, SX_A_LINEAR>), dim3(grid), dim3(256), lds, st, p);
+  else
+    hipLaunchKernelGGL((gemm_kernel<TT, BM, BN, SX_A_CONV3X3>), dim3(grid), dim3(256), lds, st, p);
+  SX_HIP_LAUNCH_CHECK();
+  return SX_OK;
+}
+
+// pick the tile that minimises (rounds over the 256 CUs) x (tile area / efficiency)
+inline int pick_tile(int M, int N) {
+  const int bm[3] = {128, 64, 64}, bn[3] = {128, 128, 64};
+  const double eff[3] = {1.0, 0.85, 0.65};
+  int best = 0;
+  double best_cost = 1e30;
+  for (int c = 0; c < 3; ++c) {
+    const long tiles = (long)((M + bm[c] - 1) / bm[c]) * ((N + bn[c] - 1) / bn[c]);
+    const long rounds = (tiles + 255) / 256;
+    const double cost = (double)rounds * bm[c] * bn[c] / eff[c];
+    if (cost < best_cost * 0.999) {
+      best_cost = cost;
+      best = c;
+    }
+  }
+  return best;
+}
+
+}  // namespace sxk_gemm
+using namespace sxk_gemm;
+
+extern "C" int sx_gemm(const sx_gemm_args* a, void* stream) {
+  SX_CHECK(a && a->A && a->W && a->C, "sx_gemm: null pointer");
+  SX_CHECK(a->dtype == SX_F16 || a->dtype == SX_BF16, "sx_gemm: dtype must be f16/bf16");
+  SX_CHECK(a->out_dtype >= SX_F16 && a->out_dtype <= SX_F32, "sx_gemm: bad out_dtype");
+  SX_CHECK(a->M > 0 && a->N > 0 && a->K > 0, "sx_gemm: empty problem M=%d N=%d K=%d", a->M, a->N, a->K);
+  SX_CHECK(a->K % 64 == 0, "sx_gemm: K=%d must be a multiple of 64 (pad the operand)", a->K);
+  SX_CHECK(a->N % 16 == 0, "sx_gemm: N=%d must be a multiple of 16 (pad the weight)", a->N);
+  SX_CHECK(!a->glu || a->N % 32 == 0, "sx_gemm: glu needs N %% 32 == 0");
+  const int n_out = a->glu ? a->N / 2 : a->N;
+  SX_CHECK(a->n_valid >= 0 && a->n_valid % 4 == 0 && a->n_valid <= n_out, "sx_gemm: n_valid=%d", a->n_valid);
+  SX_CHECK(a->ldc >= (a->n_valid > 0 ? a->n_valid : n_out) && a->ldc % 4 == 0, "sx_gemm: ldc=%d invalid for n_out=%d",
+           a->ldc, n_out);
+  SX_CHECK(!a->residual || (a->ldr >= (a->n_valid > 0 ? a->n_valid : n_out) && a->ldr % 4 == 0), "sx_gemm: ldr=%d invalid", a->ldr);
+  SX_CHECK(!a->bias2d || a->bias2d_rows > 0, "sx_gemm: bias2d_rows must be > 0");
+  GemmP p;
+  memset(&p, 0, sizeof(p));
+  p.A = a->A; p.W = a->W; p.C = a->C; p.bias = a->bias; p.bias2d = a->bias2d; p.residual = a->residual;
+  p.M = a->M; p.N = a->N; p.K = a->K; p.ldc = a->ldc; p.ldr = a->ldr; p.res_mod = a->res_mod;
+  p.n_valid = a->n_valid > 0 ? a->n_valid : n_out;
+  p.bias2d_rows = a->bias2d_rows; p.out_dtype = a->out_dtype; p.act = a->act; p.glu = a->glu;
+  uint64_t a_bytes;
+  if (a->a_mode == SX_A_CONV3X3) {
+    SX_CHECK(a->Cin % 64 == 0 && a->K == 9 * a->Cin, "sx_gemm conv: Cin=%d K=%d", a->Cin, a->K);
+    SX_CHECK(a->stride == 1 || a->stride == 2, "sx_gemm conv: stride");
+    SX_CHECK(a->M == a->B * a->Hout * a->Wout, "sx_gemm conv: M != B*Hout*Wout");
+    const int hv = a->upsample ? 2 * a->Hin : a->Hin, wv = a->upsample ? 2 * a->Win : a->Win;
+    SX_CHECK(a->Hout == (hv + 2 - 3) / a->stride + 1 && a->Wout == (wv + 2 - 3) / a->stride + 1,
+             "sx_gemm conv: output geometry mismatch");
+    p.Hin = a->Hin; p.Win = a->Win; p.Cin = a->Cin; p.Hout = a->Hout; p.Wout = a->Wout;
+    p.stride = a->stride; p.upsample = a->upsample;
+    a_bytes = (uint64_t)a->B * a->Hin * a->Win * a->Cin * 2;
+  } else {
+    SX_CHECK(a->a_mode == SX_A_LINEAR, "sx_gemm: bad a_mode");
+    a_bytes = (uint64_t)a->M * a->K * 2;
+  }
+  const uint64_t w_bytes = (uint64_t)a->N * a->K * 2;
+  SX_CHECK(a_bytes < 0x7fffffffull && w_bytes < 0x7fffffffull, "sx_gemm: operand exceeds 2 GiB descriptor range");
+  p.a_bytes = (unsigned)a_bytes;
+  p.w_bytes = (unsigned)w_bytes;
+  hipStream_t st = (hipStream_t)stream;
+  const int cfg = pick_tile(a->M, a->N);
+#define SX_GEMM_DISPATCH(TT)                                                  \
+  switch (cfg) {                                                              \
+    case 0: return launch_cfg<TT, 128, 128>(p, a->a_mode, st);                \
+    case 1: return launch_cfg<TT, 64, 128>(p, a->a_mode, st);                 \
+    default: return launch_cfg<TT, 64, 64>(p, a->a_mode, st);                 \
+  }
+  if (a->dtype == SX_BF16) { SX_GEMM_DISPATCH(BF16) } else { SX_GEMM_DISPATCH(F16) }
+#undef SX_GEMM_DISPATCH
+}

@@ -1,0 +1,211 @@
+// LayerNorm / RMSNorm / GroupNorm(+SiLU) for gfx950. HBM-bound row reductions: vector loads,
+// wave-shuffle reductions, fp32 statistics (fp64 cross-block accumulation for GroupNorm).
+#include "sx_common.h"
+
+namespace sxk_norm {
+
+template <int IN_DT>
+__device__ __forceinline__ f32x4_t load4(const void* base, size_t idx4) {
+  if (IN_DT == SX_F32) {
+    return ((const f32x4_t*)base)[idx4];
+  } else {
+    const u32x2_t u = ((const u32x2_t*)base)[idx4];
+    f32x4_t v;
+    if (IN_DT == SX_BF16) {
+      v[0] = BF16::to_f32(u[0] & 0xffff); v[1] = BF16::to_f32(u[0] >> 16);
+      v[2] = BF16::to_f32(u[1] & 0xffff); v[3] = BF16::to_f32(u[1] >> 16);
+    } else {
+      v[0] = F16::to_f32(u[0] & 0xffff); v[1] = F16::to_f32(u[0] >> 16);
+      v[2] = F16::to_f32(u[1] & 0xffff); v[3] = F16::to_f32(u[1] >> 16);
+    }
+    return v;
+  }
+}
+__device__ __forceinline__ void store4(void* base, int dt, size_t idx4, f32x4_t v) {
+  if (dt == SX_F32) {
+    ((f32x4_t*)base)[idx4] = v;
+  } else {
+    u32x2_t o;
+    if (dt == SX_BF16) { o[0] = pack2<BF16>(v[0], v[1]); o[1] = pack2<BF16>(v[2], v[3]); }
+    else { o[0] = pack2<F16>(v[0], v[1]); o[1] = pack2<F16>(v[2], v[3]); }
+    ((u32x2_t*)base)[idx4] = o;
+  }
+}
+
+// one wave per row, 4 rows per 256-thread block; the row (<= 20 KB) stays L1/L2 resident over the passes
+template <int IN_DT>
+__global__ __launch_bounds__(256) void layernorm_kernel(const void* x, void* y, int out_dt, const float* gamma,
+                                                        const float* beta, int rows, int cols, float eps, int rms) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int n4 = cols >> 2;
+  const size_t base4 = (size_t)row * n4;
+  float mean = 0.f, var;
+  if (!rms) {
+    float s = 0.f;
+    for (int i = lane; i < n4; i += 64) {
+      const f32x4_t v = load4<IN_DT>(x, base4 + i);
+      s += (v[0] + v[1]) + (v[2] + v[3]);
+    }
+    mean = wave_sum(s) / (float)cols;
+  }
+  float q = 0.f;
+  for (int i = lane; i < n4; i += 64) {
+    f32x4_t v = load4<IN_DT>(x, base4 + i);
+    v -= mean;
+    q += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+  }
+  var = wave_sum(q) / (float)cols;
+  const float rstd = rsqrtf(var + eps);
+  for (int i = lane; i < n4; i += 64) {
+    f32x4_t v = load4<IN_DT>(x, base4 + i);
+    const f32x4_t g = ((const f32x4_t*)gamma)[i];
+    v = (v - mean) * rstd * g;
+    if (beta) v += ((const f32x4_t*)beta)[i];
+    store4(y, out_dt, base4 + i, v);
+  }
+}
+
+// ---- GroupNorm over NHWC fp32 -----------------------------------------------------------------
+constexpr int GN_MAX_SLOTS2 = 6;  // C/2 pairs per row / 256 threads  (C <= 3072)
+constexpr int GN_MAX_SLOTS4 = 3;  // C/4 quads per row / 256 threads
+
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float* x, double* stats, int HW, int C, int groups,
+                                                       int rows_per_block) {
+  __shared__ float acc[2 * 64];  // [groups][2], groups <= 64
+  const int b = blockIdx.y;
+  const int r0 = blockIdx.x * rows_per_block;
+  const int r1 = min(HW, r0 + rows_per_block);
+  const int np = C >> 1, cpg = C / groups;
+  for (int i = threadIdx.x; i < 2 * groups; i += 256) acc[i] = 0.f;
+  __syncthreads();
+  float s[GN_MAX_SLOTS2], q[GN_MAX_SLOTS2];
+#pragma unroll
+  for (int k = 0; k < GN_MAX_SLOTS2; ++k) { s[k] = 0.f; q[k] = 0.f; }
+  const float2* xb = (const float2*)(x + (size_t)b * HW * C);
+  for (int r = r0; r < r1; ++r) {
+    const float2* xr = xb + (size_t)r * np;
+#pragma unroll
+    for (int k = 0; k < GN_MAX_SLOTS2; ++k) {
+      const int pidx = threadIdx.x + k * 256;
+      if (pidx < np) {
+        const float2 v = xr[pidx];
+        s[k] += v.x + v.y;
+        q[k] += v.x * v.x + v.y * v.y;
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < GN_MAX_SLOTS2; ++k) {
+    const int pidx = threadIdx.x + k * 256;
+    if (pidx < np) {
+      const int g = (2 * pidx) / cpg;
+      atomicAdd(&acc[2 * g], s[k]);
+      atomicAdd(&acc[2 * g + 1], q[k]);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * groups; i += 256) atomicAdd(&stats[(size_t)b * groups * 2 + i], (double)acc[i]);
+}
+
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float* x, void* y, void* raw16, int out_dt,
+                                                       const float* gamma, const float* beta, const double* stats,
+                                                       int HW, int C, int groups, float eps, int silu,
+                                                       int rows_per_block) {
+  const int b = blockIdx.y;
+  const int r0 = blockIdx.x * rows_per_block;
+  const int r1 = min(HW, r0 + rows_per_block);
+  const int n4 = C >> 2, cpg = C / groups;
+  const double cnt = (double)HW * cpg;
+  f32x4_t sc[GN_MAX_SLOTS4], sh[GN_MAX_SLOTS4];
+#pragma unroll
+  for (int k = 0; k < GN_MAX_SLOTS4; ++k) {
+    const int qi = threadIdx.x + k * 256;
+    if (qi < n4) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int c = qi * 4 + e;
+        const int g = c / cpg;
+        const double su = stats[((size_t)b * groups + g) * 2], sq = stats[((size_t)b * groups + g) * 2 + 1];
+        const double mean = su / cnt;
+        double var = sq / cnt - mean * mean;
+        if (var < 0) var = 0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float ga = gamma[c] * rstd;
+        sc[k][e] = ga;
+        sh[k][e] = beta[c] - (float)mean * ga;
+      }
+    }
+  }
+  const size_t bbase4 = (size_t)b * HW * n4;
+  for (int r = r0; r < r1; ++r) {
+#pragma unroll
+    for (int k = 0; k < GN_MAX_SLOTS4; ++k) {
+      const int qi = threadIdx.x + k * 256;
+      if (qi < n4) {
+        const size_t idx = bbase4 + (size_t)r * n4 + qi;
+        const f32x4_t v = ((const f32x4_t*)x)[idx];
+        f32x4_t o = v * sc[k] + sh[k];
+        if (silu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = silu_f(o[e]);
+        }
+        store4(y, out_dt, idx, o);
+        if (raw16) store4(raw16, out_dt, idx, v);
+      }
+    }
+  }
+}
+
+}  // namespace sxk_norm
+using namespace sxk_norm;
+
+extern "C" int sx_layernorm(const void* x, int in_dtype, void* y, int out_dtype, const float* gamma,
+                            const float* beta, int rows, int cols, float eps, int rms, void* stream) {
+  SX_CHECK(x && y && gamma, "sx_layernorm: null pointer");
+  SX_CHECK(rows > 0 && cols > 0 && cols % 4 == 0, "sx_layernorm: rows=%d cols=%d (cols %% 4 must be 0)", rows, cols);
+  SX_CHECK(out_dtype >= SX_F16 && out_dtype <= SX_F32, "sx_layernorm: bad out dtype");
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((rows + 3) / 4), block(256);
+  switch (in_dtype) {
+    case SX_F32:
+      hipLaunchKernelGGL(layernorm_kernel<SX_F32>, grid, block, 0, st, x, y, out_dtype, gamma, beta, rows, cols, eps, rms);
+      break;
+    case SX_F16:
+      hipLaunchKernelGGL(layernorm_kernel<SX_F16>, grid, block, 0, st, x, y, out_dtype, gamma, beta, rows, cols, eps, rms);
+      break;
+    case SX_BF16:
+      hipLaunchKernelGGL(layernorm_kernel<SX_BF16>, grid, block, 0, st, x, y, out_dtype, gamma, beta, rows, cols, eps, rms);
+      break;
+    default:
+      SX_FAIL("sx_layernorm: bad in dtype %d", in_dtype);
+  }
+  SX_HIP_LAUNCH_CHECK();
+  return SX_OK;
+}
+
+extern "C" int sx_groupnorm(const float* x, void* y, void* raw16, int out_dtype, const float* gamma,
+                            const float* beta, double* stats, int B, int HW, int C, int groups, float eps, int silu,
+                            void* stream) {
+  SX_CHECK(x && y && gamma && beta && stats, "sx_groupnorm: null pointer");
+  SX_CHECK(out_dtype == SX_F16 || out_dtype == SX_BF16, "sx_groupnorm: output must be 16-bit");
+  SX_CHECK(groups > 0 && groups <= 64 && C % groups == 0, "sx_groupnorm: C=%d groups=%d", C, groups);
+  SX_CHECK(C % 4 == 0 && (C / groups) % 2 == 0, "sx_groupnorm: C %% 4 and (C/groups) %% 2 must be 0 (C=%d)", C);
+  SX_CHECK(C / 2 <= 256 * GN_MAX_SLOTS2, "sx_groupnorm: C=%d too large", C);
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(stats, 0, sizeof(double) * 2 * B * groups, st) != hipSuccess) {
+    sx_set_error("sx_groupnorm: hipMemsetAsync failed");
+    return SX_ERR_HIP;
+  }
+  // ~2048 blocks over the chip
+  int rows_per_block = (HW * B + 2047) / 2048;
+  if (rows_per_block < 4) rows_per_block = 4;
+  const dim3 grid((HW + rows_per_block - 1) / rows_per_block, B), block(256);
+  hipLaunchKernelGGL(gn_stats_kernel, grid, block, 0, st, x, stats, HW, C, groups, rows_per_block);
+  SX_HIP_LAUNCH_CHECK();
+  hipLaunchKernelGGL(gn_apply_kernel, grid, block, 0, st, x, y, raw16, out_dtype, gamma, beta, stats, HW, C, groups,
+                     eps, silu, rows_per_block);
+  SX_HIP_LAUNCH_CHECK();
+  return SX_OK;
+}

@@ -1,0 +1,119 @@
+// seedx-mi355x — common device/host helpers for the gfx950 (CDNA4) kernels.
+// Everything here is written for wave64 / MFMA / LDS-DMA on MI355X only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include "../../include/seedx_hip.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+
+#define SX_WAVE 64
+#define SX_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+// ---- host-side error plumbing -------------------------------------------------------------
+void sx_set_error(const char* fmt, ...);
+#define SX_FAIL(...)            \
+  do {                          \
+    sx_set_error(__VA_ARGS__);  \
+    return SX_ERR_INVALID;      \
+  } while (0)
+#define SX_CHECK(cond, ...) \
+  do {                      \
+    if (!(cond)) SX_FAIL(__VA_ARGS__); \
+  } while (0)
+#define SX_HIP_LAUNCH_CHECK()                                                        \
+  do {                                                                               \
+    hipError_t e__ = hipGetLastError();                                              \
+    if (e__ != hipSuccess) {                                                         \
+      sx_set_error("%s:%d HIP launch error: %s", __FILE__, __LINE__, hipGetErrorString(e__)); \
+      return SX_ERR_HIP;                                                             \
+    }                                                                                \
+  } while (0)
+
+// ---- 16-bit float element traits ----------------------------------------------------------
+struct BF16 {
+  typedef __bf16 elem;
+  typedef bf16x8_t vec8;
+  typedef bf16x4_t vec4;
+  static __device__ __forceinline__ float to_f32(unsigned short u) { return __uint_as_float(((unsigned)u) << 16); }
+  static __device__ __forceinline__ unsigned short from_f32(float f) {
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);  // NaN
+    u += 0x7fffu + ((u >> 16) & 1u);                                                   // RNE
+    return (unsigned short)(u >> 16);
+  }
+  static __device__ __forceinline__ f32x4_t mfma16(vec8 a, vec8 b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ f32x16_t mfma32(vec8 a, vec8 b, f32x16_t c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+};
+struct F16 {
+  typedef _Float16 elem;
+  typedef f16x8_t vec8;
+  typedef f16x4_t vec4;
+  static __device__ __forceinline__ float to_f32(unsigned short u) {
+    _Float16 h;
+    __builtin_memcpy(&h, &u, 2);
+    return (float)h;
+  }
+  static __device__ __forceinline__ unsigned short from_f32(float f) {
+    _Float16 h = (_Float16)f;  // RNE, saturates to inf like torch .half()
+    unsigned short u;
+    __builtin_memcpy(&u, &h, 2);
+    return u;
+  }
+  static __device__ __forceinline__ f32x4_t mfma16(vec8 a, vec8 b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ f32x16_t mfma32(vec8 a, vec8 b, f32x16_t c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  }
+};
+
+// pack two floats -> two 16-bit values in one dword
+template <typename TT>
+__device__ __forceinline__ unsigned pack2(float lo, float hi) {
+  return (unsigned)TT::from_f32(lo) | ((unsigned)TT::from_f32(hi) << 16);
+}
+
+// ---- wave / block reductions --------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// activations (fp32 math, exact-erf GELU as torch nn.GELU())
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float apply_act(float x, int act) {
+  if (act == SX_ACT_GELU) return gelu_erf(x);
+  if (act == SX_ACT_SILU) return silu_f(x);
+  return x;
+}
+
+// bijective XCD-aware remap of a 1-D grid (block b is observed on XCD b % 8): give each XCD a
+// contiguous chunk of the logical tile order so neighbouring tiles share one L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int nx = 8;
+  int q = nwg / nx, r = nwg % nx;
+  int xcd = bid % nx, idx = bid / nx;
+  int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}

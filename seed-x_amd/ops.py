@@ -1,0 +1,374 @@
+"""Thin torch-tensor wrappers over the C-ABI kernels (include/seedx_hip.h).
+
+PyTorch is used only for device memory and the current HIP stream: every wrapper passes ``data_ptr()``s and
+``torch.cuda.current_stream().cuda_stream`` to libseedx_hip.so. There is no eager/CPU fallback — a missing
+library or a non-CUDA tensor raises.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib
+from ._lib import (SX_A_CONV3X3, SX_A_LINEAR, SX_ACT_GELU, SX_ACT_NONE, SX_ACT_SILU, SX_BF16, SX_F16, SX_F32,
+                   AttnArgs, AttnSmallArgs, GemmArgs, GemvArgs, check)
+
+_DT = {torch.float16: SX_F16, torch.bfloat16: SX_BF16, torch.float32: SX_F32}
+_TD = {v: k for k, v in _DT.items()}
+ACT = {None: SX_ACT_NONE, "none": SX_ACT_NONE, "gelu": SX_ACT_GELU, "silu": SX_ACT_SILU}
+
+
+def dt_code(dtype):
+    return _DT[dtype]
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("seedx_amd.ops: tensors must live on the GPU (no CPU fallback)")
+    return C.c_void_p(t.data_ptr())
+
+
+def _f32c(t):
+    """fp32 contiguous parameter tensor or None."""
+    if t is None:
+        return None
+    assert t.dtype == torch.float32 and t.is_contiguous(), "expected contiguous fp32 tensor"
+    return t
+
+
+# ---------------------------------------------------------------------------------------------------------
+# GEMM family
+# ---------------------------------------------------------------------------------------------------------
+def gemm(a, w, bias=None, bias2d=None, bias2d_rows=0, residual=None, res_mod=0, act=None, glu=False,
+         out_dtype=None, out=None, n_valid=0):
+    """out[M, N_out] = epilogue(a[M, K] @ w[N, K]^T). a, w: 16-bit contiguous. residual/bias fp32."""
+    lib = _lib.load()
+    assert a.dim() == 2 and w.dim() == 2 and a.is_contiguous() and w.is_contiguous()
+    assert a.dtype == w.dtype and a.dtype in (torch.float16, torch.bfloat16)
+    M, K = a.shape
+    N = w.shape[0]
+    assert w.shape[1] == K, f"K mismatch {a.shape} vs {w.shape}"
+    n_out = N // 2 if glu else N
+    n_store = n_valid if n_valid else n_out
+    out_dtype = out_dtype or a.dtype
+    if out is None:
+        out = torch.empty((M, n_store), dtype=out_dtype, device=a.device)
+    assert out.dtype == out_dtype and out.stride(-1) == 1 and out.shape[0] == M
+    args = GemmArgs()
+    args.A, args.W, args.C = a.data_ptr(), w.data_ptr(), out.data_ptr()
+    args.bias = _f32c(bias).data_ptr() if bias is not None else None
+    args.bias2d = _f32c(bias2d).data_ptr() if bias2d is not None else None
+    if residual is not None:
+        assert residual.dtype == torch.float32 and residual.stride(-1) == 1
+        args.residual = residual.data_ptr()
+        args.ldr = residual.stride(0)
+    args.M, args.N, args.K = M, N, K
+    args.ldc = out.stride(0)
+    args.n_valid = n_valid
+    args.res_mod = res_mod
+    args.bias2d_rows = bias2d_rows
+    args.dtype = _DT[a.dtype]
+    args.out_dtype = _DT[out_dtype]
+    args.act = ACT[act]
+    args.glu = 1 if glu else 0
+    args.a_mode = SX_A_LINEAR
+    check(lib.sx_gemm(C.byref(args), _stream()), "sx_gemm")
+    return out
+
+
+def conv3x3(x, w, bias=None, bias2d=None, residual=None, stride=1, upsample=False, out_dtype=None, act=None):
+    """3x3 / pad 1 convolution as implicit GEMM. x: [B, H, W, Cin] 16-bit NHWC contiguous; w: [Cout, 9*Cin]
+    ((ky,kx,cin)-ordered). Returns [B, Hout*Wout, Cout] (NHWC flattened). bias2d: [B, Cout] fp32 per-sample add.
+    residual: fp32 [B*Hout*Wout, Cout]."""
+    lib = _lib.load()
+    assert x.dim() == 4 and x.is_contiguous() and w.is_contiguous()
+    B, H, W, Cin = x.shape
+    Cout, K = w.shape
+    assert K == 9 * Cin
+    hv, wv = (2 * H, 2 * W) if upsample else (H, W)
+    Hout, Wout = (hv + 2 - 3) // stride + 1, (wv + 2 - 3) // stride + 1
+    M = B * Hout * Wout
+    out_dtype = out_dtype or x.dtype
+    out = torch.empty((M, Cout), dtype=out_dtype, device=x.device)
+    args = GemmArgs()
+    args.A, args.W, args.C = x.data_ptr(), w.data_ptr(), out.data_ptr()
+    args.bias = _f32c(bias).data_ptr() if bias is not None else None
+    if bias2d is not None:
+        args.bias2d = _f32c(bias2d).data_ptr()
+        args.bias2d_rows = Hout * Wout
+    if residual is not None:
+        assert residual.dtype == torch.float32 and residual.stride(-1) == 1
+        args.residual = residual.data_ptr()
+        args.ldr = residual.stride(0)
+    args.M, args.N, args.K = M, Cout, K
+    args.ldc = Cout
+    args.dtype = _DT[x.dtype]
+    args.out_dtype = _DT[out_dtype]
+    args.act = ACT[act]
+    args.a_mode = SX_A_CONV3X3
+    args.B, args.Hin, args.Win, args.Cin, args.Hout, args.Wout = B, H, W, Cin, Hout, Wout
+    args.stride = stride
+    args.upsample = 1 if upsample else 0
+    check(lib.sx_gemm(C.byref(args), _stream()), "sx_gemm(conv3x3)")
+    return out.view(B, Hout * Wout, Cout)
+
+
+def gemv(x, w, residual=None, act=None, glu=False, out_dtype=None):
+    lib = _lib.load()
+    assert x.dim() == 2 and x.is_contiguous() and w.is_contiguous() and x.dtype == w.dtype
+    M, K = x.shape
+    N = w.shape[0]
+    n_out = N // 2 if glu else N
+    out_dtype = out_dtype or x.dtype
+    y = torch.empty((M, n_out), dtype=out_dtype, device=x.device)
+    args = GemvArgs()
+    args.x, args.W, args.y = x.data_ptr(), w.data_ptr(), y.data_ptr()
+    if residual is not None:
+        assert residual.dtype == torch.float32 and residual.is_contiguous() and residual.shape == (M, n_out)
+        args.residual = residual.data_ptr()
+    args.M, args.N, args.K = M, N, K
+    args.dtype, args.out_dtype, args.act, args.glu = _DT[x.dtype], _DT[out_dtype], ACT[act], 1 if glu else 0
+    check(lib.sx_gemv(C.byref(args), _stream()), "sx_gemv")
+    return y
+
+
+def linear(x, w, **kw):
+    """Dispatch M <= 8 rows to the weight-streaming GEMV (when the epilogue allows), else the MFMA GEMM."""
+    if x.shape[0] <= 8 and kw.get("bias") is None and kw.get("bias2d") is None and not kw.get("res_mod") \
+            and kw.get("out") is None and not kw.get("n_valid"):
+        res = kw.get("residual")
+        if res is None or res.is_contiguous():
+            return gemv(x, w, residual=res, act=kw.get("act"), glu=kw.get("glu", False), out_dtype=kw.get("out_dtype"))
+    return gemm(x, w, **kw)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Norms
+# ---------------------------------------------------------------------------------------------------------
+def layernorm(x, gamma, beta, eps, out_dtype, rms=False):
+    lib = _lib.load()
+    assert x.is_contiguous()
+    cols = x.shape[-1]
+    rows = x.numel() // cols
+    y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    check(lib.sx_layernorm(_p(x), _DT[x.dtype], _p(y), _DT[out_dtype], _p(_f32c(gamma)), _p(_f32c(beta)), rows, cols,
+                           float(eps), 1 if rms else 0, _stream()), "sx_layernorm")
+    return y
+
+
+def rmsnorm(x, gamma, eps, out_dtype):
+    return layernorm(x, gamma, None, eps, out_dtype, rms=True)
+
+
+def groupnorm(x, gamma, beta, groups, eps, silu, out_dtype, want_raw=False):
+    """x: fp32 [B, HW, C] (NHWC). Returns y (16-bit) and optionally a 16-bit raw copy of x."""
+    lib = _lib.load()
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 3
+    B, HW, Cc = x.shape
+    y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    raw = torch.empty(x.shape, dtype=out_dtype, device=x.device) if want_raw else None
+    stats = torch.empty((B, groups, 2), dtype=torch.float64, device=x.device)
+    check(lib.sx_groupnorm(_p(x), _p(y), _p(raw), _DT[out_dtype], _p(_f32c(gamma)), _p(_f32c(beta)), _p(stats), B, HW,
+                           Cc, groups, float(eps), 1 if silu else 0, _stream()), "sx_groupnorm")
+    return (y, raw) if want_raw else y
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Attention
+# ---------------------------------------------------------------------------------------------------------
+def _bshd_strides(t):
+    assert t.dim() == 4 and t.stride(3) == 1, "expected a [B, S, H, D] view with unit stride on D"
+    return t.stride(0), t.stride(1), t.stride(2)
+
+
+def attention(q, k, v, scale, causal=False, out=None):
+    """Flash attention on MFMA. q: [B, Sq, H, D] view, k/v: [B, Skv, H, D] views (any strides with unit D stride).
+    Returns [B, Sq, H*D] contiguous 16-bit."""
+    lib = _lib.load()
+    B, Sq, H, D = q.shape
+    Skv = k.shape[1]
+    assert k.shape == (B, Skv, H, D) and v.shape == (B, Skv, H, D) and q.dtype == k.dtype == v.dtype
+    kv_pad = (Skv + 63) // 64 * 64
+    vt = torch.empty((B, H, D, kv_pad), dtype=q.dtype, device=q.device)
+    vb, vr, vh = _bshd_strides(v)
+    check(lib.sx_transpose_v(_p(v), _p(vt), B, H, Skv, D, kv_pad, vb, vr, vh, _stream()), "sx_transpose_v")
+    if out is None:
+        out = torch.empty((B, Sq, H * D), dtype=q.dtype, device=q.device)
+    a = AttnArgs()
+    a.Q, a.K, a.Vt, a.O = q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr()
+    a.B, a.H, a.Sq, a.Skv, a.D, a.kv_pad = B, H, Sq, Skv, D, kv_pad
+    a.q_batch_stride, a.q_row_stride, a.q_head_stride = _bshd_strides(q)
+    a.k_batch_stride, a.k_row_stride, a.k_head_stride = _bshd_strides(k)
+    a.o_batch_stride, a.o_row_stride = out.stride(0), out.stride(1)
+    a.scale = float(scale)
+    a.causal = 1 if causal else 0
+    a.dtype = _DT[q.dtype]
+    check(lib.sx_attention(C.byref(a), _stream()), "sx_attention")
+    return out
+
+
+def attention_small(q, k, v, scale):
+    lib = _lib.load()
+    B, Sq, H, D = q.shape
+    Skv = k.shape[1]
+    out = torch.empty((B, Sq, H * D), dtype=q.dtype, device=q.device)
+    a = AttnSmallArgs()
+    a.Q, a.K, a.V, a.O = q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr()
+    a.B, a.H, a.Sq, a.Skv, a.D = B, H, Sq, Skv, D
+    a.q_batch_stride, a.q_row_stride, a.q_head_stride = _bshd_strides(q)
+    a.k_batch_stride, a.k_row_stride, a.k_head_stride = _bshd_strides(k)
+    a.v_batch_stride, a.v_row_stride, a.v_head_stride = _bshd_strides(v)
+    a.o_batch_stride, a.o_row_stride = out.stride(0), out.stride(1)
+    a.scale = float(scale)
+    a.dtype = _DT[q.dtype]
+    check(lib.sx_attention_small(C.byref(a), _stream()), "sx_attention_small")
+    return out
+
+
+def attn_decode(q, kcache, vcache, ctx_len_dev, scale, nsplit=8):
+    """q: [H, D] 16-bit; caches [H, Tmax, D]; ctx_len_dev: int32 device scalar. Returns [1, H*D]."""
+    lib = _lib.load()
+    H, D = q.shape
+    Tmax = kcache.shape[1]
+    out = torch.empty((1, H * D), dtype=q.dtype, device=q.device)
+    scratch = torch.empty((H, nsplit, D + 2), dtype=torch.float32, device=q.device)
+    check(lib.sx_attn_decode(_p(q), _p(kcache), _p(vcache), _p(out), _p(scratch), _p(ctx_len_dev), H, D, Tmax, nsplit,
+                             float(scale), _DT[q.dtype], _stream()), "sx_attn_decode")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------
+# LLM glue
+# ---------------------------------------------------------------------------------------------------------
+def rope_kv_append(qkv, kcache, vcache, cos_tab, sin_tab, pos0_dev, H, D):
+    lib = _lib.load()
+    T = qkv.shape[0]
+    assert qkv.is_contiguous() and qkv.shape[1] == 3 * H * D
+    check(lib.sx_rope_kv_append(_p(qkv), _p(kcache), _p(vcache), _p(cos_tab), _p(sin_tab), _p(pos0_dev), T, H, D,
+                                kcache.shape[1], _DT[qkv.dtype], _stream()), "sx_rope_kv_append")
+
+
+def embedding(ids_i32, table):
+    lib = _lib.load()
+    T = ids_i32.numel()
+    out = torch.empty((T, table.shape[1]), dtype=torch.float32, device=table.device)
+    check(lib.sx_embedding(_p(ids_i32), _p(table), _p(out), T, table.shape[1], _DT[table.dtype], _stream()),
+          "sx_embedding")
+    return out
+
+
+def scatter_rows(src, rows_i32, dst):
+    lib = _lib.load()
+    assert src.dtype == torch.float32 and dst.dtype == torch.float32 and src.is_contiguous() and dst.is_contiguous()
+    check(lib.sx_scatter_rows(_p(src), _p(rows_i32), _p(dst), src.shape[0], src.shape[1], _stream()),
+          "sx_scatter_rows")
+
+
+def greedy_next(logits, vocab, img_ids_dev, prev_id_dev, next_id_dev, out_ids=None, step_dev=None):
+    lib = _lib.load()
+    assert logits.dtype == torch.float32
+    check(lib.sx_greedy_next(_p(logits), vocab, _p(img_ids_dev), img_ids_dev.numel(), _p(prev_id_dev),
+                             _p(next_id_dev), _p(out_ids), _p(step_dev), _stream()), "sx_greedy_next")
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Elementwise / layout
+# ---------------------------------------------------------------------------------------------------------
+def cast(x, dtype):
+    lib = _lib.load()
+    assert x.is_contiguous()
+    y = torch.empty(x.shape, dtype=dtype, device=x.device)
+    check(lib.sx_cast(_p(x), _DT[x.dtype], _p(y), _DT[dtype], x.numel(), _stream()), "sx_cast")
+    return y
+
+
+def copy2d(src, dst, dst_col_off=0):
+    """dst[:, off:off+cols] = src (fp32 2-D, row strides honoured)."""
+    lib = _lib.load()
+    assert src.dtype == torch.float32 and dst.dtype == torch.float32 and src.dim() == 2 and dst.dim() == 2
+    assert src.stride(1) == 1 and dst.stride(1) == 1
+    d = dst[:, dst_col_off:dst_col_off + src.shape[1]]
+    check(lib.sx_copy2d_f32(_p(src), src.stride(0), C.c_void_p(d.data_ptr()), dst.stride(0), src.shape[0],
+                            src.shape[1], _stream()), "sx_copy2d_f32")
+
+
+def add(a, b):
+    lib = _lib.load()
+    assert a.dtype == torch.float32 and b.dtype == torch.float32 and a.is_contiguous() and b.is_contiguous()
+    y = torch.empty_like(a)
+    check(lib.sx_add_f32(_p(a), _p(b), _p(y), a.numel(), _stream()), "sx_add_f32")
+    return y
+
+
+def patchify(img, patch, kpad, dtype):
+    lib = _lib.load()
+    assert img.dtype == torch.float32 and img.is_contiguous() and img.shape[1] == 3 and img.shape[2] == img.shape[3]
+    B, _, S, _ = img.shape
+    g = S // patch
+    out = torch.empty((B * g * g, kpad), dtype=dtype, device=img.device)
+    check(lib.sx_patchify(_p(img), _p(out), B, S, patch, kpad, _DT[dtype], _stream()), "sx_patchify")
+    return out
+
+
+def im2col3x3_small(x, kpad, dtype):
+    lib = _lib.load()
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 4
+    B, H, W, Cin = x.shape
+    out = torch.empty((B * H * W, kpad), dtype=dtype, device=x.device)
+    check(lib.sx_im2col3x3_small(_p(x), _p(out), B, H, W, Cin, kpad, _DT[dtype], _stream()), "sx_im2col3x3_small")
+    return out
+
+
+def avgpool_tokens(x, k):
+    lib = _lib.load()
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    B, L, D = x.shape
+    y = torch.empty((B, L // k, D), dtype=torch.float32, device=x.device)
+    check(lib.sx_avgpool_tokens(_p(x), _p(y), B, L, D, k, _stream()), "sx_avgpool_tokens")
+    return y
+
+
+def timestep_embedding(t, dim, dtype, idx_dev=None, n=None):
+    lib = _lib.load()
+    assert t.dtype == torch.float32
+    n = n if n is not None else t.numel()
+    out = torch.empty((n, dim), dtype=dtype, device=t.device)
+    check(lib.sx_timestep_embedding(_p(t), _p(idx_dev), _p(out), n, dim, _DT[dtype], _stream()),
+          "sx_timestep_embedding")
+    return out
+
+
+def nchw_to_nhwc(src, ld=None, dst=None):
+    lib = _lib.load()
+    B, Cc, H, W = src.shape
+    ld = ld or Cc
+    if dst is None:
+        dst = torch.zeros((B, H * W, ld), dtype=torch.float32, device=src.device)
+    check(lib.sx_nchw_to_nhwc(_p(src.contiguous()), _p(dst), ld, B, Cc, H * W, _stream()), "sx_nchw_to_nhwc")
+    return dst
+
+
+def nhwc_to_nchw(src, Cc, H, W):
+    lib = _lib.load()
+    B = src.shape[0]
+    ld = src.shape[-1]
+    dst = torch.empty((B, Cc, H, W), dtype=torch.float32, device=src.device)
+    check(lib.sx_nhwc_to_nchw(_p(src), ld, _p(dst), B, Cc, H * W, _stream()), "sx_nhwc_to_nchw")
+    return dst
+
+
+def add_i32(p, delta):
+    check(_lib.load().sx_add_i32(_p(p), int(delta), _stream()), "sx_add_i32")
+
+
+def cfg_euler_step(eps, latents, scaled_next, sigmas_dev, step_dev, nb, C_lat, ld_scaled, gs, igs, mode):
+    lib = _lib.load()
+    n = latents.numel()
+    check(lib.sx_cfg_euler_step(_p(eps), _p(latents), _p(scaled_next), _p(sigmas_dev), _p(step_dev), nb, n, C_lat,
+                                ld_scaled, float(gs), float(igs), mode, _stream()), "sx_cfg_euler_step")

@@ -1,0 +1,395 @@
+"""Kernel-level parity on the GPU: every HIP kernel vs a plain PyTorch fp32 reference of the same op computed
+from the SAME 16-bit-rounded inputs (so only accumulation order / output rounding differ).
+
+Tolerances (relative L2 error ‖x−ref‖/‖ref‖): fp32 outputs 2e-5; fp16 outputs 6e-4; bf16 outputs 4e-3
+(= output rounding, eps_fp16/2 = 4.9e-4, eps_bf16/2 = 3.9e-3 per element)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+TOL = {torch.float32: 2e-5, torch.float16: 6e-4, torch.bfloat16: 4e-3}
+
+
+def relerr(x, ref):
+    x, ref = x.float(), ref.float()
+    return ((x - ref).norm() / ref.norm().clamp_min(1e-20)).item()
+
+
+def rnd(shape, dtype, dev, scale=1.0, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dtype).to(dev)
+
+
+def glu_pack(w_lin, w_gate):
+    """[N/2,K] x2 -> [N,K] in 32-row groups [16 linear | 16 gate] (layout contract of sx_gemm glu)."""
+    n2, k = w_lin.shape
+    a = w_lin.view(n2 // 16, 16, k)
+    b = w_gate.view(n2 // 16, 16, k)
+    return torch.cat([a, b], dim=1).reshape(2 * n2, k).contiguous()
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 128), (200, 144, 192), (77, 80, 64), (1024, 1664, 640),
+                                   (2048, 1280, 1280), (64, 512, 256), (333, 4096, 128)])
+def test_gemm_plain(dev, dtype, M, N, K):
+    from seedx_amd import ops
+    a, w = rnd((M, K), dtype, dev, seed=1), rnd((N, K), dtype, dev, 0.05, seed=2)
+    ref = a.float() @ w.float().t()
+    out32 = ops.gemm(a, w, out_dtype=torch.float32)
+    assert relerr(out32, ref) < TOL[torch.float32]
+    out16 = ops.gemm(a, w)
+    assert out16.dtype == dtype and relerr(out16, ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_gemm_asymmetric_identity(dev, dtype):
+    """A = I with an asymmetric W catches transposed / permuted fragment layouts."""
+    from seedx_amd import ops
+    K = 128
+    a = torch.eye(K, dtype=dtype, device=dev)
+    w = (torch.arange(192 * K, device=dev).view(192, K) % 251).to(dtype) / 64
+    out = ops.gemm(a, w, out_dtype=torch.float32)
+    assert torch.equal(out, w.float().t().contiguous())
+
+
+@pytest.mark.parametrize("act", [None, "gelu", "silu"])
+def test_gemm_epilogues(dev, act):
+    from seedx_amd import ops
+    dtype = torch.bfloat16
+    M, N, K = 300, 272, 128
+    a, w = rnd((M, K), dtype, dev, seed=3), rnd((N, K), dtype, dev, 0.1, seed=4)
+    bias = rnd((N,), torch.float32, dev, seed=5)
+    res = rnd((M, N), torch.float32, dev, seed=6)
+    ref = a.float() @ w.float().t() + bias
+    if act == "gelu":
+        ref = F.gelu(ref)
+    elif act == "silu":
+        ref = F.silu(ref)
+    out = ops.gemm(a, w, bias=bias, act=act, residual=res, out_dtype=torch.float32)
+    assert relerr(out, ref + res) < 5e-5
+    # residual broadcast (pos-embed): rows m % 100
+    res2 = rnd((100, N), torch.float32, dev, seed=7)
+    out = ops.gemm(a, w, bias=bias, act=act, residual=res2, res_mod=100, out_dtype=torch.float32)
+    assert relerr(out, ref + res2.repeat(3, 1)) < 5e-5
+    # per-sample bias2d (time embedding): 3 samples x 100 rows
+    b2 = rnd((3, N), torch.float32, dev, seed=8)
+    ref2 = a.float() @ w.float().t() + bias + b2.repeat_interleave(100, 0)
+    out = ops.gemm(a, w, bias=bias, bias2d=b2, bias2d_rows=100, out_dtype=torch.float32)
+    assert relerr(out, ref2) < 5e-5
+
+
+@pytest.mark.parametrize("act", ["gelu", "silu"])
+@pytest.mark.parametrize("M", [200, 4])
+def test_gemm_glu(dev, act, M):
+    from seedx_amd import ops
+    dtype = torch.float16
+    N2, K = 160, 192
+    a = rnd((M, K), dtype, dev, seed=9)
+    wl, wg = rnd((N2, K), dtype, dev, 0.1, seed=10), rnd((N2, K), dtype, dev, 0.1, seed=11)
+    bl, bg = rnd((N2,), torch.float32, dev, seed=12), rnd((N2,), torch.float32, dev, seed=13)
+    w = glu_pack(wl, wg)
+    bias = glu_pack(bl.view(-1, 1), bg.view(-1, 1)).view(-1).contiguous()
+    lin = a.float() @ wl.float().t() + bl
+    gate = a.float() @ wg.float().t() + bg
+    ref = lin * (F.gelu(gate) if act == "gelu" else F.silu(gate))
+    out = ops.gemm(a, w, bias=bias, act=act, glu=True, out_dtype=torch.float32)
+    assert out.shape == (M, N2) and relerr(out, ref) < 5e-5
+    if M <= 8:
+        ref_nb = (a.float() @ wl.float().t()) * (F.gelu(a.float() @ wg.float().t()) if act == "gelu"
+                                                 else F.silu(a.float() @ wg.float().t()))
+        out = ops.gemv(a, w, act=act, glu=True, out_dtype=torch.float32)
+        assert relerr(out, ref_nb) < 5e-5
+
+
+def test_gemm_n_valid(dev):
+    from seedx_amd import ops
+    dtype = torch.bfloat16
+    a, w = rnd((500, 128), dtype, dev, seed=14), rnd((16, 128), dtype, dev, 0.1, seed=15)
+    w[4:] = 0
+    out = ops.gemm(a, w, out_dtype=torch.float32, n_valid=4)
+    assert out.shape == (500, 4)
+    assert relerr(out, (a.float() @ w.float().t())[:, :4]) < TOL[torch.float32]
+
+
+def _conv_ref(x_nhwc, w_flat, bias, stride, upsample):
+    B, H, W, Cin = x_nhwc.shape
+    Cout = w_flat.shape[0]
+    x = x_nhwc.float().permute(0, 3, 1, 2)
+    if upsample:
+        x = F.interpolate(x, scale_factor=2.0, mode="nearest")
+    w = w_flat.float().view(Cout, 3, 3, Cin).permute(0, 3, 1, 2)
+    y = F.conv2d(x, w, bias, stride=stride, padding=1)
+    return y.permute(0, 2, 3, 1).reshape(B, -1, Cout)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,H,W,Cin,Cout,stride,upsample", [(2, 16, 16, 64, 128, 1, False), (1, 10, 12, 128, 64, 1, False),
+                                                             (2, 16, 16, 64, 64, 2, False), (2, 8, 8, 64, 128, 1, True),
+                                                             (3, 32, 32, 320, 320, 1, False)])
+def test_conv3x3(dev, dtype, B, H, W, Cin, Cout, stride, upsample):
+    from seedx_amd import ops
+    x = rnd((B, H, W, Cin), dtype, dev, seed=16)
+    w = rnd((Cout, 9 * Cin), dtype, dev, 0.05, seed=17)
+    bias = rnd((Cout,), torch.float32, dev, seed=18)
+    ref = _conv_ref(x, w, bias, stride, upsample)
+    out = ops.conv3x3(x, w, bias=bias, stride=stride, upsample=upsample, out_dtype=torch.float32)
+    assert out.shape == ref.shape and relerr(out, ref) < TOL[torch.float32]
+    # time-embedding add + residual
+    b2 = rnd((B, Cout), torch.float32, dev, seed=19)
+    res = rnd((ref.shape[0] * ref.shape[1], Cout), torch.float32, dev, seed=20)
+    out = ops.conv3x3(x, w, bias=bias, bias2d=b2, residual=res, stride=stride, upsample=upsample,
+                      out_dtype=torch.float32)
+    assert relerr(out, ref + b2[:, None, :] + res.view_as(ref)) < TOL[torch.float32]
+
+
+@pytest.mark.parametrize("in_dt,out_dt", [(torch.float32, torch.bfloat16), (torch.float32, torch.float32),
+                                          (torch.float16, torch.float16), (torch.bfloat16, torch.float32)])
+@pytest.mark.parametrize("rows,cols", [(7, 1664), (165, 5120), (512, 640), (3, 4096)])
+def test_layernorm(dev, in_dt, out_dt, rows, cols):
+    from seedx_amd import ops
+    x = rnd((rows, cols), in_dt, dev, 2.0, seed=21) + 0.5
+    g, b = rnd((cols,), torch.float32, dev, seed=22), rnd((cols,), torch.float32, dev, seed=23)
+    ref = F.layer_norm(x.float(), (cols,), g, b, 1e-6)
+    y = ops.layernorm(x, g, b, 1e-6, out_dt)
+    assert relerr(y, ref) < max(TOL[out_dt], 1e-5)
+    xf = x.float()
+    ref = xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-5) * g
+    y = ops.rmsnorm(x, g, 1e-5, out_dt)
+    assert relerr(y, ref) < max(TOL[out_dt], 1e-5)
+
+
+@pytest.mark.parametrize("B,HW,C", [(2, 64, 320), (3, 100, 960), (1, 1024, 1280), (2, 256, 2560), (2, 4096, 640)])
+@pytest.mark.parametrize("silu", [False, True])
+def test_groupnorm(dev, B, HW, C, silu):
+    from seedx_amd import ops
+    x = rnd((B, HW, C), torch.float32, dev, 1.5, seed=24) + 0.3
+    g, b = rnd((C,), torch.float32, dev, seed=25), rnd((C,), torch.float32, dev, seed=26)
+    ref = F.group_norm(x.permute(0, 2, 1), 32, g, b, 1e-5).permute(0, 2, 1)
+    if silu:
+        ref = F.silu(ref)
+    y, raw = ops.groupnorm(x, g, b, 32, 1e-5, silu, torch.float16, want_raw=True)
+    assert relerr(y, ref) < TOL[torch.float16]
+    assert relerr(raw, x) < TOL[torch.float16]
+
+
+def _attn_ref(q, k, v, scale, causal):
+    # q [B,Sq,H,D], k/v [B,Skv,H,D]
+    qf, kf, vf = (t.float().permute(0, 2, 1, 3) for t in (q, k, v))
+    s = (qf @ kf.transpose(-1, -2)) * scale
+    if causal:
+        Sq, Skv = s.shape[-2:]
+        i = torch.arange(Sq, device=s.device)[:, None]
+        j = torch.arange(Skv, device=s.device)[None, :]
+        s = s.masked_fill(j > i + (Skv - Sq), float("-inf"))
+    o = torch.softmax(s, -1) @ vf
+    return o.permute(0, 2, 1, 3).reshape(q.shape[0], q.shape[1], -1)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,H,Sq,Skv,D,causal", [(1, 2, 128, 128, 64, False), (2, 3, 200, 333, 64, False),
+                                                  (1, 2, 256, 64, 64, False), (2, 4, 1024, 1024, 104, False),
+                                                  (1, 2, 64, 64, 128, False), (1, 5, 165, 165, 128, True),
+                                                  (1, 3, 64, 229, 128, True), (1, 2, 300, 300, 64, True),
+                                                  (1, 2, 256, 1024, 128, False), (1, 1, 130, 70, 8, False)])
+def test_attention_mfma(dev, dtype, B, H, Sq, Skv, D, causal):
+    from seedx_amd import ops
+    q = rnd((B, Sq, H, D), dtype, dev, seed=27)
+    k = rnd((B, Skv, H, D), dtype, dev, seed=28)
+    v = rnd((B, Skv, H, D), dtype, dev, seed=29)
+    scale = 1.0 / math.sqrt(D)
+    ref = _attn_ref(q, k, v, scale, causal)
+    out = ops.attention(q, k, v, scale, causal)
+    # P is rounded to 16 bit before P·V: error ~ eps/2 relative
+    assert relerr(out, ref) < (1.2e-3 if dtype == torch.float16 else 8e-3)
+
+
+def test_attention_fused_qkv_layouts(dev):
+    """ViT per-head-interleaved [T, H, 3, D] and blocked [T, 3, H, D] fused-QKV layouts through strided views."""
+    from seedx_amd import ops
+    dtype, B, S, H, D = torch.float16, 2, 160, 4, 104
+    qkv = rnd((B, S, H, 3, D), dtype, dev, seed=30)
+    q, k, v = qkv[:, :, :, 0], qkv[:, :, :, 1], qkv[:, :, :, 2]
+    out = ops.attention(q, k, v, D ** -0.5)
+    assert relerr(out, _attn_ref(q, k, v, D ** -0.5, False)) < 1.2e-3
+    qkv = rnd((B, S, 3, H, 64), dtype, dev, seed=31)
+    q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+    out = ops.attention(q, k, v, 0.125)
+    assert relerr(out, _attn_ref(q, k, v, 0.125, False)) < 1.2e-3
+
+
+def test_attention_spiked_scores(dev):
+    """A large outlier key late in the sequence forces the online-softmax rescale path."""
+    from seedx_amd import ops
+    dtype, B, H, S, D = torch.float16, 1, 2, 512, 64
+    q, k, v = rnd((B, S, H, D), dtype, dev, seed=32), rnd((B, S, H, D), dtype, dev, seed=33), rnd((B, S, H, D), dtype, dev, seed=34)
+    k[:, 400] = q[:, 7] * 3.0
+    out = ops.attention(q, k, v, 0.125)
+    assert relerr(out, _attn_ref(q, k, v, 0.125, False)) < 1.2e-3
+
+
+@pytest.mark.parametrize("B,H,Sq,Skv,D", [(2, 32, 64, 256, 160), (1, 16, 1, 65, 64), (2, 16, 64, 320, 64), (1, 32, 64, 64, 128)])
+def test_attention_small(dev, B, H, Sq, Skv, D):
+    from seedx_amd import ops
+    dtype = torch.float16
+    q, k, v = rnd((B, Sq, H, D), dtype, dev, seed=35), rnd((B, Skv, H, D), dtype, dev, seed=36), rnd((B, Skv, H, D), dtype, dev, seed=37)
+    out = ops.attention_small(q, k, v, D ** -0.5)
+    assert relerr(out, _attn_ref(q, k, v, D ** -0.5, False)) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,K", [(1, 512, 1024), (1, 5120, 5120), (3, 130, 256), (8, 1000, 512)])
+def test_gemv(dev, dtype, M, N, K):
+    from seedx_amd import ops
+    x, w = rnd((M, K), dtype, dev, seed=38), rnd((N, K), dtype, dev, 0.05, seed=39)
+    res = rnd((M, N), torch.float32, dev, seed=40)
+    out = ops.gemv(x, w, residual=res, out_dtype=torch.float32)
+    assert relerr(out, x.float() @ w.float().t() + res) < 5e-5
+    out = ops.gemv(x, w, act="silu")
+    assert relerr(out, F.silu(x.float() @ w.float().t())) < TOL[dtype]
+
+
+@pytest.mark.parametrize("ctx", [1, 17, 166, 1000])
+def test_attn_decode(dev, ctx):
+    from seedx_amd import ops
+    dtype, H, D, Tmax = torch.bfloat16, 8, 128, 1024
+    q = rnd((H, D), dtype, dev, seed=41)
+    kc, vc = rnd((H, Tmax, D), dtype, dev, seed=42), rnd((H, Tmax, D), dtype, dev, seed=43)
+    ctx_dev = torch.tensor([ctx], dtype=torch.int32, device=dev)
+    out = ops.attn_decode(q, kc, vc, ctx_dev, D ** -0.5, nsplit=4)
+    s = torch.einsum("hd,htd->ht", q.float(), kc[:, :ctx].float()) * D ** -0.5
+    ref = torch.einsum("ht,htd->hd", torch.softmax(s, -1), vc[:, :ctx].float()).reshape(1, -1)
+    assert relerr(out, ref) < TOL[dtype]
+
+
+def test_rope_kv_append(dev):
+    from seedx_amd import ops
+    dtype, T, H, D, Tmax, pos0 = torch.float16, 5, 3, 128, 64, 7
+    qkv = rnd((T, 3 * H * D), dtype, dev, seed=44)
+    inv = 1.0 / (10000 ** (torch.arange(0, D, 2).float() / D))
+    fr = torch.outer(torch.arange(Tmax).float(), inv)
+    cos_t, sin_t = fr.cos().to(dev).contiguous(), fr.sin().to(dev).contiguous()
+    kc = torch.zeros((H, Tmax, D), dtype=dtype, device=dev)
+    vc = torch.zeros_like(kc)
+    q0 = qkv.clone()
+    ops.rope_kv_append(qkv, kc, vc, cos_t, sin_t, torch.tensor([pos0], dtype=torch.int32, device=dev), H, D)
+
+    def rope(x, pos):  # x [T,H,D]
+        c = torch.cat([cos_t, cos_t], -1)[pos].to(dtype).float()[:, None, :]
+        s = torch.cat([sin_t, sin_t], -1)[pos].to(dtype).float()[:, None, :]
+        xf = x.float()
+        rot = torch.cat([-xf[..., D // 2:], xf[..., :D // 2]], -1)
+        return xf * c + rot * s
+    pos = torch.arange(pos0, pos0 + T, device=dev)
+    v3 = q0.view(T, 3, H, D)
+    assert relerr(qkv.view(T, 3, H, D)[:, 0], rope(v3[:, 0], pos)) < TOL[dtype]
+    assert relerr(kc[:, pos0:pos0 + T].permute(1, 0, 2), rope(v3[:, 1], pos)) < TOL[dtype]
+    assert torch.equal(vc[:, pos0:pos0 + T].permute(1, 0, 2), v3[:, 2])
+    assert kc[:, :pos0].abs().sum() == 0 and kc[:, pos0 + T:].abs().sum() == 0
+
+
+def test_embedding_scatter_greedy(dev):
+    from seedx_amd import ops
+    table = rnd((100, 64), torch.float16, dev, seed=45)
+    ids = torch.tensor([3, 99, 0, 3], dtype=torch.int32, device=dev)
+    e = ops.embedding(ids, table)
+    assert torch.equal(e, table[ids.long()].float())
+    dst = torch.zeros((10, 64), dtype=torch.float32, device=dev)
+    ops.scatter_rows(e[:2].contiguous(), torch.tensor([7, 2], dtype=torch.int32, device=dev), dst)
+    assert torch.equal(dst[7], e[0]) and torch.equal(dst[2], e[1]) and dst[0].abs().sum() == 0
+    # greedy + logits rule. img ids = [50 (<img>), 51..54, 55 (</img>)]
+    vocab = 90
+    img = torch.tensor([50, 51, 52, 53, 54, 55], dtype=torch.int32, device=dev)
+    logits = rnd((1, 96), torch.float32, dev, seed=46) - 5.0   # all negative → zeroed image ids would win
+    logits[0, 90:] = 100.0                                       # padding columns beyond vocab must be ignored
+    cur = torch.tensor([52], dtype=torch.int32, device=dev)
+    outs = torch.full((4,), -1, dtype=torch.int32, device=dev)
+    step = torch.tensor([1], dtype=torch.int32, device=dev)
+    ops.greedy_next(logits.clone(), vocab, img, cur, cur, outs, step)
+    assert cur.item() == 53 and outs[1].item() == 53                # forced chain
+    cur.fill_(7)
+    l2 = logits.clone()
+    ops.greedy_next(l2, vocab, img, cur, cur)
+    # reference semantics: image ids (except <img>) set to 0.0, then argmax → first zeroed id wins here
+    ref = logits[0, :vocab].clone()
+    ref[img[1:].long()] = 0.0
+    assert cur.item() == int(ref.argmax()) == 51
+    assert torch.equal(l2[0, :vocab], ref)
+    cur.fill_(55)                                                   # </img> is NOT in img_ids[:-1] → normal rule
+    l3 = logits.clone(); l3[0, 10] = 3.0
+    ops.greedy_next(l3, vocab, img, cur, cur)
+    assert cur.item() == 10
+
+
+def test_elementwise(dev):
+    from seedx_amd import ops
+    x = rnd((3, 1001), torch.float32, dev, seed=47)
+    assert torch.equal(ops.cast(x, torch.float16), x.half()) and torch.equal(ops.cast(x, torch.bfloat16), x.bfloat16())
+    assert torch.equal(ops.cast(x.half(), torch.float32), x.half().float())
+    a, b = rnd((50, 64), torch.float32, dev, seed=48), rnd((50, 64), torch.float32, dev, seed=49)
+    assert torch.equal(ops.add(a, b), a + b)
+    dst = torch.zeros((50, 192), dtype=torch.float32, device=dev)
+    ops.copy2d(a, dst, 0); ops.copy2d(b, dst, 128)
+    assert torch.equal(dst[:, :64], a) and torch.equal(dst[:, 128:], b) and dst[:, 64:128].abs().sum() == 0
+    # patchify == conv1 unfold
+    img = rnd((2, 3, 56, 56), torch.float32, dev, seed=50)
+    p = ops.patchify(img, 14, 640, torch.float16)
+    ref = F.unfold(img, 14, stride=14).transpose(1, 2).reshape(-1, 588)
+    assert torch.equal(p[:, :588], ref.half()) and p[:, 588:].abs().sum() == 0
+    # im2col small
+    xs = rnd((2, 6, 5, 4), torch.float32, dev, seed=51)
+    col = ops.im2col3x3_small(xs, 64, torch.float16)
+    w = rnd((16, 36), torch.float16, dev, 0.2, seed=52)
+    wp = torch.zeros((16, 64), dtype=torch.float16, device=dev); wp[:, :36] = w
+    y = ops.gemm(col, wp, out_dtype=torch.float32)
+    refc = _conv_ref(xs.half(), w, None, 1, False).reshape(-1, 16)
+    assert relerr(y, refc) < TOL[torch.float32]
+    # avgpool tokens
+    t = rnd((2, 256, 96), torch.float32, dev, seed=53)
+    assert relerr(ops.avgpool_tokens(t, 4), F.avg_pool1d(t.permute(0, 2, 1), 4, 4).permute(0, 2, 1)) < 1e-6
+    # timestep embedding (flip_sin_to_cos, shift 0)
+    ts = torch.tensor([981.0, 1.0, 1024.0], device=dev)
+    emb = ops.timestep_embedding(ts, 320, torch.float32)
+    half = 160
+    freqs = torch.exp(-math.log(10000) * torch.arange(half, device=dev).float() / half)
+    arg = ts[:, None] * freqs[None]
+    assert (emb - torch.cat([arg.cos(), arg.sin()], -1)).abs().max() < 2e-4
+    idx = torch.tensor([1], dtype=torch.int32, device=dev)
+    emb2 = ops.timestep_embedding(ts, 320, torch.float32, idx_dev=idx, n=2)
+    assert torch.equal(emb2[0], emb[1]) and torch.equal(emb2[1], emb[1])
+    # layouts
+    lat = rnd((2, 4, 8, 8), torch.float32, dev, seed=54)
+    nhwc = ops.nchw_to_nhwc(lat, ld=8)
+    assert torch.equal(nhwc[..., :4], lat.permute(0, 2, 3, 1).reshape(2, 64, 4)) and nhwc[..., 4:].abs().sum() == 0
+    assert torch.equal(ops.nhwc_to_nchw(nhwc, 4, 8, 8), lat)
+    c = torch.tensor([5], dtype=torch.int32, device=dev); ops.add_i32(c, 3); assert c.item() == 8
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_cfg_euler_step(dev, mode):
+    from seedx_amd import ops
+    HW, Cl = 64, 4
+    nb = 2 if mode == 0 else 3
+    ld = 4 if mode == 0 else 8
+    lat = rnd((1, HW, Cl), torch.float32, dev, 5.0, seed=55)
+    eps = rnd((nb, HW, Cl), torch.float32, dev, seed=56)
+    sig = torch.tensor([14.6, 12.1, 9.7, 0.0], device=dev)
+    step = torch.tensor([1], dtype=torch.int32, device=dev)
+    scaled = torch.zeros((nb, HW, ld), dtype=torch.float32, device=dev)
+    lat0 = lat.clone()
+    ops.cfg_euler_step(eps, lat, scaled, sig, step, nb, Cl, ld, 7.5, 1.5, mode)
+    s, sn = 12.1, 9.7
+    if mode == 0:
+        e = eps[0] + 7.5 * (eps[1] - eps[0])
+    else:
+        x0 = [lat0[0] - s * eps[i] for i in range(3)]
+        x0c = x0[2] + 7.5 * (x0[0] - x0[1]) + 1.5 * (x0[1] - x0[2])
+        e = (x0c - lat0[0]) / (-s)
+    ref = lat0[0] + e * (sn - s)
+    assert relerr(lat[0], ref) < 1e-5
+    for kk in range(nb):
+        assert relerr(scaled[kk, :, :Cl], ref / math.sqrt(sn * sn + 1)) < 1e-5
+    assert scaled[..., Cl:].abs().sum() == 0
