@@ -74,6 +74,7 @@ typedef struct sx_gemm_args {
   int32_t B, Hin, Win, Cin, Hout, Wout;
   int32_t stride;   /* 1 or 2 (pad is always 1)                                                      */
   int32_t upsample; /* 1 = input is nearest-2x upsampled on the fly (Hout = 2*Hin)                   */
+  int32_t ld_bias2d; /* row stride of bias2d in floats (0 = N): lets one GEMM produce every resnet's time add    */
 } sx_gemm_args;
 int sx_gemm(const sx_gemm_args* args, void* stream);
 
@@ -207,6 +208,8 @@ int sx_nchw_to_nhwc(const float* src, float* dst, int ld, int B, int C, int HW, 
 int sx_nhwc_to_nchw(const float* src, int ld, float* dst, int B, int C, int HW, void* stream);
 /* *p += delta on the device (step / position counters of graph-replayed loops) */
 int sx_add_i32(int32_t* p, int delta, void* stream);
+/* y = silu(x) as 16-bit (ResnetBlock2D.time_emb_proj input: nonlinearity(temb), diffusers [ext]) */
+int sx_silu_cast(const float* x, void* y, int dtype, int64_t n, void* stream);
 
 /* Fused classifier-free guidance + Euler step on fp32 latents (NHWC [1][HW][C], n = HW*C; eps [nb][HW][C]).
  * mode 0 (t2i, StableDiffusionXLPipeline.__call__ [ext]; order [uncond, text]):

@@ -187,7 +187,8 @@ def logits_rule(last_id, scores, img_ids):
     return scores
 
 
-def greedy_generate(sd, cfg, input_ids, inputs_embeds, img_ids, max_new_tokens, eos_id=None, table_dtype=None):
+def greedy_generate(sd, cfg, input_ids, inputs_embeds, img_ids, max_new_tokens, eos_id=None, table_dtype=None,
+                    force_ids=None, trace=None):
     """HF 4.30.2 greedy_search [ext] as invoked at seed_x.py:184-189 with prepare_inputs_for_generation
     (modeling_llama_xformer.py:748-779): step 0 feeds inputs_embeds, later steps the last token id.
     Returns generated ids (list) and the per-step last-layer (post-norm) hidden states [n_new, H]
@@ -200,6 +201,13 @@ def greedy_generate(sd, cfg, input_ids, inputs_embeds, img_ids, max_new_tokens, 
     for _ in range(max_new_tokens):
         scores = logits_rule(ids[-1], logits[0, -1].clone(), img_ids)
         nxt = int(torch.argmax(scores))
+        if force_ids is not None:
+            # teacher forcing (tests only): follow the given ids, record the oracle's own choice and the score gap
+            # between its arg-max and the forced id, so 16-bit near-ties can be told apart from real mismatches
+            f = int(force_ids[len(new)])
+            if trace is not None:
+                trace.append((nxt, f, float(scores[nxt] - scores[f]), float(scores.std())))
+            nxt = f
         ids.append(nxt)
         new.append(nxt)
         if eos_id is not None and nxt == eos_id:
@@ -214,7 +222,7 @@ def greedy_generate(sd, cfg, input_ids, inputs_embeds, img_ids, max_new_tokens, 
 
 def lvlm_generate(sd_llm, sd_agent, cfg, res_cfg, input_ids, image_embeds, embeds_cmp_mask, ids_cmp_mask,
                   patch_positions, img_ids, boi_id, eoi_id, max_new_tokens, num_img_gen_tokens=64, eos_id=None,
-                  table_dtype=None):
+                  table_dtype=None, force_ids=None, trace=None, return_prefill=False):
     """ContinuousLVLM.generate (seed_x.py:130-223). input_ids: list[int]; image_embeds [n,256,4096]-like or None.
     sd_agent keys: input_resampler.*, output_resampler.*, patch_pos_embed. Returns dict like the reference plus ids."""
     emb = sd_llm["model.embed_tokens.weight"]
@@ -226,7 +234,11 @@ def lvlm_generate(sd_llm, sd_agent, cfg, res_cfg, input_ids, image_embeds, embed
             rel = torch.mm(torch.cat([pp, 1 - pp], dim=-1) / 2, sd_agent["patch_pos_embed"]).unsqueeze(1)
             lm = lm + rel
         x[ids_cmp_mask] = lm[embeds_cmp_mask].view(-1, x.shape[-1])                     # :173
-    new, hidden = greedy_generate(sd_llm, cfg, input_ids, x, img_ids, max_new_tokens, eos_id, table_dtype)
+    if return_prefill:
+        logits, _, hn = llama_forward(sd_llm, cfg, x, None, table_dtype)
+        return {"inputs_embeds": x, "logits": logits, "hidden": hn}
+    new, hidden = greedy_generate(sd_llm, cfg, input_ids, x, img_ids, max_new_tokens, eos_id, table_dtype,
+                                  force_ids, trace)
     n_in = len(input_ids)
     last_hidden = hidden[n_in:]                                                          # :196-197
     gen = torch.tensor(new)

@@ -21,7 +21,7 @@ class GemmArgs(C.Structure):
                 ("res_mod", c_i32), ("bias2d_rows", c_i32), ("dtype", c_i32), ("out_dtype", c_i32),
                 ("act", c_i32), ("glu", c_i32), ("a_mode", c_i32),
                 ("B", c_i32), ("Hin", c_i32), ("Win", c_i32), ("Cin", c_i32), ("Hout", c_i32), ("Wout", c_i32),
-                ("stride", c_i32), ("upsample", c_i32)]
+                ("stride", c_i32), ("upsample", c_i32), ("ld_bias2d", c_i32)]
 
 
 class GemvArgs(C.Structure):
@@ -74,6 +74,7 @@ SIGNATURES = {
     "sx_nchw_to_nhwc": [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp],
     "sx_nhwc_to_nchw": [c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp],
     "sx_add_i32": [c_vp, c_i32, c_vp],
+    "sx_silu_cast": [c_vp, c_vp, c_i32, c_i64, c_vp],
     "sx_cfg_euler_step": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_i32, c_f32, c_f32, c_i32, c_vp],
 }
 

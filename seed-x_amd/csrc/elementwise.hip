@@ -264,3 +264,19 @@ extern "C" int sx_add_i32(int32_t* p, int delta, void* stream) {
   SX_HIP_LAUNCH_CHECK();
   return SX_OK;
 }
+
+// y = silu(x) cast to 16 bit (time-embedding path: every ResnetBlock2D consumes silu(emb))
+__global__ void silu_cast_kernel(const float* x, void* y, int dt, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float v = silu_f(x[i]);
+    ((unsigned short*)y)[i] = dt == SX_BF16 ? BF16::from_f32(v) : F16::from_f32(v);
+  }
+}
+extern "C" int sx_silu_cast(const float* x, void* y, int dtype, int64_t n, void* stream) {
+  SX_CHECK(x && y && (dtype == SX_F16 || dtype == SX_BF16), "sx_silu_cast: bad args");
+  hipLaunchKernelGGL(silu_cast_kernel, dim3((unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256)), dim3(256), 0,
+                     ST, x, y, dtype, n);
+  SX_HIP_LAUNCH_CHECK();
+  return SX_OK;
+}

@@ -27,7 +27,7 @@ struct GemmP {
   const float* bias2d;
   const float* residual;
   int M, N, K, ldc, ldr, n_valid, res_mod, bias2d_rows, out_dtype, act, glu;
-  int Hin, Win, Cin, Hout, Wout, stride, upsample;
+  int Hin, Win, Cin, Hout, Wout, stride, upsample, ldb2;
   int tiles_m, tiles_n;
   unsigned a_bytes, w_bytes;
 };
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
       rv[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     }
     if (p.bias2d) {
-      const float* b2 = p.bias2d + (size_t)(mc / p.bias2d_rows) * p.N;
+      const float* b2 = p.bias2d + (size_t)(mc / p.bias2d_rows) * p.ldb2;
 #pragma unroll
       for (int i = 0; i < FN; ++i) v[i] += *(const f32x4_t*)(b2 + ncol[i]);
     }
@@ -282,6 +282,7 @@ extern "C" int sx_gemm(const sx_gemm_args* a, void* stream) {
   p.M = a->M; p.N = a->N; p.K = a->K; p.ldc = a->ldc; p.ldr = a->ldr; p.res_mod = a->res_mod;
   p.n_valid = a->n_valid > 0 ? a->n_valid : n_out;
   p.bias2d_rows = a->bias2d_rows; p.out_dtype = a->out_dtype; p.act = a->act; p.glu = a->glu;
+  p.ldb2 = a->ld_bias2d > 0 ? a->ld_bias2d : a->N;
   uint64_t a_bytes;
   if (a->a_mode == SX_A_CONV3X3) {
     SX_CHECK(a->Cin % 64 == 0 && a->K == 9 * a->Cin, "sx_gemm conv: Cin=%d K=%d", a->Cin, a->K);

@@ -1,0 +1,399 @@
+"""Path C — SDXL-adapter de-tokenizer on the HIP kernels: ResamplerXLV2, Euler scheduler tables, the two CFG
+denoise loops and the SDXLAdapter / SDXLAdapterWithLatentImage front ends.
+
+Reference interfaces mirrored (same names, argument meaning, defaults):
+  * ``ResamplerXLV2``                        src/models/detokenizer/resampler.py:226-286
+  * ``SDXLAdapter``                          src/models/detokenizer/adapter_modules.py:11-169
+  * ``SDXLAdapterWithLatentImage``           adapter_modules.py:172-287
+  * t2i loop ``StableDiffusionXLPipeline.__call__`` [ext diffusers 0.25.0] as driven by adapter_modules.py:156-167
+  * edit loop ``StableDiffusionXLText2ImageAndEditPipeline.__call__``  pipeline_stable_diffusion_xl_t2i_edit.py:900-963
+  * ``EulerDiscreteScheduler`` [ext] with the SDXL scheduler config (eval_seed_x_detokenizer.py:30)
+The VAE (AutoencoderKL decode/encode) is a "next" row: ``generate`` returns latents unless a VAE
+object exposing ``decode`` is supplied through ``init_pipe``.
+
+One denoise step = {time embeddings → UNet (CFG batch 2 or 3) → fused CFG + Euler update + next scaled input}, all
+device-resident (step counter, sigma table and timestep table live in HBM) and captured once into a HIP graph that is
+replayed ``num_inference_steps`` times.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import ops
+
+
+# ---------------------------------------------------------------------------------------------------------------
+class ResamplerXLV2:
+    def __init__(self, dim=1024, depth=8, dim_head=64, heads=16, num_queries=8, embedding_dim=768, output1_dim=768,
+                 output2_dim=1280, ff_mult=4, normalize=True):
+        if normalize:
+            raise NotImplementedError("normalize=True is not used by the shipped configs (…_no_normalize.yaml)")
+        self.dim, self.depth, self.dim_head, self.heads = dim, depth, dim_head, heads
+        self.num_queries, self.embedding_dim = num_queries, embedding_dim
+        self.o1, self.o2, self.ff_mult = output1_dim, output2_dim, ff_mult
+        self.in_dim, self.out_dim = dim, output1_dim + output2_dim
+        self.device, self.dtype = None, torch.float16
+        self._sd, self._P = None, None
+
+    def load_state_dict(self, sd, prefix="", strict=True):
+        need = ["latents", "proj_in.weight", "norm_out.weight", "unet_proj_1.weight", "unet_attnpool.c_proj.weight"]
+        missing = [prefix + k for k in need if prefix + k not in sd]
+        if missing and strict:
+            raise KeyError(f"ResamplerXLV2: missing keys {missing}")
+        self._sd = {k[len(prefix):]: v.detach().float().cpu() for k, v in sd.items() if k.startswith(prefix)}
+        self._P = None
+        return missing
+
+    def to(self, device=None, dtype=None):
+        if device is not None:
+            self.device = torch.device(device)
+        if dtype is not None:
+            self.dtype = dtype
+        self._P = None
+        return self
+
+    def eval(self):
+        return self
+
+    def requires_grad_(self, flag=True):
+        return self
+
+    def _pack(self):
+        if self._P is not None:
+            return self._P
+        sd, dev, dt = self._sd, self.device, self.dtype
+        f32 = lambda k: sd[k].to(dev, torch.float32).contiguous()
+        w16 = lambda k: sd[k].to(dev, dt).contiguous()
+        P = dict(latents=f32("latents")[0], pin=(w16("proj_in.weight"), f32("proj_in.bias")),
+                 nout=(f32("norm_out.weight"), f32("norm_out.bias")), layers=[])
+        for i in range(self.depth):
+            a, f = f"layers.{i}.0.", f"layers.{i}.1."
+            P["layers"].append(dict(n1=(f32(a + "norm1.weight"), f32(a + "norm1.bias")),
+                                    n2=(f32(a + "norm2.weight"), f32(a + "norm2.bias")),
+                                    wq=w16(a + "to_q.weight"), wkv=w16(a + "to_kv.weight"), wo=w16(a + "to_out.weight"),
+                                    fn=(f32(f + "0.weight"), f32(f + "0.bias")), w1=w16(f + "1.weight"),
+                                    w3=w16(f + "3.weight")))
+        P["proj"] = (torch.cat([sd["unet_proj_1.weight"], sd["unet_proj_2.weight"]], 0).to(dev, dt).contiguous(),
+                     torch.cat([sd["unet_proj_1.bias"], sd["unet_proj_2.bias"]], 0).to(dev, torch.float32).contiguous())
+        p = "unet_attnpool."
+        P["pool_pos"] = f32(p + "positional_embedding")
+        P["pool_q"] = (w16(p + "q_proj.weight"), f32(p + "q_proj.bias"))
+        P["pool_kv"] = (torch.cat([sd[p + "k_proj.weight"], sd[p + "v_proj.weight"]], 0).to(dev, dt).contiguous(),
+                        torch.cat([sd[p + "k_proj.bias"], sd[p + "v_proj.bias"]], 0).to(dev, torch.float32).contiguous())
+        P["pool_c"] = (w16(p + "c_proj.weight"), f32(p + "c_proj.bias"))
+        self._P = P
+        return P
+
+    def forward(self, x, pooled_text_embeds=None):
+        """x [B, n, embedding_dim] → (prompt_embeds [B, nq, o1+o2] fp32, pooled [B, o2] fp32)  (resampler.py:266-286)."""
+        P, dt, dim, heads, hd = self._pack(), self.dtype, self.dim, self.heads, self.dim_head
+        B, n, _ = x.shape
+        nq, inner = self.num_queries, self.heads * self.dim_head
+        x16 = x.to(self.device)
+        x16 = x16.contiguous() if x16.dtype == dt else ops.cast(x16.float().contiguous(), dt)
+        xs = ops.gemm(x16.view(B * n, -1), P["pin"][0], bias=P["pin"][1], out_dtype=torch.float32)       # proj_in
+        lat = P["latents"].unsqueeze(0).expand(B, nq, dim).contiguous().view(B * nq, dim)
+        scale = 1.0 / math.sqrt(hd)                     # (q·hd^-¼)·(k·hd^-¼), resampler.py:68-69
+        for lw in P["layers"]:
+            xn = ops.layernorm(xs, lw["n1"][0], lw["n1"][1], 1e-5, dt)
+            ln = ops.layernorm(lat, lw["n2"][0], lw["n2"][1], 1e-5, dt)
+            q = ops.gemm(ln, lw["wq"]).view(B, nq, heads, hd)
+            kv = torch.empty((B, n + nq, 2 * inner), dtype=dt, device=self.device)                       # cat(x, latents)
+            for b in range(B):
+                ops.gemm(xn[b * n:(b + 1) * n], lw["wkv"], out=kv[b, :n])
+                ops.gemm(ln[b * nq:(b + 1) * nq], lw["wkv"], out=kv[b, n:])
+            kv5 = kv.view(B, n + nq, 2, heads, hd)
+            att = ops.attention(q, kv5[:, :, 0], kv5[:, :, 1], scale)
+            lat = ops.gemm(att.view(B * nq, inner), lw["wo"], residual=lat, out_dtype=torch.float32)
+            h = ops.layernorm(lat, lw["fn"][0], lw["fn"][1], 1e-5, dt)
+            h = ops.gemm(h, lw["w1"], act="gelu")
+            lat = ops.gemm(h, lw["w3"], residual=lat, out_dtype=torch.float32)
+        hid = ops.layernorm(lat, P["nout"][0], P["nout"][1], 1e-5, torch.float32)                        # norm_out
+        hid16 = ops.cast(hid, dt)
+        prompt = ops.gemm(hid16, P["proj"][0], bias=P["proj"][1], out_dtype=torch.float32).view(B, nq, -1)
+        # AttentionPool2d (resampler.py:89-116): token 0 = mean token; only its output row is needed
+        mean = ops.avgpool_tokens(hid.view(B, nq, dim), nq)                                               # [B,1,dim]
+        t = torch.empty((B, nq + 1, dim), dtype=torch.float32, device=self.device)
+        t[:, 0:1] = mean
+        t[:, 1:] = hid.view(B, nq, dim)
+        t = ops.add(t, P["pool_pos"].unsqueeze(0).expand(B, nq + 1, dim).contiguous())
+        t16 = ops.cast(t, dt)
+        kvp = ops.gemm(t16.view(B * (nq + 1), dim), P["pool_kv"][0], bias=P["pool_kv"][1]).view(B, nq + 1, 2, heads, dim // heads)
+        qp = ops.gemm(t16[:, 0].contiguous(), P["pool_q"][0], bias=P["pool_q"][1]).view(B, 1, heads, dim // heads)
+        o = ops.attention_small(qp, kvp[:, :, 0], kvp[:, :, 1], 1.0 / math.sqrt(dim // heads))
+        pooled = ops.gemm(o.view(B, dim), P["pool_c"][0], bias=P["pool_c"][1], out_dtype=torch.float32)
+        return prompt, pooled
+
+    __call__ = forward
+
+
+# ---------------------------------------------------------------------------------------------------------------
+class EulerDiscreteScheduler:
+    """SDXL scheduler config of diffusers' EulerDiscreteScheduler [ext]: scaled_linear betas 0.00085→0.012, 1000 train
+    steps, `leading` spacing, steps_offset 1, epsilon prediction, linear sigma interpolation."""
+    order = 1
+
+    def __init__(self, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, steps_offset=1, **_):
+        self.config = dict(num_train_timesteps=num_train_timesteps, beta_start=beta_start, beta_end=beta_end,
+                           steps_offset=steps_offset, timestep_spacing="leading", prediction_type="epsilon")
+        betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
+        self.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0)
+        self.timesteps, self.sigmas = None, None
+
+    @classmethod
+    def from_pretrained(cls, path, subfolder=None):
+        import json
+        import os
+        f = os.path.join(path, subfolder or "", "scheduler_config.json")
+        j = json.load(open(f))
+        assert j.get("timestep_spacing", "leading") == "leading" and j.get("beta_schedule") == "scaled_linear"
+        return cls(j["num_train_timesteps"], j["beta_start"], j["beta_end"], j.get("steps_offset", 0))
+
+    def set_timesteps(self, num_inference_steps, device=None):
+        n = self.config["num_train_timesteps"]
+        ac = self.alphas_cumprod.numpy()
+        ratio = n // num_inference_steps
+        ts = (np.arange(0, num_inference_steps) * ratio).round()[::-1].copy().astype(np.float32) + self.config["steps_offset"]
+        sig = np.array(((1 - ac) / ac) ** 0.5)
+        sig = np.interp(ts, np.arange(0, len(sig)), sig)
+        sig = np.concatenate([sig, [0.0]]).astype(np.float32)
+        self.timesteps, self.sigmas = torch.from_numpy(ts), torch.from_numpy(sig)
+        self.num_inference_steps = num_inference_steps
+
+    @property
+    def init_noise_sigma(self):
+        return float((self.sigmas.max() ** 2 + 1) ** 0.5)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+class _DenoiseLoop:
+    """Device-resident CFG + Euler loop around UNet.forward_nhwc, one HIP graph replay per step."""
+
+    def __init__(self, unet, use_graph=True):
+        self.unet, self.use_graph = unet, use_graph
+        self._graph_key, self._graph, self._state = None, None, None
+        self._ctx_static = None
+
+    def run(self, mode, latents_nchw, prompt_embeds, pooled, time_ids, scheduler, num_steps, guidance_scale,
+            image_guidance_scale=1.5, image_latents_nchw=None):
+        """mode 0 (t2i): prompt_embeds ordered [uncond, text]; mode 1 (edit): [text, image, uncond].
+        latents_nchw: [1,4,H,W] already multiplied by init_noise_sigma. Returns fp32 [1,4,H,W]."""
+        unet = self.unet
+        unet._pack()
+        dev = unet.device
+        nb = 2 if mode == 0 else 3
+        _, Cl, H, W = latents_nchw.shape
+        HW = H * W
+        cin = unet.cfg["in_channels"]
+        assert cin == (Cl if mode == 0 else 2 * Cl), f"UNet in_channels {cin} does not match mode {mode}"
+        scheduler.set_timesteps(num_steps)
+        ts_dev = scheduler.timesteps.to(dev)
+        sig_dev = scheduler.sigmas.to(dev)
+        key = (mode, H, W, num_steps, float(guidance_scale), float(image_guidance_scale))
+        if self._state is None or self._graph_key != key:
+            self._state = dict(lat=torch.empty((1, HW, Cl), dtype=torch.float32, device=dev),
+                               scaled=torch.zeros((nb, HW, cin), dtype=torch.float32, device=dev),
+                               step=torch.zeros(1, dtype=torch.int32, device=dev),
+                               ehs=torch.empty(prompt_embeds.shape, dtype=torch.float32, device=dev),
+                               pooled=torch.empty(pooled.shape, dtype=torch.float32, device=dev),
+                               tid=torch.empty(time_ids.shape, dtype=torch.float32, device=dev),
+                               ts=torch.empty_like(ts_dev), sig=torch.empty_like(sig_dev))
+            self._graph, self._graph_key = None, key
+            self._ctx_static = None
+        S = self._state
+        S["ts"].copy_(ts_dev); S["sig"].copy_(sig_dev)
+        S["ehs"].copy_(prompt_embeds.to(dev).float()); S["pooled"].copy_(pooled.to(dev).float())
+        S["tid"].copy_(time_ids.to(dev).float())
+        S["step"].zero_()
+        ops.nchw_to_nhwc(latents_nchw.to(dev, torch.float32), dst=S["lat"])
+        s0 = float(scheduler.sigmas[0])
+        S["scaled"][:, :, :Cl] = S["lat"] / math.sqrt(s0 * s0 + 1.0)             # scale_model_input at step 0 (setup)
+        if mode == 1:
+            il = image_latents_nchw.to(dev, torch.float32)                       # [3,4,H,W] = [enc, enc, 0] (:544-546)
+            S["scaled"][:, :, Cl:] = il.permute(0, 2, 3, 1).reshape(nb, HW, Cl)
+        unet._ctx_key = None
+        ctx = unet.prepare_context(S["ehs"])                                      # step-invariant cross-attn K/V
+        if self._graph is not None and self._ctx_static is not None:
+            for per_s, per_n in zip(self._ctx_static, ctx):                       # the graph holds these addresses
+                for a, b in zip(per_s, per_n):
+                    a.copy_(b)
+            ctx = self._ctx_static
+        else:
+            self._ctx_static = ctx
+
+        def step_body():
+            temb = unet.time_embeddings(S["ts"], S["step"], S["pooled"], S["tid"], nb)
+            eps = unet.forward_nhwc(S["scaled"], temb, ctx, nb, H, W)
+            ops.cfg_euler_step(eps, S["lat"], S["scaled"], S["sig"], S["step"], nb, Cl, cin, guidance_scale,
+                               image_guidance_scale, mode)
+            ops.add_i32(S["step"], 1)
+
+        if not self.use_graph:
+            for _ in range(num_steps):
+                step_body()
+        else:
+            if self._graph is None:
+                snap = {k: S[k].clone() for k in ("lat", "scaled", "step")}
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    step_body()                                                   # warm-up (allocator, lazy loads)
+                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    step_body()
+                for k, v in snap.items():
+                    S[k].copy_(v)
+                self._graph = g
+            for _ in range(num_steps):
+                self._graph.replay()
+        return ops.nhwc_to_nchw(S["lat"], Cl, H, W)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+class SDXLAdapter:
+    def __init__(self, unet, resampler, full_ft=False, vit_down=False):
+        self.unet, self.resampler = unet, resampler
+        self.full_ft, self.vit_down = full_ft, vit_down
+        self.device, self.dtype = None, torch.float16
+        self.visual_encoder = self.image_transform = self.discrete_model = self.vae = self.scheduler = None
+        self._neg_cache = {}
+        self._loop = None
+        self.use_graph = True
+
+    @classmethod
+    def from_pretrained(cls, unet, resampler, pretrained_model_path=None, **kwargs):
+        model = cls(unet=unet, resampler=resampler, **kwargs)
+        if pretrained_model_path is not None:
+            ckpt = torch.load(pretrained_model_path, map_location="cpu")          # adapter_modules.py:62-65
+            model.load_state_dict(ckpt)
+        return model
+
+    def load_state_dict(self, sd, strict=True):
+        """Checkpoint keys: resampler.* and unet.* (second stage: 8-channel unet.conv_in)."""
+        self.resampler.load_state_dict(sd, prefix="resampler.", strict=strict)
+        if any(k.startswith("unet.") for k in sd):
+            self.unet.load_state_dict(sd, prefix="unet.", strict=strict)
+        return [], []
+
+    def to(self, device=None, dtype=None):
+        if device is not None:
+            self.device = torch.device(device)
+        if dtype is not None:
+            self.dtype = dtype
+        self.unet.to(self.device, self.dtype)
+        self.resampler.to(self.device, self.dtype)
+        return self
+
+    def eval(self):
+        return self
+
+    def encode_image_embeds(self, image_embeds):
+        return self.resampler(image_embeds)                                         # adapter_modules.py:54-57
+
+    def init_pipe(self, vae, scheduler, visual_encoder, image_transform, discrete_model=None, dtype=torch.float16,
+                  device='cuda'):
+        self.device, self.dtype = torch.device(device), dtype
+        self.vae, self.scheduler = vae, scheduler
+        self.visual_encoder = visual_encoder.to(self.device, dtype=self.dtype)
+        self.discrete_model = discrete_model
+        self.image_transform = image_transform
+        self.to(self.device, self.dtype)
+        self._loop = _DenoiseLoop(self.unet, self.use_graph)
+
+    def _negative_embeds(self, image_size, pooled):
+        """ViT features of an all-zero image: constant per model → cached (the reference recomputes a full ViT forward
+        on every call, adapter_modules.py:109-116)."""
+        key = (image_size, pooled)
+        if key not in self._neg_cache:
+            z = torch.zeros(1, 3, image_size, image_size, device=self.device)
+            e = self.visual_encoder(z).float()
+            if pooled:
+                e = ops.avgpool_tokens(e.contiguous(), 4)                           # avg_pool1d(k=4,s=4), :112-115
+            self._neg_cache[key] = e
+        return self._neg_cache[key]
+
+    @torch.no_grad()
+    def get_image_embeds(self, image_pil=None, image_tensor=None, image_embeds=None, return_negative=True, image_size=448):
+        assert int(image_pil is not None) + int(image_tensor is not None) + int(image_embeds is not None) == 1
+        if image_pil is not None:
+            image_tensor = self.image_transform(image_pil).unsqueeze(0)
+        if image_tensor is not None:
+            image_tensor = image_tensor.to(self.device, torch.float32)
+            if return_negative:
+                image_tensor = torch.cat([image_tensor, torch.zeros_like(image_tensor)], dim=0)   # :103-106
+            image_embeds = self.visual_encoder(image_tensor).float()                # 256 tokens, NO pooling (:108)
+        elif return_negative:
+            neg = self._negative_embeds(image_size, self.vit_down)
+            image_embeds = torch.cat([image_embeds.to(self.device).float(), neg], dim=0)   # :116
+        if self.discrete_model is not None:
+            image_embeds = self.discrete_model.encode_image_embeds(image_embeds)    # identity (discrete_models.py:16-17)
+        prompt, pooled = self.encode_image_embeds(image_embeds)
+        if return_negative:
+            prompt, prompt_neg = prompt.chunk(2)
+            pooled, pooled_neg = pooled.chunk(2)
+        else:
+            prompt_neg = pooled_neg = None
+        return prompt, prompt_neg, pooled, pooled_neg
+
+    def _time_ids(self, height, width, n):
+        return torch.tensor([[height, width, 0, 0, height, width]] * n, dtype=torch.float32)   # _get_add_time_ids :554-566
+
+    def _noise(self, seed, height, width):
+        g = torch.Generator(self.device).manual_seed(seed) if seed is not None else None
+        return torch.randn((1, 4, height // 8, width // 8), generator=g, device=self.device, dtype=torch.float32)
+
+    def _finish(self, latents, output_type):
+        if output_type == "latent" or self.vae is None:
+            return latents
+        scaling = getattr(getattr(self.vae, "config", None), "scaling_factor", 0.13025)
+        img = self.vae.decode(latents / scaling)                                     # pipeline…:965-977
+        return getattr(img, "sample", img)
+
+    def generate(self, image_pil=None, image_tensor=None, image_embeds=None, seed=None, height=1024, width=1024,
+                 guidance_scale=7.5, num_inference_steps=30, input_image_size=448, output_type="latent", latents=None,
+                 **kwargs):
+        pe, pe_neg, pool, pool_neg = self.get_image_embeds(image_pil=image_pil, image_tensor=image_tensor,
+                                                           image_embeds=image_embeds, return_negative=True,
+                                                           image_size=input_image_size)
+        self.scheduler.set_timesteps(num_inference_steps)
+        if latents is None:
+            latents = self._noise(seed, height, width)
+        latents = latents.to(self.device, torch.float32) * self.scheduler.init_noise_sigma
+        ehs = torch.cat([pe_neg, pe], dim=0)                                         # order [uncond, text]
+        pooled = torch.cat([pool_neg, pool], dim=0)
+        out = self._loop.run(0, latents, ehs, pooled, self._time_ids(height, width, 2), self.scheduler,
+                             num_inference_steps, guidance_scale)
+        return self._finish(out, output_type)
+
+
+class SDXLAdapterWithLatentImage(SDXLAdapter):
+    """Edit variant (adapter_modules.py:172-287): 8-channel UNet input, 3-way guidance."""
+
+    def generate(self, image_pil=None, image_tensor=None, image_embeds=None, latent_image=None, seed=42, height=1024,
+                 width=1024, guidance_scale=7.5, num_inference_steps=30, input_image_size=448,
+                 image_guidance_scale=1.5, output_type="latent", latents=None, image_latents=None, **kwargs):
+        pe, pe_neg, pool, pool_neg = self.get_image_embeds(image_pil=image_pil, image_tensor=image_tensor,
+                                                           image_embeds=image_embeds, return_negative=True,
+                                                           image_size=input_image_size)
+        self.scheduler.set_timesteps(num_inference_steps)
+        if latents is None:
+            latents = self._noise(seed, height, width)
+        latents = latents.to(self.device, torch.float32) * self.scheduler.init_noise_sigma
+        if image_latents is None:
+            if latent_image is None:
+                image_latents = torch.zeros(1, 4, height // 8, width // 8)          # pipeline…:909-910 (no source image)
+            else:
+                if self.vae is None:
+                    raise NotImplementedError("VAE encode of `latent_image` is a 'next' row (SURVEY.md §8f-1): pass "
+                                              "`image_latents` = vae.encode(img).latent_dist.mode() (NOT scaled, :523)")
+                image_latents = self.vae.encode(latent_image).latent_dist.mode()
+        il = image_latents.to(self.device, torch.float32)
+        il3 = torch.cat([il, il, torch.zeros_like(il)], dim=0)                       # [img, img, 0]  (:544-546)
+        ehs = torch.cat([pe, pe_neg, pe_neg], dim=0)                                 # order [text, image, uncond] (:884)
+        pooled = torch.cat([pool, pool_neg, pool_neg], dim=0)
+        out = self._loop.run(1, latents, ehs, pooled, self._time_ids(height, width, 3), self.scheduler,
+                             num_inference_steps, guidance_scale, image_guidance_scale, il3)
+        return self._finish(out, output_type)

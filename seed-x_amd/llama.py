@@ -1,0 +1,278 @@
+"""Path B — Llama-style decoder on the HIP kernels (prefill on MFMA, single-token decode on the HBM-bound
+GEMV path, device-resident greedy loop captured in a HIP graph).
+
+Mirrors ``src/models/mllm/modeling_llama_xformer.py`` (``LlamaForCausalLM``: ``forward`` :643-746 semantics —
+logits, past_key_values, hidden_states with the LAST entry = post-final-norm state :595-599 —,
+``get_input_embeddings`` :623) with the reference's state-dict key names. Differences by design:
+  * KV cache is pre-allocated [layer][head][Tmax][hd] and appended in place by the fused RoPE kernel, instead of
+    ``torch.cat`` every step (:215-220)
+  * q/k/v and gate/up projections are fused GEMMs (weights concatenated / GLU-packed at load)
+  * the 4 NaN/Inf guards (:702-713) and the per-layer ``attention_mask.sum()`` sync (:236) are dropped: prefill and
+    multi-token chunks are causal (bottom-right aligned), q_len == 1 attends to the whole cache — same math
+  * logits are only produced for the last position (the greedy loop never reads the others)
+"""
+import math
+
+import torch
+
+from . import ops
+
+
+def glu_pack_rows(lin, gate):
+    """[I,K] linear rows and [I,K] gate rows → [2I,K] in 32-row groups [16 linear | 16 gate] (sx_gemm glu contract)."""
+    I, K = lin.shape
+    assert I % 16 == 0
+    return torch.cat([lin.view(I // 16, 16, K), gate.view(I // 16, 16, K)], dim=1).reshape(2 * I, K).contiguous()
+
+
+class LlamaConfigLite:
+    def __init__(self, hidden_size, intermediate_size, num_hidden_layers, num_attention_heads, vocab_size,
+                 rms_norm_eps=1e-5, max_position_embeddings=4096, rope_base=10000.0, **_):
+        self.hidden_size, self.intermediate_size = hidden_size, intermediate_size
+        self.num_hidden_layers, self.num_attention_heads = num_hidden_layers, num_attention_heads
+        self.vocab_size, self.rms_norm_eps = vocab_size, rms_norm_eps
+        self.max_position_embeddings, self.rope_base = max_position_embeddings, rope_base
+
+
+class _Embedding:
+    """Callable returned by get_input_embeddings(): ids → fp32 embeddings (seed_x.py:158)."""
+
+    def __init__(self, owner):
+        self.owner = owner
+
+    def __call__(self, input_ids):
+        ids = input_ids.to(device=self.owner.device, dtype=torch.int32).reshape(-1).contiguous()
+        e = ops.embedding(ids, self.owner._P["embed"])
+        return e.view(*input_ids.shape, -1)
+
+
+class LlamaForCausalLM:
+    def __init__(self, config, max_cache_len=None):
+        self.config = config if not isinstance(config, dict) else LlamaConfigLite(**config)
+        c = self.config
+        self.H, self.nh, self.L = c.hidden_size, c.num_attention_heads, c.num_hidden_layers
+        self.hd = self.H // self.nh
+        self.I, self.V = c.intermediate_size, c.vocab_size
+        self.Vpad = (self.V + 63) // 64 * 64       # 32330 → 32384: lm_head rows padded with zeros
+        self.Tmax = max_cache_len or c.max_position_embeddings
+        self.device, self.dtype = None, torch.float16
+        self._sd, self._P = None, None
+        self._graph = None
+
+    # ---- reference-compatible plumbing ---------------------------------------------------------------------
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, torch_dtype=torch.float16, low_cpu_mem_usage=True, **kw):
+        """HF directory (config.json + *.bin / *.safetensors shards), like llm_seed_x_i.yaml:1-3."""
+        import glob
+        import json
+        import os
+        cfg = json.load(open(os.path.join(pretrained_model_name_or_path, "config.json")))
+        m = cls(LlamaConfigLite(**cfg), **kw)
+        sd = {}
+        for f in sorted(glob.glob(os.path.join(pretrained_model_name_or_path, "*.safetensors"))):
+            from safetensors.torch import load_file
+            sd.update(load_file(f))
+        for f in sorted(glob.glob(os.path.join(pretrained_model_name_or_path, "pytorch_model*.bin"))):
+            sd.update(torch.load(f, map_location="cpu"))
+        m.load_state_dict(sd)
+        m.dtype = torch_dtype
+        return m
+
+    def expected_keys(self):
+        keys = ["model.embed_tokens.weight", "model.norm.weight", "lm_head.weight"]
+        for i in range(self.L):
+            p = f"model.layers.{i}."
+            keys += [p + f"self_attn.{n}.weight" for n in ("q_proj", "k_proj", "v_proj", "o_proj")]
+            keys += [p + f"mlp.{n}.weight" for n in ("gate_proj", "up_proj", "down_proj")]
+            keys += [p + "input_layernorm.weight", p + "post_attention_layernorm.weight"]
+        return keys
+
+    def load_state_dict(self, sd, strict=True):
+        missing = [k for k in self.expected_keys() if k not in sd]
+        if missing and strict:
+            raise KeyError(f"LlamaForCausalLM: missing keys {missing[:6]} (+{max(0, len(missing) - 6)})")
+        self._sd = sd
+        self._P = None
+        return missing, []
+
+    def to(self, device=None, dtype=None):
+        if device is not None:
+            self.device = torch.device(device)
+        if dtype is not None:
+            assert dtype in (torch.float16, torch.bfloat16)
+            self.dtype = dtype
+        self._P = None
+        return self
+
+    def eval(self):
+        return self
+
+    def get_input_embeddings(self):
+        self._pack()
+        return _Embedding(self)
+
+    # ---- packing ---------------------------------------------------------------------------------------------------
+    def _pack(self):
+        if self._P is not None:
+            return self._P
+        if self._sd is None:
+            raise RuntimeError("LlamaForCausalLM: load_state_dict() first")
+        if self.device is None or self.device.type != "cuda":
+            raise RuntimeError("LlamaForCausalLM runs on the GPU only")
+        sd, dev, dt = self._sd, self.device, self.dtype
+        f32 = lambda t: t.detach().to(dev, torch.float32).contiguous()
+        w16 = lambda t: t.detach().to(dev, dt).contiguous()
+        P = {"embed": w16(sd["model.embed_tokens.weight"]), "norm": f32(sd["model.norm.weight"]), "layers": []}
+        lm = torch.zeros(self.Vpad, self.H, dtype=dt, device=dev)
+        lm[:self.V] = sd["lm_head.weight"].detach().to(dev, dt)
+        P["lm_head"] = lm
+        for i in range(self.L):
+            p = f"model.layers.{i}."
+            qkv = torch.cat([sd[p + f"self_attn.{n}.weight"].detach() for n in ("q_proj", "k_proj", "v_proj")], dim=0)
+            gu = glu_pack_rows(sd[p + "mlp.up_proj.weight"].detach().to(dev, dt), sd[p + "mlp.gate_proj.weight"].detach().to(dev, dt))
+            P["layers"].append(dict(
+                ln1=f32(sd[p + "input_layernorm.weight"]), ln2=f32(sd[p + "post_attention_layernorm.weight"]),
+                wqkv=w16(qkv), wo=w16(sd[p + "self_attn.o_proj.weight"]), wgu=gu,
+                wd=w16(sd[p + "mlp.down_proj.weight"])))
+        inv = 1.0 / (self.config.rope_base ** (torch.arange(0, self.hd, 2).float() / self.hd))
+        fr = torch.outer(torch.arange(self.Tmax).float(), inv)           # [Tmax, hd/2] fp32 (:97-113)
+        P["cos"], P["sin"] = fr.cos().to(dev).contiguous(), fr.sin().to(dev).contiguous()
+        P["kc"] = torch.zeros((self.L, self.nh, self.Tmax, self.hd), dtype=dt, device=dev)
+        P["vc"] = torch.zeros_like(P["kc"])
+        # device-resident loop state
+        P["pos"] = torch.zeros(1, dtype=torch.int32, device=dev)         # position of the next input token
+        P["ctx"] = torch.ones(1, dtype=torch.int32, device=dev)          # pos + 1 (keys visible to that token)
+        P["step"] = torch.zeros(1, dtype=torch.int32, device=dev)        # index into out_ids / hidden buffer
+        P["cur"] = torch.zeros(1, dtype=torch.int32, device=dev)         # current input token id
+        self._P = P
+        self._sd = None
+        self._graph = None
+        return P
+
+    # ---- core passes ---------------------------------------------------------------------------------------------------
+    def reset(self):
+        P = self._pack()
+        P["pos"].zero_()
+        P["step"].zero_()
+        P["ctx"].fill_(1)               # invariant: ctx == pos + 1 (keys visible to the token at `pos`)
+
+    def _layers_multi(self, x, T):
+        """T > 1 tokens at positions pos..pos+T-1 (prefill or a forced-token chunk): MFMA GEMMs + causal flash
+        attention over the cache. x: fp32 [T, H] residual stream. Returns the final residual stream."""
+        P, dt, H, nh, hd = self._P, self.dtype, self.H, self.nh, self.hd
+        pos0 = int(P["pos"].item())
+        Tk = pos0 + T
+        assert Tk <= self.Tmax, f"sequence {Tk} exceeds the KV cache ({self.Tmax})"
+        eps = self.config.rms_norm_eps
+        scale = 1.0 / math.sqrt(hd)
+        for li, lw in enumerate(P["layers"]):
+            h = ops.rmsnorm(x, lw["ln1"], eps, dt)
+            qkv = ops.gemm(h, lw["wqkv"])                                             # [T, 3H]
+            ops.rope_kv_append(qkv, P["kc"][li], P["vc"][li], P["cos"], P["sin"], P["pos"], nh, hd)
+            q4 = qkv.view(1, T, 3, nh, hd)[:, :, 0]
+            k4 = P["kc"][li][:, :Tk].permute(1, 0, 2).unsqueeze(0)                     # [1, Tk, nh, hd] view of the cache
+            v4 = P["vc"][li][:, :Tk].permute(1, 0, 2).unsqueeze(0)
+            att = ops.attention(q4, k4, v4, scale, causal=True)                       # [1, T, H]
+            x = ops.gemm(att.view(T, H), lw["wo"], residual=x, out_dtype=torch.float32)
+            h = ops.rmsnorm(x, lw["ln2"], eps, dt)
+            g = ops.gemm(h, lw["wgu"], act="silu", glu=True)                          # silu(gate) * up, [T, I]
+            x = ops.gemm(g, lw["wd"], residual=x, out_dtype=torch.float32)
+        ops.add_i32(P["pos"], T)
+        ops.add_i32(P["ctx"], T)
+        return x
+
+    def _layers_single(self, x):
+        """One token at position *pos (device scalar): weight-streaming GEMVs + split-KV decode attention. No host
+        reads → graph-capturable."""
+        P, dt, H, nh, hd = self._P, self.dtype, self.H, self.nh, self.hd
+        eps = self.config.rms_norm_eps
+        scale = 1.0 / math.sqrt(hd)
+        for li, lw in enumerate(P["layers"]):
+            h = ops.rmsnorm(x, lw["ln1"], eps, dt)
+            qkv = ops.gemv(h, lw["wqkv"])                                             # [1, 3H]
+            ops.rope_kv_append(qkv, P["kc"][li], P["vc"][li], P["cos"], P["sin"], P["pos"], nh, hd)
+            att = ops.attn_decode(qkv[0, :H].view(nh, hd), P["kc"][li], P["vc"][li], P["ctx"], scale)
+            x = ops.gemv(att, lw["wo"], residual=x, out_dtype=torch.float32)
+            h = ops.rmsnorm(x, lw["ln2"], eps, dt)
+            g = ops.gemv(h, lw["wgu"], act="silu", glu=True)
+            x = ops.gemv(g, lw["wd"], residual=x, out_dtype=torch.float32)
+        ops.add_i32(P["pos"], 1)
+        ops.add_i32(P["ctx"], 1)
+        return x
+
+    def forward_embeds(self, inputs_embeds, need_logits=True):
+        """inputs_embeds: fp32 [T, H] on the GPU, appended at the current cache position.
+        Returns (logits fp32 [Vpad] of the LAST position or None, final-norm hidden states fp32 [T, H])."""
+        P = self._pack()
+        x = inputs_embeds.to(device=self.device, dtype=torch.float32).contiguous()
+        T = x.shape[0]
+        if T == 1:
+            x = self._layers_single(x)
+        else:
+            # ctx counts keys visible to the LAST token of the chunk; _layers_multi advances both by T
+            x = self._layers_multi(x, T)
+        hn = ops.rmsnorm(x, P["norm"], self.config.rms_norm_eps, torch.float32)      # :595
+        logits = None
+        if need_logits:
+            logits = ops.linear(ops.cast(hn[-1:].contiguous(), self.dtype), P["lm_head"], out_dtype=torch.float32)[0]
+        return logits, hn
+
+    # reference-style entry (prefill + cached steps through inputs_embeds / input_ids), batch 1
+    def forward(self, input_ids=None, inputs_embeds=None, past_key_values=None, use_cache=True,
+                output_hidden_states=False, return_dict=True, **_):
+        """Subset of the reference forward (:643-746) that the inference path uses: batch 1; the KV cache lives in
+        the module (``past_key_values=None`` resets it, anything else continues). Returns a dict with ``logits``
+        [1, 1, V] (last position only), ``hidden_states`` = (final-norm states [1, T, H],) and ``past_key_values``
+        = a token standing for the internal cache."""
+        self._pack()
+        if past_key_values is None:
+            self.reset()
+        if inputs_embeds is None:
+            inputs_embeds = self.get_input_embeddings()(input_ids)
+        x = inputs_embeds.reshape(-1, self.H)
+        logits, hn = self.forward_embeds(x)
+        out = {"logits": logits[: self.V].view(1, 1, -1), "past_key_values": "internal-cache",
+               "hidden_states": (hn.view(1, -1, self.H),) if output_hidden_states else None}
+        return out
+
+    __call__ = forward
+
+    # ---- device-resident greedy decode step ---------------------------------------------------------------------
+    def _decode_step_body(self, img_ids_dev, out_ids, hid_buf):
+        """cur → embedding → 40 layers → final norm → lm_head → logits rule + argmax → cur. Also records the
+        post-norm hidden state of the INPUT token at hid_buf[step] (what seed_x.py:196 collects) and the new id at
+        out_ids[step]; then step += 1. Everything stays on the device."""
+        P = self._P
+        x = ops.embedding(P["cur"], P["embed"])                                        # [1, H] fp32
+        x = self._layers_single(x)
+        hn = ops.rmsnorm(x, P["norm"], self.config.rms_norm_eps, torch.float32)
+        ops.scatter_rows(hn, P["step"], hid_buf)
+        logits = ops.gemv(ops.cast(hn, self.dtype), P["lm_head"], out_dtype=torch.float32)
+        ops.greedy_next(logits, self.V, img_ids_dev, P["cur"], P["cur"], out_ids, P["step"])
+        ops.add_i32(P["step"], 1)
+
+    def decode_step(self, img_ids_dev, out_ids, hid_buf, use_graph=True):
+        self._pack()
+        if not use_graph:
+            self._decode_step_body(img_ids_dev, out_ids, hid_buf)
+            return
+        key = (img_ids_dev.data_ptr(), out_ids.data_ptr(), hid_buf.data_ptr())
+        if self._graph is None or self._graph[0] != key:
+            # warm-up on a side stream (allocator / lazy module load), then capture one token step
+            P = self._P
+            snap = {k: P[k].clone() for k in ("pos", "ctx", "step", "cur")}
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                self._decode_step_body(img_ids_dev, out_ids, hid_buf)
+            torch.cuda.current_stream().wait_stream(s)
+            torch.cuda.synchronize()
+            for k, v in snap.items():
+                P[k].copy_(v)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._decode_step_body(img_ids_dev, out_ids, hid_buf)
+            for k, v in snap.items():
+                P[k].copy_(v)
+            self._graph = (key, g)
+        self._graph[1].replay()

@@ -46,7 +46,7 @@ def _f32c(t):
 # GEMM family
 # ---------------------------------------------------------------------------------------------------------
 def gemm(a, w, bias=None, bias2d=None, bias2d_rows=0, residual=None, res_mod=0, act=None, glu=False,
-         out_dtype=None, out=None, n_valid=0):
+         out_dtype=None, out=None, n_valid=0, ld_bias2d=0):
     """out[M, N_out] = epilogue(a[M, K] @ w[N, K]^T). a, w: 16-bit contiguous. residual/bias fp32."""
     lib = _lib.load()
     assert a.dim() == 2 and w.dim() == 2 and a.is_contiguous() and w.is_contiguous()
@@ -63,7 +63,10 @@ def gemm(a, w, bias=None, bias2d=None, bias2d_rows=0, residual=None, res_mod=0, 
     args = GemmArgs()
     args.A, args.W, args.C = a.data_ptr(), w.data_ptr(), out.data_ptr()
     args.bias = _f32c(bias).data_ptr() if bias is not None else None
-    args.bias2d = _f32c(bias2d).data_ptr() if bias2d is not None else None
+    if bias2d is not None:
+        assert bias2d.dtype == torch.float32 and bias2d.stride(-1) == 1
+        args.bias2d = bias2d.data_ptr()
+        args.ld_bias2d = ld_bias2d or bias2d.stride(0)
     if residual is not None:
         assert residual.dtype == torch.float32 and residual.stride(-1) == 1
         args.residual = residual.data_ptr()
@@ -82,7 +85,8 @@ def gemm(a, w, bias=None, bias2d=None, bias2d_rows=0, residual=None, res_mod=0, 
     return out
 
 
-def conv3x3(x, w, bias=None, bias2d=None, residual=None, stride=1, upsample=False, out_dtype=None, act=None):
+def conv3x3(x, w, bias=None, bias2d=None, residual=None, stride=1, upsample=False, out_dtype=None, act=None,
+            n_valid=0):
     """3x3 / pad 1 convolution as implicit GEMM. x: [B, H, W, Cin] 16-bit NHWC contiguous; w: [Cout, 9*Cin]
     ((ky,kx,cin)-ordered). Returns [B, Hout*Wout, Cout] (NHWC flattened). bias2d: [B, Cout] fp32 per-sample add.
     residual: fp32 [B*Hout*Wout, Cout]."""
@@ -95,19 +99,23 @@ def conv3x3(x, w, bias=None, bias2d=None, residual=None, stride=1, upsample=Fals
     Hout, Wout = (hv + 2 - 3) // stride + 1, (wv + 2 - 3) // stride + 1
     M = B * Hout * Wout
     out_dtype = out_dtype or x.dtype
-    out = torch.empty((M, Cout), dtype=out_dtype, device=x.device)
+    n_store = n_valid if n_valid else Cout
+    out = torch.empty((M, n_store), dtype=out_dtype, device=x.device)
     args = GemmArgs()
     args.A, args.W, args.C = x.data_ptr(), w.data_ptr(), out.data_ptr()
     args.bias = _f32c(bias).data_ptr() if bias is not None else None
+    args.n_valid = n_valid
     if bias2d is not None:
-        args.bias2d = _f32c(bias2d).data_ptr()
+        assert bias2d.dtype == torch.float32 and bias2d.stride(-1) == 1 and bias2d.shape == (B, Cout)
+        args.bias2d = bias2d.data_ptr()
         args.bias2d_rows = Hout * Wout
+        args.ld_bias2d = bias2d.stride(0)
     if residual is not None:
         assert residual.dtype == torch.float32 and residual.stride(-1) == 1
         args.residual = residual.data_ptr()
         args.ldr = residual.stride(0)
     args.M, args.N, args.K = M, Cout, K
-    args.ldc = Cout
+    args.ldc = n_store
     args.dtype = _DT[x.dtype]
     args.out_dtype = _DT[out_dtype]
     args.act = ACT[act]
@@ -116,7 +124,7 @@ def conv3x3(x, w, bias=None, bias2d=None, residual=None, stride=1, upsample=Fals
     args.stride = stride
     args.upsample = 1 if upsample else 0
     check(lib.sx_gemm(C.byref(args), _stream()), "sx_gemm(conv3x3)")
-    return out.view(B, Hout * Wout, Cout)
+    return out.view(B, Hout * Wout, n_store)
 
 
 def gemv(x, w, residual=None, act=None, glu=False, out_dtype=None):
@@ -361,6 +369,14 @@ def nhwc_to_nchw(src, Cc, H, W):
     dst = torch.empty((B, Cc, H, W), dtype=torch.float32, device=src.device)
     check(lib.sx_nhwc_to_nchw(_p(src), ld, _p(dst), B, Cc, H * W, _stream()), "sx_nhwc_to_nchw")
     return dst
+
+
+def silu_cast(x, dtype):
+    lib = _lib.load()
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    y = torch.empty(x.shape, dtype=dtype, device=x.device)
+    check(lib.sx_silu_cast(_p(x), _p(y), _DT[dtype], x.numel(), _stream()), "sx_silu_cast")
+    return y
 
 
 def add_i32(p, delta):
