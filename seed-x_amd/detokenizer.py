@@ -46,11 +46,13 @@ class ResamplerXLV2:
         return missing
 
     def to(self, device=None, dtype=None):
+        old = (self.device, self.dtype)
         if device is not None:
             self.device = torch.device(device)
         if dtype is not None:
             self.dtype = dtype
-        self._P = None
+        if (self.device, self.dtype) != old:
+            self._P = None
         return self
 
     def eval(self):

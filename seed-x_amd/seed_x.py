@@ -65,7 +65,7 @@ class ContinuousLVLM:
     def generate(self, tokenizer, prompt=None, input_ids=None, image_embeds=None, embeds_cmp_mask=None,
                  ids_cmp_mask=None, logits_processor=None, num_img_gen_tokens=64, temperature=0.7, num_beams=1,
                  max_new_tokens=120, top_p=0.5, dtype=torch.float16, device='cuda', patch_positions=None,
-                 eos_token_id="auto"):
+                 eos_token_id="auto", force_image_at=None):
         """Greedy (do_sample=False, num_beams=1 — temperature/top_p are inert in the reference too, seed_x.py:175-189).
         ``eos_token_id``: "auto" → tokenizer.eos_token_id; None disables the EOS stop (fixed-length benchmarking)."""
         assert logits_processor is None, "the AutoImageTokenGenerationProcessor rule is fused on the device"
@@ -117,6 +117,17 @@ class ContinuousLVLM:
         ops.add_i32(P["step"], 1)
         n_new = 1
         cur = int(P["cur"].item())
+
+        def maybe_force(cur):
+            # synthetic-weights benchmarking only: random-init weights never emit <img>, so the transcript is pinned by
+            # overwriting generated token #force_image_at with <img> AFTER its full forward/lm_head/argmax has run
+            # (no work is skipped). Never set with real checkpoints.
+            if force_image_at is not None and n_new - 1 == force_image_at:
+                P["cur"].fill_(boi_id)
+                out_ids[n_new - 1] = boi_id
+                return boi_id
+            return cur
+        cur = maybe_force(cur)
         # ---- token loop -------------------------------------------------------------------------------------------
         while n_new < max_new_tokens and not (eos_token_id is not None and cur == eos_token_id):
             nchunk = num_img_gen_tokens + 1
@@ -134,7 +145,7 @@ class ContinuousLVLM:
                 continue
             llm.decode_step(img_ids_dev, out_ids, hid, use_graph=self.use_graph)
             n_new += 1
-            cur = int(P["cur"].item())
+            cur = maybe_force(int(P["cur"].item()))
 
         generate_ids = out_ids[:n_new].cpu().long()
         last_hidden = hid[1:n_new]                                                           # seed_x.py:196-197

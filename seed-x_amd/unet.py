@@ -89,13 +89,17 @@ class UNet2DConditionModel:
         return missing, []
 
     def to(self, device=None, dtype=None):
+        old = (self.device, self.dtype)
         if device is not None:
             self.device = torch.device(device)
         if dtype is not None:
             assert dtype in (torch.float16, torch.bfloat16)
             self.dtype = dtype
-        self._P = None
-        self._ctx_key = None
+        if (self.device, self.dtype) != old:
+            if self._P is not None and self._sd is None:
+                raise RuntimeError("weights were already packed for %s/%s; reload the state dict to move them" % old)
+            self._P = None
+            self._ctx_key = None
         return self
 
     def eval(self):

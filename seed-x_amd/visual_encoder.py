@@ -77,7 +77,7 @@ class Resampler:
         missing = []
         for n in self.parameter_names():
             if prefix + n in sd:
-                own[n] = sd[prefix + n].detach().float().cpu()
+                own[n] = sd[prefix + n].detach()
             elif n == "pos_embed":
                 own[n] = get_2d_sincos_pos_embed(self.embed_dim, self.grid_size)
             else:
@@ -89,11 +89,13 @@ class Resampler:
         return missing
 
     def to(self, device=None, dtype=None):
+        old = (self.device, self.dtype)
         if device is not None:
             self.device = torch.device(device)
         if dtype is not None:
             self.dtype = dtype
-        self._packed = {}
+        if (self.device, self.dtype) != old:
+            self._packed = {}
         return self
 
     def eval(self):
@@ -110,11 +112,11 @@ class Resampler:
         if "kv_proj.weight" in sd:
             P["kv_w"] = w16(sd["kv_proj.weight"])
         P["ln_kv"] = (f32(sd["ln_kv.weight"]), f32(sd["ln_kv.bias"]))
-        Win, bin_ = sd["attn.in_proj_weight"], sd["attn.in_proj_bias"]
+        Win, bin_ = sd["attn.in_proj_weight"], sd["attn.in_proj_bias"].float().cpu()
         # K/V projections fused: [2E, E]; the key-side position term in_proj_k(pos↑)+b_k is a constant table
         P["kv_in_w"] = w16(Win[E:])
-        pos_k = get_abs_pos(sd["pos_embed"], n_kv)                                 # [n_kv, E] fp32 (host, constant)
-        kb = pos_k @ Win[E:2 * E].t() + bin_[E:2 * E]                              # fp32 host precompute
+        pos_k = get_abs_pos(sd["pos_embed"].float().cpu(), n_kv)                   # [n_kv, E] fp32 (host, constant)
+        kb = pos_k @ Win[E:2 * E].float().cpu().t() + bin_[E:2 * E]                # fp32 host precompute (load time)
         vb = bin_[2 * E:].unsqueeze(0).expand(n_kv, E)
         P["kv_res"] = f32(torch.cat([kb, vb], dim=1))                              # residual table, rows m % n_kv
         P["out_w"] = w16(sd["attn.out_proj.weight"])
@@ -198,19 +200,24 @@ class VisionTransformerWithAttnPool:
         missing = [k for k in self.expected_keys() if k not in sd and k != "attn_pool.pos_embed"]
         if missing and strict:
             raise KeyError(f"VisionTransformerWithAttnPool: missing keys {missing[:8]} (+{max(0, len(missing) - 8)})")
-        self._sd = {k: v.detach().float().cpu() for k, v in sd.items() if k in set(self.expected_keys())}
+        keys = set(self.expected_keys())
+        self._sd = {k: v.detach() for k, v in sd.items() if k in keys}
         self.attn_pool.load_state_dict(sd, prefix="attn_pool.", strict=strict)
         self._P = None
         return missing, []
 
     def to(self, device=None, dtype=None):
+        old = (self.device, self.dtype)
         if device is not None:
             self.device = torch.device(device)
         if dtype is not None:
             assert dtype in (torch.float16, torch.bfloat16), "compute dtype must be fp16 or bf16"
             self.dtype = dtype
         self.attn_pool.to(self.device, self.dtype)
-        self._P = None
+        if (self.device, self.dtype) != old:
+            if self._P is not None and self._sd is None:
+                raise RuntimeError("weights were already packed for %s/%s; reload the state dict to move them" % old)
+            self._P = None
         return self
 
     def eval(self):
@@ -232,10 +239,10 @@ class VisionTransformerWithAttnPool:
         w16 = lambda t: t.to(dev, dt).contiguous()
         P = {}
         cw = sd["conv1.weight"].reshape(W, -1)
-        cwp = torch.zeros(W, self.kpad)
+        cwp = torch.zeros(W, self.kpad, dtype=cw.dtype, device=cw.device)
         cwp[:, :cw.shape[1]] = cw
         P["conv_w"] = w16(cwp)
-        P["pos"] = f32(get_abs_pos(sd["positional_embedding"], self.grid * self.grid))
+        P["pos"] = f32(get_abs_pos(sd["positional_embedding"].float().cpu(), self.grid * self.grid))
         P["ln_pre"] = (f32(sd["ln_pre.weight"]), f32(sd["ln_pre.bias"]))
         P["layers"] = []
         for i in range(self.layers):
