@@ -77,6 +77,8 @@ typedef struct sx_gemm_args {
   int32_t ld_bias2d; /* row stride of bias2d in floats (0 = N): lets one GEMM produce every resnet's time add    */
 } sx_gemm_args;
 int sx_gemm(const sx_gemm_args* args, void* stream);
+/* tuning/test hook: force tile config 0..3 (128x128, 128x80, 64x128, 64x64); -1 = automatic */
+int sx_gemm_force_tile(int cfg);
 
 /* batch-1..8 row GEMV for single-token decode (HBM-bound weight streaming, no MFMA).
  * replaces: the same nn.Linear calls at q_len == 1 (modeling_llama_xformer.py:204-206,239,166-167,707).

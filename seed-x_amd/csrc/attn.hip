@@ -159,23 +159,27 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnP p) {
       }
     }
     // ---- online softmax (log2 domain), lane owns query row qrow ------------------------------------
-    const int kmax = p.causal ? (qrow + coff) : 0x7fffffff;
+    // raw scores stay unscaled: p = exp2(s*c - m*c) is ONE fma + v_exp per element; masking only on edge tiles
+    const float c = p.scale_log2;
+    if (p.causal || kv0 + 64 > p.Skv) {  // wave-uniform: interior tiles skip the mask entirely
+      const int kmax = p.causal ? (qrow + coff) : 0x7fffffff;
+#pragma unroll
+      for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int kv = kv0 + 32 * jb + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          if (kv >= p.Skv || kv > kmax) s[jb][r] = -INFINITY;
+        }
+    }
     float mloc = -INFINITY;
 #pragma unroll
-    for (int jb = 0; jb < 2; ++jb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int kv = kv0 + 32 * jb + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        float v = s[jb][r] * p.scale_log2;
-        if (kv >= p.Skv || kv > kmax) v = -INFINITY;
-        s[jb][r] = v;
-        mloc = fmaxf(mloc, v);
-      }
+    for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, fmaxf(s[0][r], s[1][r]));
     mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
     const float m_new = fmaxf(m_run, mloc);
     const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
-    const float alpha = (m_run == -INFINITY) ? 0.f : exp2f(m_run - m_safe);
+    const float alpha = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f((m_run - m_safe) * c);
     m_run = m_new;
+    const float mc = -m_safe * c;
     float psum = 0.f;
     vec8 pb[4];
 #pragma unroll
@@ -185,18 +189,20 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnP p) {
         unsigned w[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const float p0 = exp2f(s[jb][8 * s2 + 2 * j] - m_safe);
-          const float p1 = exp2f(s[jb][8 * s2 + 2 * j + 1] - m_safe);
+          const float p0 = __builtin_amdgcn_exp2f(fmaf(s[jb][8 * s2 + 2 * j], c, mc));
+          const float p1 = __builtin_amdgcn_exp2f(fmaf(s[jb][8 * s2 + 2 * j + 1], c, mc));
           psum += p0 + p1;
           w[j] = pack2<TT>(p0, p1);
         }
         __builtin_memcpy(&pb[2 * jb + s2], w, 16);
       }
     l_run = l_run * alpha + psum;
+    if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {  // wave-uniform: the running max rarely moves after the first tiles
 #pragma unroll
-    for (int i = 0; i < NDT; ++i)
+      for (int i = 0; i < NDT; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+        for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+    }
 
     // ---- O^T += V^T · P^T ---------------------------------------------------------------------------
 #pragma unroll

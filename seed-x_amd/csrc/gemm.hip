@@ -4,14 +4,17 @@
 //
 // Replaces every nn.Linear / nn.Conv2d(3x3) on the SEED-X hot path (see include/seedx_hip.h for the
 // reference call sites). Design:
-//   * block = 4 waves (2x2), tile BM x BN x 64; each wave owns (BM/2)x(BN/2) as 16x16x32 MFMA fragments
+//   * block = 4 waves laid out WM x WN over a BM x BN x 64 tile; each wave owns (BM/WM)x(BN/WN) as
+//     16x16x32 MFMA fragments. Tile shapes: 128x128 (2x2), 128x80 (4x1: N = 320/640/1280 of the SDXL UNet
+//     divide into exactly k·256 tiles), 64x128, 64x64 — picked per problem to fill the 256 CUs
 //   * A and W tiles are DMA'd HBM→LDS with `buffer_load_dwordx4 … lds` (no VGPR round trip); rows
 //     beyond M / N and zero-padding taps of the convolution use the buffer descriptor's range check
 //     (offset >= num_records returns 0), so there is no edge code in the main loop
 //   * LDS rows are 128 B (64 k-elements); the 16-B chunk index is XOR-swizzled with (row & 7). The DMA
 //     destination is lane-linear, so the swizzle is applied to the per-lane SOURCE address and again on
 //     the ds_read_b128 side (same involution) → conflict-free fragment reads
-//   * 2-stage LDS ring, one barrier per k-tile: next tile's DMA is issued before the MFMAs of the current
+//   * NSTAGE-deep LDS ring (2 or 3), ONE raw s_barrier per k-tile; DMA of later tiles stays in flight
+//     across the barrier and is retired with a COUNTED `s_waitcnt vmcnt(N)` (never a drain in steady state)
 //   * operands are swapped in the MFMA (D = Wfrag · Afrag^T) so a lane ends up with 4 CONSECUTIVE output
 //     columns of one row → vector bias/residual loads and 8/16-byte stores in the fused epilogue
 //   * 1-D grid with a bijective XCD remap: consecutive tiles (same W panel) share one XCD's L2
@@ -32,19 +35,29 @@ struct GemmP {
   unsigned a_bytes, w_bytes;
 };
 
-template <typename TT, int BM, int BN, int AMODE>
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <typename TT, int BM, int BN, int WM, int WN, int NSTAGE, int AMODE>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // body uses gfx950-only builtins (LDS-DMA, MFMA); the host pass only needs the stub
   typedef typename TT::vec8 vec8;
-  constexpr int FM = BM / 32, FN = BN / 32;  // 16x16 fragments per wave along m / n
-  constexpr int A_PER_WAVE = BM / 32;        // 1-KiB DMA slots (8 rows x 128 B) per wave per k-tile
-  constexpr int B_PER_WAVE = BN / 32;
-  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+  static_assert(WM * WN == 4, "4 waves per block");
+  constexpr int TM = BM / WM, TN = BN / WN;       // wave tile
+  constexpr int FM = TM / 16, FN = TN / 16;       // 16x16 fragments per wave along m / n
+  constexpr int BNP = (BN + 31) / 32 * 32;        // W rows staged per tile (padded so every wave issues the same count)
+  constexpr int A_PER_WAVE = BM / 32;             // 1-KiB DMA slots (8 rows x 128 B) per wave per k-tile
+  constexpr int B_PER_WAVE = BNP / 32;
+  constexpr int LOADS = A_PER_WAVE + B_PER_WAVE;  // DMA instructions per wave per k-tile (vmcnt unit)
+  constexpr int A_BYTES = BM * 128, B_BYTES = BNP * 128, STAGE = A_BYTES + B_BYTES;
+  static_assert(LOADS * (NSTAGE - 1) <= 63, "vmcnt range");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
 
   const int t = xcd_remap(blockIdx.x, gridDim.x);
   const int tile_m = t % p.tiles_m, tile_n = t / p.tiles_m;
@@ -77,8 +90,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
   }
 #pragma unroll
   for (int i = 0; i < B_PER_WAVE; ++i) {
-    const int row = n0 + (wave * B_PER_WAVE + i) * 8 + rl;
-    w_off[i] = (row < p.N) ? (unsigned)row * (unsigned)p.K * 2u + gchunk : 0x80000000u;
+    const int lrow = (wave * B_PER_WAVE + i) * 8 + rl;   // rows >= BN are padding: fetched as zeros, never read
+    const int row = n0 + lrow;
+    w_off[i] = (row < p.N && lrow < BN) ? (unsigned)row * (unsigned)p.K * 2u + gchunk : 0x80000000u;
   }
   const int Hv = p.upsample ? 2 * p.Hin : p.Hin, Wv = p.upsample ? 2 * p.Win : p.Win;
   const int cpt = (AMODE == SX_A_CONV3X3) ? p.Cin / 64 : 1;  // k-tiles per filter tap
@@ -128,13 +142,19 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
   frag_sw[1] = (unsigned)((4 + (lane >> 4)) ^ (lane & 7)) << 4;
 
   const int nkt = p.K / 64;
-  stage(0, 0);
-  __syncthreads();
+  constexpr int D = NSTAGE - 1;  // prefetch distance in k-tiles
+#pragma unroll
+  for (int s = 0; s < D; ++s)
+    if (s < nkt) stage(s, s);
+  int cur = 0, nxt = D % NSTAGE;  // ring slots of tile kt and tile kt + D
   for (int kt = 0; kt < nkt; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nkt) stage(cur ^ 1, kt + 1);
-    const unsigned char* sA = smem + cur * STAGE + (wm * (BM / 2)) * 128;
-    const unsigned char* sB = smem + cur * STAGE + A_BYTES + (wn * (BN / 2)) * 128;
+    // tile kt must have landed (this wave's share): allow the younger (D-1) tiles to stay in flight
+    if (D >= 2 && kt + 1 < nkt) wait_vmcnt<LOADS*(D - 1)>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();  // everyone's share landed AND everyone finished reading ring slot `nxt`
+    if (kt + D < nkt) stage(nxt, kt + D);
+    const unsigned char* sA = smem + cur * STAGE + (wm * TM) * 128;
+    const unsigned char* sB = smem + cur * STAGE + A_BYTES + (wn * TN) * 128;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       vec8 af[FM], wf[FN];
@@ -147,7 +167,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
 #pragma unroll
         for (int j = 0; j < FM; ++j) acc[i][j] = TT::mfma16(wf[i], af[j], acc[i][j]);
     }
-    __syncthreads();
+    cur = (cur + 1 == NSTAGE) ? 0 : cur + 1;
+    nxt = (nxt + 1 == NSTAGE) ? 0 : nxt + 1;
   }
 
   // ---- fused epilogue: lane holds C[m][n .. n+3], m = ..+(lane&15), n = ..+(lane>>4)*4 ----------
@@ -159,7 +180,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
   f32x4_t bv[FN];
 #pragma unroll
   for (int i = 0; i < FN; ++i) {
-    const int nb = n0 + wn * (BN / 2) + i * 16;
+    const int nb = n0 + wn * TN + i * 16;
     ncol[i] = nb + lq;
     nout[i] = p.glu ? (nb >> 1) + lq : ncol[i];
     nok[i] = ncol[i] < p.N && nout[i] < p.n_valid && !(p.glu && (i & 1));
@@ -173,7 +194,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
   }
 #pragma unroll
   for (int j = 0; j < FM; ++j) {
-    const int m = m0 + wm * (BM / 2) + j * 16 + (lane & 15);
+    const int m = m0 + wm * TM + j * 16 + (lane & 15);
     const bool mok = m < p.M;
     const int mc = mok ? m : p.M - 1;
     f32x4_t v[FN], rv[FN];
@@ -226,41 +247,53 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
 #endif
 }
 
-template <typename TT, int BM, int BN>
+template <typename TT, int BM, int BN, int WM, int WN, int NSTAGE>
 int launch_cfg(const GemmP& p0, int a_mode, hipStream_t st) {
   GemmP p = p0;
   p.tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.N + BN - 1) / BN;
   const int grid = p.tiles_m * p.tiles_n;
-  const size_t lds = 2 * (size_t)(BM + BN) * 128;
-  if (a_mode == SX_A_LINEAR)
-    hipLaunchKernelGGL((gemm_kernel<TT, BM, BN, SX_A_LINEAR>), dim3(grid), dim3(256), lds, st, p);
-  else
-    hipLaunchKernelGGL((gemm_kernel<TT, BM, BN, SX_A_CONV3X3>), dim3(grid), dim3(256), lds, st, p);
+  const size_t lds = (size_t)NSTAGE * (BM + (BN + 31) / 32 * 32) * 128;
+  if (a_mode == SX_A_LINEAR) {
+    auto k = gemm_kernel<TT, BM, BN, WM, WN, NSTAGE, SX_A_LINEAR>;
+    if (lds > 65536) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, p);
+  } else {
+    auto k = gemm_kernel<TT, BM, BN, WM, WN, NSTAGE, SX_A_CONV3X3>;
+    if (lds > 65536) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, p);
+  }
   SX_HIP_LAUNCH_CHECK();
   return SX_OK;
 }
 
+// tile menu: {BM, BN, relative per-tile efficiency, usable with glu}
+struct TileCfg { int bm, bn; double eff; bool glu_ok; };
+static const TileCfg kTiles[4] = {{128, 128, 1.00, true}, {128, 80, 0.88, false}, {64, 128, 0.85, true}, {64, 64, 0.65, true}};
+
 // pick the tile that minimises (rounds over the 256 CUs) x (tile area / efficiency)
-inline int pick_tile(int M, int N) {
-  const int bm[3] = {128, 64, 64}, bn[3] = {128, 128, 64};
-  const double eff[3] = {1.0, 0.85, 0.65};
-  int best = 0;
-  double best_cost = 1e30;
-  for (int c = 0; c < 3; ++c) {
-    const long tiles = (long)((M + bm[c] - 1) / bm[c]) * ((N + bn[c] - 1) / bn[c]);
-    const long rounds = (tiles + 255) / 256;
-    const double cost = (double)rounds * bm[c] * bn[c] / eff[c];
-    if (cost < best_cost * 0.999) {
-      best_cost = cost;
-      best = c;
-    }
-  }
-  return best;
+// Rules fitted to the MI355X sweep in tools/bench_gemm_tiles.py (profiles/r1_gemm_tile_sweep.txt):
+//   >= 1.5 rounds of 128x128 tiles over the 256 CUs → 128x128 (2 co-resident blocks per CU hide the DMA latency)
+//   linear, N % 80 == 0 and one round of 128x80 tiles fills the chip (M=2048, N=1280 of the UNet) → 128x80
+//   few row tiles (M <= 192: LLM prefill / forced-token chunk) → 64x64 to maximise the tile count
+//   otherwise → 64x128 with the 3-deep ring
+inline int pick_tile(int M, int N, bool glu, bool conv, int force) {
+  if (force >= 0 && force < 4 && (!glu || kTiles[force].glu_ok)) return force;
+  auto tiles = [&](int c) { return (long)((M + kTiles[c].bm - 1) / kTiles[c].bm) * ((N + kTiles[c].bn - 1) / kTiles[c].bn); };
+  if (tiles(0) >= (conv ? 256 : 384)) return 0;
+  if (!glu && !conv && N % 80 == 0 && tiles(1) <= 256 && tiles(1) >= 192) return 1;
+  if (M <= 192 && tiles(2) < 256) return 3;
+  return 2;
 }
 
 }  // namespace sxk_gemm
 using namespace sxk_gemm;
+
+static int g_force_tile = -1;
+extern "C" int sx_gemm_force_tile(int cfg) {  // tuning / test hook: -1 = automatic
+  g_force_tile = cfg;
+  return SX_OK;
+}
 
 extern "C" int sx_gemm(const sx_gemm_args* a, void* stream) {
   SX_CHECK(a && a->A && a->W && a->C, "sx_gemm: null pointer");
@@ -303,12 +336,13 @@ extern "C" int sx_gemm(const sx_gemm_args* a, void* stream) {
   p.a_bytes = (unsigned)a_bytes;
   p.w_bytes = (unsigned)w_bytes;
   hipStream_t st = (hipStream_t)stream;
-  const int cfg = pick_tile(a->M, a->N);
+  const int cfg = pick_tile(a->M, a->N, a->glu != 0, a->a_mode == SX_A_CONV3X3, g_force_tile);
 #define SX_GEMM_DISPATCH(TT)                                                  \
   switch (cfg) {                                                              \
-    case 0: return launch_cfg<TT, 128, 128>(p, a->a_mode, st);                \
-    case 1: return launch_cfg<TT, 64, 128>(p, a->a_mode, st);                 \
-    default: return launch_cfg<TT, 64, 64>(p, a->a_mode, st);                 \
+    case 0: return launch_cfg<TT, 128, 128, 2, 2, 2>(p, a->a_mode, st);       \
+    case 1: return launch_cfg<TT, 128, 80, 4, 1, 3>(p, a->a_mode, st);        \
+    case 2: return launch_cfg<TT, 64, 128, 2, 2, 3>(p, a->a_mode, st);        \
+    default: return launch_cfg<TT, 64, 64, 2, 2, 3>(p, a->a_mode, st);        \
   }
   if (a->dtype == SX_BF16) { SX_GEMM_DISPATCH(BF16) } else { SX_GEMM_DISPATCH(F16) }
 #undef SX_GEMM_DISPATCH

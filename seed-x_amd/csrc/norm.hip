@@ -32,8 +32,10 @@ __device__ __forceinline__ void store4(void* base, int dt, size_t idx4, f32x4_t 
   }
 }
 
-// one wave per row, 4 rows per 256-thread block; the row (<= 20 KB) stays L1/L2 resident over the passes
-template <int IN_DT>
+// One wave per row, 4 rows per 256-thread block. The whole row is loaded ONCE into registers (NV float4 per lane,
+// all loads in flight together), statistics come from two wave reductions, then the row is written: one HBM read
+// and one write per element, no dependent re-read passes.
+template <int IN_DT, int NV>
 __global__ __launch_bounds__(256) void layernorm_kernel(const void* x, void* y, int out_dt, const float* gamma,
                                                         const float* beta, int rows, int cols, float eps, int rms) {
   const int lane = threadIdx.x & 63;
@@ -41,29 +43,37 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const void* x, void* y, 
   if (row >= rows) return;
   const int n4 = cols >> 2;
   const size_t base4 = (size_t)row * n4;
-  float mean = 0.f, var;
+  f32x4_t v[NV];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int i = lane + 64 * k;
+    v[k] = (i < n4) ? load4<IN_DT>(x, base4 + i) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  }
+  float mean = 0.f;
   if (!rms) {
     float s = 0.f;
-    for (int i = lane; i < n4; i += 64) {
-      const f32x4_t v = load4<IN_DT>(x, base4 + i);
-      s += (v[0] + v[1]) + (v[2] + v[3]);
-    }
+#pragma unroll
+    for (int k = 0; k < NV; ++k) s += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
     mean = wave_sum(s) / (float)cols;
   }
   float q = 0.f;
-  for (int i = lane; i < n4; i += 64) {
-    f32x4_t v = load4<IN_DT>(x, base4 + i);
-    v -= mean;
-    q += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int i = lane + 64 * k;
+    if (i < n4) {
+      const f32x4_t d = v[k] - mean;
+      q += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+    }
   }
-  var = wave_sum(q) / (float)cols;
-  const float rstd = rsqrtf(var + eps);
-  for (int i = lane; i < n4; i += 64) {
-    f32x4_t v = load4<IN_DT>(x, base4 + i);
-    const f32x4_t g = ((const f32x4_t*)gamma)[i];
-    v = (v - mean) * rstd * g;
-    if (beta) v += ((const f32x4_t*)beta)[i];
-    store4(y, out_dt, base4 + i, v);
+  const float rstd = rsqrtf(wave_sum(q) / (float)cols + eps);
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int i = lane + 64 * k;
+    if (i < n4) {
+      f32x4_t o = (v[k] - mean) * rstd * ((const f32x4_t*)gamma)[i];
+      if (beta) o += ((const f32x4_t*)beta)[i];
+      store4(y, out_dt, base4 + i, o);
+    }
   }
 }
 
@@ -168,19 +178,25 @@ extern "C" int sx_layernorm(const void* x, int in_dtype, void* y, int out_dtype,
   SX_CHECK(out_dtype >= SX_F16 && out_dtype <= SX_F32, "sx_layernorm: bad out dtype");
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((rows + 3) / 4), block(256);
+  const int n4 = cols / 4;
+  SX_CHECK(n4 <= 64 * 24, "sx_layernorm: cols=%d exceeds the register-resident limit (6144)", cols);
+#define SX_LN_GO(DT, NV) \
+  hipLaunchKernelGGL((layernorm_kernel<DT, NV>), grid, block, 0, st, x, y, out_dtype, gamma, beta, rows, cols, eps, rms)
+#define SX_LN_NV(DT)                        \
+  if (n4 <= 64 * 3) { SX_LN_GO(DT, 3); }    \
+  else if (n4 <= 64 * 5) { SX_LN_GO(DT, 5); }  \
+  else if (n4 <= 64 * 8) { SX_LN_GO(DT, 8); }  \
+  else if (n4 <= 64 * 16) { SX_LN_GO(DT, 16); } \
+  else { SX_LN_GO(DT, 24); }
   switch (in_dtype) {
-    case SX_F32:
-      hipLaunchKernelGGL(layernorm_kernel<SX_F32>, grid, block, 0, st, x, y, out_dtype, gamma, beta, rows, cols, eps, rms);
-      break;
-    case SX_F16:
-      hipLaunchKernelGGL(layernorm_kernel<SX_F16>, grid, block, 0, st, x, y, out_dtype, gamma, beta, rows, cols, eps, rms);
-      break;
-    case SX_BF16:
-      hipLaunchKernelGGL(layernorm_kernel<SX_BF16>, grid, block, 0, st, x, y, out_dtype, gamma, beta, rows, cols, eps, rms);
-      break;
+    case SX_F32: SX_LN_NV(SX_F32) break;
+    case SX_F16: SX_LN_NV(SX_F16) break;
+    case SX_BF16: SX_LN_NV(SX_BF16) break;
     default:
       SX_FAIL("sx_layernorm: bad in dtype %d", in_dtype);
   }
+#undef SX_LN_NV
+#undef SX_LN_GO
   SX_HIP_LAUNCH_CHECK();
   return SX_OK;
 }

@@ -46,10 +46,10 @@ struct BF16 {
   typedef bf16x4_t vec4;
   static __device__ __forceinline__ float to_f32(unsigned short u) { return __uint_as_float(((unsigned)u) << 16); }
   static __device__ __forceinline__ unsigned short from_f32(float f) {
-    unsigned u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);  // NaN
-    u += 0x7fffu + ((u >> 16) & 1u);                                                   // RNE
-    return (unsigned short)(u >> 16);
+    __bf16 h = (__bf16)f;  // hardware RNE convert on gfx950 (v_cvt_pk_bf16_f32)
+    unsigned short u;
+    __builtin_memcpy(&u, &h, 2);
+    return u;
   }
   static __device__ __forceinline__ f32x4_t mfma16(vec8 a, vec8 b, f32x4_t c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
@@ -81,10 +81,16 @@ struct F16 {
   }
 };
 
-// pack two floats -> two 16-bit values in one dword
+// pack two floats -> two 16-bit values in one dword (vector convert → v_cvt_pk_bf16_f32 / v_cvt_f16_f32 pairs)
 template <typename TT>
 __device__ __forceinline__ unsigned pack2(float lo, float hi) {
-  return (unsigned)TT::from_f32(lo) | ((unsigned)TT::from_f32(hi) << 16);
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  typedef typename TT::elem e2_t __attribute__((ext_vector_type(2)));
+  const f32x2_t v = {lo, hi};
+  const e2_t r = __builtin_convertvector(v, e2_t);
+  unsigned u;
+  __builtin_memcpy(&u, &r, 4);
+  return u;
 }
 
 // ---- wave / block reductions --------------------------------------------------------------

@@ -218,8 +218,9 @@ class _DenoiseLoop:
         ctx = unet.prepare_context(S["ehs"])                                      # step-invariant cross-attn K/V
         if self._graph is not None and self._ctx_static is not None:
             for per_s, per_n in zip(self._ctx_static, ctx):                       # the graph holds these addresses
-                for a, b in zip(per_s, per_n):
-                    a.copy_(b)
+                for (ka, va), (kb, vb) in zip(per_s, per_n):
+                    ka.copy_(kb)
+                    va.copy_(vb)
             ctx = self._ctx_static
         else:
             self._ctx_static = ctx

@@ -195,17 +195,29 @@ def _bshd_strides(t):
     return t.stride(0), t.stride(1), t.stride(2)
 
 
-def attention(q, k, v, scale, causal=False, out=None):
+def transpose_v(v):
+    """V [B, Skv, H, D] (strided view) → V^T [B, H, D, kv_pad] zero-padded along keys (operand layout of sx_attention)."""
+    lib = _lib.load()
+    B, Skv, H, D = v.shape
+    kv_pad = (Skv + 63) // 64 * 64
+    vt = torch.empty((B, H, D, kv_pad), dtype=v.dtype, device=v.device)
+    vb, vr, vh = _bshd_strides(v)
+    check(lib.sx_transpose_v(_p(v), _p(vt), B, H, Skv, D, kv_pad, vb, vr, vh, _stream()), "sx_transpose_v")
+    return vt
+
+
+def attention(q, k, v, scale, causal=False, out=None, vt=None):
     """Flash attention on MFMA. q: [B, Sq, H, D] view, k/v: [B, Skv, H, D] views (any strides with unit D stride).
-    Returns [B, Sq, H*D] contiguous 16-bit."""
+    vt: optional precomputed transpose_v(v) (step-invariant cross-attention context). Returns [B, Sq, H*D] 16-bit."""
     lib = _lib.load()
     B, Sq, H, D = q.shape
     Skv = k.shape[1]
-    assert k.shape == (B, Skv, H, D) and v.shape == (B, Skv, H, D) and q.dtype == k.dtype == v.dtype
-    kv_pad = (Skv + 63) // 64 * 64
-    vt = torch.empty((B, H, D, kv_pad), dtype=q.dtype, device=q.device)
-    vb, vr, vh = _bshd_strides(v)
-    check(lib.sx_transpose_v(_p(v), _p(vt), B, H, Skv, D, kv_pad, vb, vr, vh, _stream()), "sx_transpose_v")
+    assert k.shape == (B, Skv, H, D) and q.dtype == k.dtype
+    if vt is None:
+        assert v.shape == (B, Skv, H, D) and v.dtype == q.dtype
+        vt = transpose_v(v)
+    kv_pad = vt.shape[-1]
+    assert vt.shape == (B, H, D, kv_pad) and vt.is_contiguous()
     if out is None:
         out = torch.empty((B, Sq, H * D), dtype=q.dtype, device=q.device)
     a = AttnArgs()

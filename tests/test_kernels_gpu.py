@@ -45,6 +45,27 @@ def test_gemm_plain(dev, dtype, M, N, K):
     assert out16.dtype == dtype and relerr(out16, ref) < TOL[dtype]
 
 
+@pytest.mark.parametrize("tile", [0, 1, 2, 3])
+@pytest.mark.parametrize("M,N,K", [(300, 272, 192), (2048, 1280, 640), (128, 80, 64), (77, 336, 1024)])
+def test_gemm_every_tile_config(dev, tile, M, N, K):
+    """Each tile shape / pipeline depth (128x128x2, 128x80x3, 64x128x3, 64x64x3) forced in turn, linear and conv."""
+    from seedx_amd import _lib, ops
+    lib = _lib.load()
+    dtype = torch.bfloat16
+    a, w = rnd((M, K), dtype, dev, seed=60), rnd((N, K), dtype, dev, 0.05, seed=61)
+    bias, res = rnd((N,), torch.float32, dev, seed=62), rnd((M, N), torch.float32, dev, seed=63)
+    x = rnd((2, 12, 10, 64), dtype, dev, seed=64)
+    wc = rnd((N, 9 * 64), dtype, dev, 0.05, seed=65)
+    try:
+        lib.sx_gemm_force_tile(tile)
+        out = ops.gemm(a, w, bias=bias, residual=res, act="silu", out_dtype=torch.float32)
+        outc = ops.conv3x3(x, wc, bias=bias, out_dtype=torch.float32)
+    finally:
+        lib.sx_gemm_force_tile(-1)
+    assert relerr(out, F.silu(a.float() @ w.float().t() + bias) + res) < 5e-5
+    assert relerr(outc, _conv_ref(x, wc, bias, 1, False)) < TOL[torch.float32]
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_gemm_asymmetric_identity(dev, dtype):
     """A = I with an asymmetric W catches transposed / permuted fragment layouts."""
