@@ -218,12 +218,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     a = ap.parse_args()
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    from seedx_amd import dist_utils as du
+    ctx = du.init("nccl")                       # RCCL over xGMI; only barrier + max-reduce of the wall time
+    rank, world, local = ctx.rank, ctx.world, ctx.local
     assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -232,29 +229,24 @@ def main():
     with torch.no_grad():
         vit, agent, adapter = build_models(dev, dtype)
         inp = make_inputs(dev)
+        seeds = du.shard_seeds(ctx, a.steps)      # independent requests, round-robin over ranks
         for i in range(a.warmup):
             one_generation(vit, agent, adapter, tok, inp, a.unet_steps, a.text_tokens, seed=100 + i)
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+        du.barrier(ctx)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for i in range(a.steps):
-            one_generation(vit, agent, adapter, tok, inp, a.unet_steps, a.text_tokens, seed=i)
+        for sd_ in seeds:
+            one_generation(vit, agent, adapter, tok, inp, a.unet_steps, a.text_tokens, seed=sd_)
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+        du.barrier(ctx)
         torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([dt], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
+        dt = du.max_over_ranks(ctx, time.perf_counter() - t0)
         roof = None
         if rank == 0 and not a.no_roofline:
             roof = gemm_roofline(vit, agent, adapter, tok, inp, a.unet_steps, a.text_tokens)
     if rank == 0:
-        total = a.steps * world
+        total = du.total_units(ctx, a.steps)
         rec = {"metric": "end-to-end generations/sec (img-in -> txt + 1024px-img-out)", "value": total / dt,
                "unit": "gens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -274,8 +266,7 @@ def main():
             except Exception as ex:  # the oracle is optional infrastructure; never fail the measurement on it
                 rec["cpu_baseline"] = {"error": repr(ex)}
         print(json.dumps(rec), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    du.finalize(ctx)
 
 
 if __name__ == "__main__":

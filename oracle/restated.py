@@ -148,7 +148,7 @@ def llama_forward(sd, cfg, inputs_embeds, past=None, table_dtype=None):
     if table_dtype is not None:
         cos, sin = cos.to(table_dtype).float(), sin.to(table_dtype).float()
     pos = torch.arange(Tp, Tp + T)
-    cos, sin = cos[pos][None, None], sin[pos][None, None]
+    cos, sin = cos[pos][None, None].to(x.device), sin[pos][None, None].to(x.device)
     new_past = []
     for i in range(L):
         p = f"model.layers.{i}."
@@ -164,8 +164,8 @@ def llama_forward(sd, cfg, inputs_embeds, past=None, table_dtype=None):
         new_past.append((k, v))
         s = q @ k.transpose(-1, -2) / math.sqrt(hd)
         Tk = k.shape[2]
-        ii = torch.arange(T)[:, None] + (Tk - T)
-        jj = torch.arange(Tk)[None, :]
+        ii = torch.arange(T, device=x.device)[:, None] + (Tk - T)
+        jj = torch.arange(Tk, device=x.device)[None, :]
         s = s.masked_fill(jj > ii, float("-inf"))
         o = (torch.softmax(s, dim=-1) @ v).transpose(1, 2).reshape(1, T, H)
         x = x + F.linear(o, sd[p + "self_attn.o_proj.weight"])                         # :239,297

@@ -146,7 +146,7 @@ def unet_sd(cfg, seed=1234, device="cpu", dtype=torch.float32):
 def timestep_embedding(t, dim):
     """diffusers get_timestep_embedding with flip_sin_to_cos=True, downscale_freq_shift=0 [ext]."""
     half = dim // 2
-    freqs = torch.exp(-math.log(10000) * torch.arange(half, dtype=torch.float32) / half)
+    freqs = torch.exp(-math.log(10000) * torch.arange(half, dtype=torch.float32, device=t.device) / half)
     arg = t.float()[:, None] * freqs[None]
     return torch.cat([arg.cos(), arg.sin()], dim=-1)
 
