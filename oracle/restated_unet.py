@@ -202,7 +202,7 @@ def unet_forward(sd, cfg, sample, timestep, encoder_hidden_states, text_embeds, 
     [B,pooled], time_ids [B,6] → [B,Cout,H,W]."""
     boc, G = cfg["block_out_channels"], cfg["norm_groups"]
     B = sample.shape[0]
-    t = torch.as_tensor(timestep, dtype=torch.float32).reshape(-1).expand(B)
+    t = torch.as_tensor(timestep, dtype=torch.float32).reshape(-1).expand(B).to(sample.device)
     emb = timestep_embedding(t, boc[0])
     emb = F.linear(F.silu(F.linear(emb, sd["time_embedding.linear_1.weight"], sd["time_embedding.linear_1.bias"])),
                    sd["time_embedding.linear_2.weight"], sd["time_embedding.linear_2.bias"])
