@@ -96,16 +96,67 @@ def make_inputs(dev, seed=0):
     return image, patch_pos, ids, mask
 
 
-def one_generation(vit, agent, adapter, tok, inp, steps_unet, n_text, seed):
+BATCH = 1   # generations processed together per step on one GPU (set from --batch)
+
+
+def front_half(vit, agent, tok, inp, n_text):
+    """Paths A + B for BATCH requests: ViT on all 2·BATCH crops at once, then each request's greedy decode in turn.
+    Returns the image-generation features [BATCH, 64, 4096]."""
     image, patch_pos, ids, mask = inp
-    emb = vit(image)                                                            # path A
-    out = agent.generate(tok, input_ids=[ids], image_embeds=emb, embeds_cmp_mask=torch.tensor([True, True]),
-                         ids_cmp_mask=mask, patch_positions=patch_pos, max_new_tokens=n_text + 66 + 1,
-                         eos_token_id=None, force_image_at=n_text)              # path B
-    assert out["has_img_output"] and out["img_gen_feat"].shape == (1, 64, 4096), "transcript did not yield an image"
-    lat = adapter.generate(image_embeds=out["img_gen_feat"], num_inference_steps=steps_unet, seed=seed,
-                           output_type="latent")                                # path C
-    return out, lat
+    G = BATCH
+    emb = vit(image if G == 1 else image.repeat(G, 1, 1, 1))                    # path A, [2G, 256, 4096]
+    feats = []
+    for g in range(G):
+        out = agent.generate(tok, input_ids=[ids], image_embeds=emb[2 * g:2 * g + 2],
+                             embeds_cmp_mask=torch.tensor([True, True]), ids_cmp_mask=mask, patch_positions=patch_pos,
+                             max_new_tokens=n_text + 66 + 1, eos_token_id=None, force_image_at=n_text)   # path B
+        assert out["has_img_output"] and out["img_gen_feat"].shape == (1, 64, 4096), "transcript did not yield an image"
+        feats.append(out["img_gen_feat"])
+    return torch.cat(feats, dim=0)
+
+
+def back_half(adapter, feats, steps_unet, seed):
+    """Path C for BATCH requests as one UNet batch of 2·BATCH CFG samples (enqueue-only: no host sync inside)."""
+    G = feats.shape[0]
+    lat = adapter.generate(image_embeds=feats, num_inference_steps=steps_unet, seed=[seed * G + g for g in range(G)],
+                           output_type="latent")
+    assert lat.shape[0] == G
+    return lat
+
+
+def one_generation(vit, agent, adapter, tok, inp, steps_unet, n_text, seed):
+    """One bench step, strictly sequential on the current stream."""
+    feats = front_half(vit, agent, tok, inp, n_text)
+    return feats, back_half(adapter, feats, steps_unet, seed)
+
+
+class Pipeline:
+    """Request-level software pipeline on two HIP streams: while the MFMA-bound de-tokenizer of request i runs on the
+    `back` stream, the HBM-bound LLM decode (and ViT) of request i+1 runs on the `front` stream. Every request still
+    executes all of its work; only the phases of CONSECUTIVE requests overlap."""
+
+    def __init__(self, vit, agent, adapter, tok, inp, steps_unet, n_text):
+        self.args = (vit, agent, adapter, tok, inp, steps_unet, n_text)
+        self.s_front, self.s_back = torch.cuda.Stream(), torch.cuda.Stream()
+        self.keep = []
+
+    def submit(self, seed):
+        vit, agent, adapter, tok, inp, steps_unet, n_text = self.args
+        with torch.cuda.stream(self.s_front):
+            feats = front_half(vit, agent, tok, inp, n_text)
+            ev = torch.cuda.Event()
+            ev.record(self.s_front)
+        with torch.cuda.stream(self.s_back):
+            self.s_back.wait_event(ev)
+            lat = back_half(adapter, feats, steps_unet, seed)
+        self.keep.append((feats, lat))          # keep tensors alive until both streams are drained
+
+    def drain(self):
+        self.s_front.synchronize()
+        self.s_back.synchronize()
+        out = [l for _, l in self.keep]
+        self.keep = []
+        return out
 
 
 def gemm_roofline(vit, agent, adapter, tok, inp, steps_unet, n_text):
@@ -141,8 +192,8 @@ def gemm_roofline(vit, agent, adapter, tok, inp, steps_unet, n_text):
     n = len(rec)
     return {"bound": "mfma", "achieved": fl / tot_s / 1e12, "peak": PEAK_TFLOPS_16BIT, "unit": "TFLOP/s",
             "frac": fl / tot_s / 1e12 / PEAK_TFLOPS_16BIT, "traffic": None, "kernel": "sxk_gemm::gemm_kernel<*>",
-            "launches_per_generation": n, "avg_launch_us": tot_s / n * 1e6, "avg_launch_gflop": fl / n / 1e9,
-            "gemm_time_s_per_generation": tot_s}
+            "launches_per_step": n, "avg_launch_us": tot_s / n * 1e6, "avg_launch_gflop": fl / n / 1e9,
+            "gemm_time_s_per_step": tot_s}
 
 
 def cpu_baseline():
@@ -215,9 +266,14 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
     ap.add_argument("--unet-steps", type=int, default=50)
     ap.add_argument("--text-tokens", type=int, default=61)
+    ap.add_argument("--overlap", type=int, default=1,
+                    help="1: pipeline consecutive requests on two streams (LLM decode of request i+1 under the UNet of request i)")
+    ap.add_argument("--batch", type=int, default=1, help="independent generations processed together per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     a = ap.parse_args()
+    global BATCH
+    BATCH = a.batch
     from seedx_amd import dist_utils as du
     ctx = du.init("nccl")                       # RCCL over xGMI; only barrier + max-reduce of the wall time
     rank, world, local = ctx.rank, ctx.world, ctx.local
@@ -230,14 +286,22 @@ def main():
         vit, agent, adapter = build_models(dev, dtype)
         inp = make_inputs(dev)
         seeds = du.shard_seeds(ctx, a.steps)      # independent requests, round-robin over ranks
-        for i in range(a.warmup):
-            one_generation(vit, agent, adapter, tok, inp, a.unet_steps, a.text_tokens, seed=100 + i)
+        pipe = Pipeline(vit, agent, adapter, tok, inp, a.unet_steps, a.text_tokens) if a.overlap else None
+
+        def run(seed_list):
+            if pipe is None:
+                for sd_ in seed_list:
+                    one_generation(vit, agent, adapter, tok, inp, a.unet_steps, a.text_tokens, seed=sd_)
+            else:
+                for sd_ in seed_list:
+                    pipe.submit(sd_)
+                pipe.drain()
+        run([100 + i for i in range(a.warmup)])
         torch.cuda.synchronize()
         du.barrier(ctx)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for sd_ in seeds:
-            one_generation(vit, agent, adapter, tok, inp, a.unet_steps, a.text_tokens, seed=sd_)
+        run(seeds)
         torch.cuda.synchronize()
         du.barrier(ctx)
         torch.cuda.synchronize()
@@ -246,7 +310,7 @@ def main():
         if rank == 0 and not a.no_roofline:
             roof = gemm_roofline(vit, agent, adapter, tok, inp, a.unet_steps, a.text_tokens)
     if rank == 0:
-        total = du.total_units(ctx, a.steps)
+        total = du.total_units(ctx, a.steps) * a.batch
         rec = {"metric": "end-to-end generations/sec (img-in -> txt + 1024px-img-out)", "value": total / dt,
                "unit": "gens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -255,8 +319,10 @@ def main():
                                       "(%d text + <img> + 64 forced + </img>) -> %d-step SDXL-UNet CFG-2 de-tokenize "
                                       "@1024x1024 (VAE decode excluded)" % (a.text_tokens, a.unet_steps),
                           "parallelism": "replica x%d (independent generations, no data-path collective)" % world,
-                          "batch_per_gpu": 1},
-               "flops_per_generation": 2 * FLOP_VIT_CROP + (165 + 128) * FLOP_LLM_TOKEN + 2 * a.unet_steps * FLOP_UNET_SAMPLE}
+                          "batch_per_gpu": a.batch,
+                          "request_pipelining": bool(a.overlap)},
+               "flops_per_generation": 2 * FLOP_VIT_CROP + (165 + 128) * FLOP_LLM_TOKEN + 2 * a.unet_steps * FLOP_UNET_SAMPLE,
+               "generations_per_step": a.batch}
         rec["model_tflops"] = rec["flops_per_generation"] * rec["value"] / world / 1e12
         if roof is not None:
             rec["roofline"] = roof

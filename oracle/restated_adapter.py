@@ -1,0 +1,43 @@
+"""CPU restatement of the SDXLAdapter front ends (TEST INFRASTRUCTURE; composes oracle/restated*.py).
+
+Follows src/models/detokenizer/adapter_modules.py:
+  * get_image_embeds (:96-130): three mutually exclusive inputs; pooling ONLY on the image_embeds branch (:109-116)
+  * SDXLAdapter.generate (:132-169) → t2i loop, order [uncond, text]
+  * SDXLAdapterWithLatentImage.generate (:249-287) → edit loop (pipeline_stable_diffusion_xl_t2i_edit.py:900-963)
+"""
+import torch
+import torch.nn.functional as F
+
+from . import restated, restated_unet as ru
+
+
+def get_image_embeds(sd_vit, cfg_vit, sd_x, cfg_x, image_tensor=None, image_embeds=None, vit_down=True, image_size=None):
+    assert (image_tensor is None) != (image_embeds is None)
+    if image_tensor is not None:
+        x = torch.cat([image_tensor, torch.zeros_like(image_tensor)], dim=0)          # :103-106
+        feats = restated.vit_forward(sd_vit, cfg_vit, x)                               # no pooling on this branch (:108)
+    else:
+        s = image_size or cfg_vit["image_size"]
+        neg = restated.vit_forward(sd_vit, cfg_vit, torch.zeros(1, 3, s, s))           # :110-111
+        if vit_down:
+            neg = F.avg_pool1d(neg.permute(0, 2, 1), kernel_size=4, stride=4).permute(0, 2, 1)   # :112-115
+        feats = torch.cat([image_embeds.float(), neg.expand(image_embeds.shape[0], -1, -1)], dim=0)   # :116
+    prompt, pooled = restated.resampler_xlv2_forward(sd_x, cfg_x, feats)               # :118-120 (discrete model = identity)
+    n = prompt.shape[0] // 2
+    return prompt[:n], prompt[n:], pooled[:n], pooled[n:]                              # :122-124
+
+
+def adapter_generate(sd_vit, cfg_vit, sd_x, cfg_x, sd_unet, cfg_unet, latents, steps, image_tensor=None,
+                     image_embeds=None, vit_down=True, guidance_scale=7.5, image_latents=None,
+                     image_guidance_scale=1.5, height=1024, width=1024):
+    """latents: raw N(0,1) noise [1,4,h,w] (scaled by init_noise_sigma here, as the pipelines do). image_latents given
+    → edit variant. Returns final latents."""
+    pe, pe_neg, pool, pool_neg = get_image_embeds(sd_vit, cfg_vit, sd_x, cfg_x, image_tensor, image_embeds, vit_down)
+    _, _, init = ru.euler_tables(steps)
+    tid = torch.tensor([[height, width, 0, 0, height, width]], dtype=torch.float32)     # pipeline…:554-566
+    fn = lambda s, t, e, p, ti: ru.unet_forward(sd_unet, cfg_unet, s, t, e, p, ti)
+    lat0 = latents.float() * init
+    if image_latents is None:
+        return ru.t2i_loop(fn, lat0, pe, pe_neg, pool, pool_neg, tid, steps, guidance_scale)
+    il3 = torch.cat([image_latents, image_latents, torch.zeros_like(image_latents)], dim=0)   # :544-546
+    return ru.edit_loop(fn, lat0, il3, pe, pe_neg, pool, pool_neg, tid, steps, guidance_scale, image_guidance_scale)

@@ -269,7 +269,8 @@ int launch_cfg(const GemmP& p0, int a_mode, hipStream_t st) {
 
 // tile menu: {BM, BN, relative per-tile efficiency, usable with glu}
 struct TileCfg { int bm, bn; double eff; bool glu_ok; };
-static const TileCfg kTiles[4] = {{128, 128, 1.00, true}, {128, 80, 0.88, false}, {64, 128, 0.85, true}, {64, 64, 0.65, true}};
+static const TileCfg kTiles[6] = {{128, 128, 1.00, true}, {128, 80, 0.88, false}, {64, 128, 0.85, true}, {64, 64, 0.65, true},
+                                  {256, 128, 1.0, true}, {256, 128, 1.0, true}};
 
 // pick the tile that minimises (rounds over the 256 CUs) x (tile area / efficiency)
 // Rules fitted to the MI355X sweep in tools/bench_gemm_tiles.py (profiles/r1_gemm_tile_sweep.txt):
@@ -278,7 +279,7 @@ static const TileCfg kTiles[4] = {{128, 128, 1.00, true}, {128, 80, 0.88, false}
 //   few row tiles (M <= 192: LLM prefill / forced-token chunk) → 64x64 to maximise the tile count
 //   otherwise → 64x128 with the 3-deep ring
 inline int pick_tile(int M, int N, bool glu, bool conv, int force) {
-  if (force >= 0 && force < 4 && (!glu || kTiles[force].glu_ok)) return force;
+  if (force >= 0 && force < 6 && (!glu || kTiles[force].glu_ok)) return force;
   auto tiles = [&](int c) { return (long)((M + kTiles[c].bm - 1) / kTiles[c].bm) * ((N + kTiles[c].bn - 1) / kTiles[c].bn); };
   if (tiles(0) >= (conv ? 256 : 384)) return 0;
   if (!glu && !conv && N % 80 == 0 && tiles(1) <= 256 && tiles(1) >= 192) return 1;
@@ -342,7 +343,9 @@ extern "C" int sx_gemm(const sx_gemm_args* a, void* stream) {
     case 0: return launch_cfg<TT, 128, 128, 2, 2, 2>(p, a->a_mode, st);       \
     case 1: return launch_cfg<TT, 128, 80, 4, 1, 3>(p, a->a_mode, st);        \
     case 2: return launch_cfg<TT, 64, 128, 2, 2, 3>(p, a->a_mode, st);        \
-    default: return launch_cfg<TT, 64, 64, 2, 2, 3>(p, a->a_mode, st);        \
+    case 3: return launch_cfg<TT, 64, 64, 2, 2, 3>(p, a->a_mode, st);         \
+    case 4: return launch_cfg<TT, 256, 128, 2, 2, 2>(p, a->a_mode, st);       \
+    default: return launch_cfg<TT, 256, 128, 2, 2, 3>(p, a->a_mode, st);      \
   }
   if (a->dtype == SX_BF16) { SX_GEMM_DISPATCH(BF16) } else { SX_GEMM_DISPATCH(F16) }
 #undef SX_GEMM_DISPATCH

@@ -77,30 +77,94 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const void* x, void* y, 
   }
 }
 
+// Few rows (single-token decode: rows == 1): one 256-thread BLOCK per row, x / gamma / beta loads all in flight
+// together, two LDS block reductions. Cuts the dependent-latency chain of the wave-per-row kernel (20 loads per lane).
+template <int IN_DT>
+__global__ __launch_bounds__(256) void layernorm_block_kernel(const void* x, void* y, int out_dt, const float* gamma,
+                                                              const float* beta, int rows, int cols, float eps, int rms) {
+  __shared__ float red[8];
+  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int n4 = cols >> 2;
+  const size_t base4 = (size_t)row * n4;
+  constexpr int NV = 6;
+  f32x4_t v[NV], g[NV], b[NV];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int i = tid + 256 * k;
+    const bool ok = i < n4;
+    v[k] = ok ? load4<IN_DT>(x, base4 + i) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    g[k] = ok ? ((const f32x4_t*)gamma)[i] : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    b[k] = (ok && beta) ? ((const f32x4_t*)beta)[i] : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  }
+  float mean = 0.f;
+  if (!rms) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) s += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
+    s = wave_sum(s);
+    if (lane == 0) red[w] = s;
+    __syncthreads();
+    mean = (red[0] + red[1] + red[2] + red[3]) / (float)cols;
+  }
+  float q = 0.f;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    if (tid + 256 * k < n4) {
+      const f32x4_t d = v[k] - mean;
+      q += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+    }
+  }
+  q = wave_sum(q);
+  if (lane == 0) red[4 + w] = q;
+  __syncthreads();
+  const float rstd = rsqrtf((red[4] + red[5] + red[6] + red[7]) / (float)cols + eps);
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int i = tid + 256 * k;
+    if (i < n4) store4(y, out_dt, base4 + i, (v[k] - mean) * rstd * g[k] + b[k]);
+  }
+}
+
 // ---- GroupNorm over NHWC fp32 -----------------------------------------------------------------
 constexpr int GN_MAX_SLOTS2 = 6;  // C/2 pairs per row / 256 threads  (C <= 3072)
 constexpr int GN_MAX_SLOTS4 = 3;  // C/4 quads per row / 256 threads
 
-__global__ __launch_bounds__(256) void gn_stats_kernel(const float* x, double* stats, int HW, int C, int groups,
+// blockDim.x = T (320 / 160 / 256, chosen so the C/2 channel pairs tile the block evenly); each thread owns fixed
+// channel pairs and walks the block's rows four at a time (4 independent 8-B loads in flight per slot).
+__global__ __launch_bounds__(320) void gn_stats_kernel(const float* x, double* stats, int HW, int C, int groups,
                                                        int rows_per_block) {
   __shared__ float acc[2 * 64];  // [groups][2], groups <= 64
+  const int T = blockDim.x;
   const int b = blockIdx.y;
   const int r0 = blockIdx.x * rows_per_block;
   const int r1 = min(HW, r0 + rows_per_block);
   const int np = C >> 1, cpg = C / groups;
-  for (int i = threadIdx.x; i < 2 * groups; i += 256) acc[i] = 0.f;
+  for (int i = threadIdx.x; i < 2 * groups; i += T) acc[i] = 0.f;
   __syncthreads();
   float s[GN_MAX_SLOTS2], q[GN_MAX_SLOTS2];
 #pragma unroll
   for (int k = 0; k < GN_MAX_SLOTS2; ++k) { s[k] = 0.f; q[k] = 0.f; }
   const float2* xb = (const float2*)(x + (size_t)b * HW * C);
-  for (int r = r0; r < r1; ++r) {
-    const float2* xr = xb + (size_t)r * np;
+  int r = r0;
+  for (; r + 3 < r1; r += 4) {
 #pragma unroll
     for (int k = 0; k < GN_MAX_SLOTS2; ++k) {
-      const int pidx = threadIdx.x + k * 256;
+      const int pidx = threadIdx.x + k * T;
       if (pidx < np) {
-        const float2 v = xr[pidx];
+        const float2 v0 = xb[(size_t)r * np + pidx], v1 = xb[(size_t)(r + 1) * np + pidx];
+        const float2 v2 = xb[(size_t)(r + 2) * np + pidx], v3 = xb[(size_t)(r + 3) * np + pidx];
+        s[k] += ((v0.x + v0.y) + (v1.x + v1.y)) + ((v2.x + v2.y) + (v3.x + v3.y));
+        q[k] += ((v0.x * v0.x + v0.y * v0.y) + (v1.x * v1.x + v1.y * v1.y)) +
+                ((v2.x * v2.x + v2.y * v2.y) + (v3.x * v3.x + v3.y * v3.y));
+      }
+    }
+  }
+  for (; r < r1; ++r) {
+#pragma unroll
+    for (int k = 0; k < GN_MAX_SLOTS2; ++k) {
+      const int pidx = threadIdx.x + k * T;
+      if (pidx < np) {
+        const float2 v = xb[(size_t)r * np + pidx];
         s[k] += v.x + v.y;
         q[k] += v.x * v.x + v.y * v.y;
       }
@@ -108,7 +172,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* x, double* s
   }
 #pragma unroll
   for (int k = 0; k < GN_MAX_SLOTS2; ++k) {
-    const int pidx = threadIdx.x + k * 256;
+    const int pidx = threadIdx.x + k * T;
     if (pidx < np) {
       const int g = (2 * pidx) / cpg;
       atomicAdd(&acc[2 * g], s[k]);
@@ -116,7 +180,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* x, double* s
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < 2 * groups; i += 256) atomicAdd(&stats[(size_t)b * groups * 2 + i], (double)acc[i]);
+  for (int i = threadIdx.x; i < 2 * groups; i += T) atomicAdd(&stats[(size_t)b * groups * 2 + i], (double)acc[i]);
 }
 
 __global__ __launch_bounds__(256) void gn_apply_kernel(const float* x, void* y, void* raw16, int out_dt,
@@ -149,21 +213,34 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* x, void* y, 
     }
   }
   const size_t bbase4 = (size_t)b * HW * n4;
-  for (int r = r0; r < r1; ++r) {
+  auto one = [&](int r, int k, const f32x4_t v) {
+    const size_t idx = bbase4 + (size_t)r * n4 + threadIdx.x + k * 256;
+    f32x4_t o = v * sc[k] + sh[k];
+    if (silu) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = silu_f(o[e]);
+    }
+    store4(y, out_dt, idx, o);
+    if (raw16) store4(raw16, out_dt, idx, v);
+  };
+  int r = r0;
+  for (; r + 1 < r1; r += 2) {
 #pragma unroll
     for (int k = 0; k < GN_MAX_SLOTS4; ++k) {
       const int qi = threadIdx.x + k * 256;
       if (qi < n4) {
-        const size_t idx = bbase4 + (size_t)r * n4 + qi;
-        const f32x4_t v = ((const f32x4_t*)x)[idx];
-        f32x4_t o = v * sc[k] + sh[k];
-        if (silu) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = silu_f(o[e]);
-        }
-        store4(y, out_dt, idx, o);
-        if (raw16) store4(raw16, out_dt, idx, v);
+        const f32x4_t v0 = ((const f32x4_t*)x)[bbase4 + (size_t)r * n4 + qi];
+        const f32x4_t v1 = ((const f32x4_t*)x)[bbase4 + (size_t)(r + 1) * n4 + qi];
+        one(r, k, v0);
+        one(r + 1, k, v1);
       }
+    }
+  }
+  for (; r < r1; ++r) {
+#pragma unroll
+    for (int k = 0; k < GN_MAX_SLOTS4; ++k) {
+      const int qi = threadIdx.x + k * 256;
+      if (qi < n4) one(r, k, ((const f32x4_t*)x)[bbase4 + (size_t)r * n4 + qi]);
     }
   }
 }
@@ -188,6 +265,17 @@ extern "C" int sx_layernorm(const void* x, int in_dtype, void* y, int out_dtype,
   else if (n4 <= 64 * 8) { SX_LN_GO(DT, 8); }  \
   else if (n4 <= 64 * 16) { SX_LN_GO(DT, 16); } \
   else { SX_LN_GO(DT, 24); }
+  if (rows <= 16) {  // decode-sized: block per row
+    const dim3 g1(rows);
+    switch (in_dtype) {
+      case SX_F32: hipLaunchKernelGGL(layernorm_block_kernel<SX_F32>, g1, block, 0, st, x, y, out_dtype, gamma, beta, rows, cols, eps, rms); break;
+      case SX_F16: hipLaunchKernelGGL(layernorm_block_kernel<SX_F16>, g1, block, 0, st, x, y, out_dtype, gamma, beta, rows, cols, eps, rms); break;
+      case SX_BF16: hipLaunchKernelGGL(layernorm_block_kernel<SX_BF16>, g1, block, 0, st, x, y, out_dtype, gamma, beta, rows, cols, eps, rms); break;
+      default: SX_FAIL("sx_layernorm: bad in dtype %d", in_dtype);
+    }
+    SX_HIP_LAUNCH_CHECK();
+    return SX_OK;
+  }
   switch (in_dtype) {
     case SX_F32: SX_LN_NV(SX_F32) break;
     case SX_F16: SX_LN_NV(SX_F16) break;
@@ -218,7 +306,15 @@ extern "C" int sx_groupnorm(const float* x, void* y, void* raw16, int out_dtype,
   int rows_per_block = (HW * B + 2047) / 2048;
   if (rows_per_block < 4) rows_per_block = 4;
   const dim3 grid((HW + rows_per_block - 1) / rows_per_block, B), block(256);
-  hipLaunchKernelGGL(gn_stats_kernel, grid, block, 0, st, x, stats, HW, C, groups, rows_per_block);
+  const int np = C / 2;
+  const int T = (np % 320 == 0) ? 320 : ((np % 160 == 0) ? 160 : 256);
+  SX_CHECK((np + T - 1) / T <= GN_MAX_SLOTS2, "sx_groupnorm: C=%d too large", C);
+  // stats: ~512 blocks in total — every block ends with 2*groups fp64 atomics on the same B*groups*2 words, so the
+  // block count (not the byte count) bounds this kernel once the atomics serialise in L2
+  int rows_stats = (HW * B + 511) / 512;
+  if (rows_stats < 8) rows_stats = 8;
+  const dim3 grid_s((HW + rows_stats - 1) / rows_stats, B);
+  hipLaunchKernelGGL(gn_stats_kernel, grid_s, dim3(T), 0, st, x, stats, HW, C, groups, rows_stats);
   SX_HIP_LAUNCH_CHECK();
   hipLaunchKernelGGL(gn_apply_kernel, grid, block, 0, st, x, y, raw16, out_dtype, gamma, beta, stats, HW, C, groups,
                      eps, silu, rows_per_block);

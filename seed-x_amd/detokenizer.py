@@ -180,22 +180,26 @@ class _DenoiseLoop:
     def run(self, mode, latents_nchw, prompt_embeds, pooled, time_ids, scheduler, num_steps, guidance_scale,
             image_guidance_scale=1.5, image_latents_nchw=None):
         """mode 0 (t2i): prompt_embeds ordered [uncond, text]; mode 1 (edit): [text, image, uncond].
-        latents_nchw: [1,4,H,W] already multiplied by init_noise_sigma. Returns fp32 [1,4,H,W]."""
+        latents_nchw: [G,4,H,W] already multiplied by init_noise_sigma, G >= 1 independent generations denoised as one
+        UNet batch of nb·G samples ordered [branch][generation] (prompt_embeds / pooled / time_ids / image latents all
+        follow that order). Returns fp32 [G,4,H,W]."""
         unet = self.unet
         unet._pack()
         dev = unet.device
         nb = 2 if mode == 0 else 3
-        _, Cl, H, W = latents_nchw.shape
+        G, Cl, H, W = latents_nchw.shape
         HW = H * W
+        NB = nb * G
+        assert prompt_embeds.shape[0] == NB and pooled.shape[0] == NB and time_ids.shape[0] == NB
         cin = unet.cfg["in_channels"]
         assert cin == (Cl if mode == 0 else 2 * Cl), f"UNet in_channels {cin} does not match mode {mode}"
         scheduler.set_timesteps(num_steps)
         ts_dev = scheduler.timesteps.to(dev)
         sig_dev = scheduler.sigmas.to(dev)
-        key = (mode, H, W, num_steps, float(guidance_scale), float(image_guidance_scale))
+        key = (mode, G, H, W, num_steps, float(guidance_scale), float(image_guidance_scale))
         if self._state is None or self._graph_key != key:
-            self._state = dict(lat=torch.empty((1, HW, Cl), dtype=torch.float32, device=dev),
-                               scaled=torch.zeros((nb, HW, cin), dtype=torch.float32, device=dev),
+            self._state = dict(lat=torch.empty((G, HW, Cl), dtype=torch.float32, device=dev),
+                               scaled=torch.zeros((NB, HW, cin), dtype=torch.float32, device=dev),
                                step=torch.zeros(1, dtype=torch.int32, device=dev),
                                ehs=torch.empty(prompt_embeds.shape, dtype=torch.float32, device=dev),
                                pooled=torch.empty(pooled.shape, dtype=torch.float32, device=dev),
@@ -210,10 +214,10 @@ class _DenoiseLoop:
         S["step"].zero_()
         ops.nchw_to_nhwc(latents_nchw.to(dev, torch.float32), dst=S["lat"])
         s0 = float(scheduler.sigmas[0])
-        S["scaled"][:, :, :Cl] = S["lat"] / math.sqrt(s0 * s0 + 1.0)             # scale_model_input at step 0 (setup)
+        S["scaled"].view(nb, G, HW, cin)[:, :, :, :Cl] = S["lat"] / math.sqrt(s0 * s0 + 1.0)   # scale_model_input, step 0
         if mode == 1:
-            il = image_latents_nchw.to(dev, torch.float32)                       # [3,4,H,W] = [enc, enc, 0] (:544-546)
-            S["scaled"][:, :, Cl:] = il.permute(0, 2, 3, 1).reshape(nb, HW, Cl)
+            il = image_latents_nchw.to(dev, torch.float32)                       # [3·G,4,H,W] = [enc, enc, 0] (:544-546)
+            S["scaled"][:, :, Cl:] = il.permute(0, 2, 3, 1).reshape(NB, HW, Cl)
         unet._ctx_key = None
         ctx = unet.prepare_context(S["ehs"])                                      # step-invariant cross-attn K/V
         if self._graph is not None and self._ctx_static is not None:
@@ -226,8 +230,8 @@ class _DenoiseLoop:
             self._ctx_static = ctx
 
         def step_body():
-            temb = unet.time_embeddings(S["ts"], S["step"], S["pooled"], S["tid"], nb)
-            eps = unet.forward_nhwc(S["scaled"], temb, ctx, nb, H, W)
+            temb = unet.time_embeddings(S["ts"], S["step"], S["pooled"], S["tid"], NB)
+            eps = unet.forward_nhwc(S["scaled"], temb, ctx, NB, H, W)
             ops.cfg_euler_step(eps, S["lat"], S["scaled"], S["sig"], S["step"], nb, Cl, cin, guidance_scale,
                                image_guidance_scale, mode)
             ops.add_i32(S["step"], 1)
@@ -330,7 +334,8 @@ class SDXLAdapter:
             image_embeds = self.visual_encoder(image_tensor).float()                # 256 tokens, NO pooling (:108)
         elif return_negative:
             neg = self._negative_embeds(image_size, self.vit_down)
-            image_embeds = torch.cat([image_embeds.to(self.device).float(), neg], dim=0)   # :116
+            ie = image_embeds.to(self.device).float()
+            image_embeds = torch.cat([ie, neg.expand(ie.shape[0], -1, -1)], dim=0)        # :116 (one negative per sample)
         if self.discrete_model is not None:
             image_embeds = self.discrete_model.encode_image_embeds(image_embeds)    # identity (discrete_models.py:16-17)
         prompt, pooled = self.encode_image_embeds(image_embeds)
@@ -344,9 +349,14 @@ class SDXLAdapter:
     def _time_ids(self, height, width, n):
         return torch.tensor([[height, width, 0, 0, height, width]] * n, dtype=torch.float32)   # _get_add_time_ids :554-566
 
-    def _noise(self, seed, height, width):
-        g = torch.Generator(self.device).manual_seed(seed) if seed is not None else None
-        return torch.randn((1, 4, height // 8, width // 8), generator=g, device=self.device, dtype=torch.float32)
+    def _noise(self, seed, height, width, n=1):
+        """One [1,4,h,w] noise tensor per generation; `seed` may be an int (generation i uses seed + i) or a list."""
+        out = []
+        for i in range(n):
+            sd = None if seed is None else (seed[i] if isinstance(seed, (list, tuple)) else seed + i)
+            g = torch.Generator(self.device).manual_seed(sd) if sd is not None else None
+            out.append(torch.randn((1, 4, height // 8, width // 8), generator=g, device=self.device, dtype=torch.float32))
+        return torch.cat(out, dim=0)
 
     def _finish(self, latents, output_type):
         if output_type == "latent" or self.vae is None:
@@ -362,12 +372,13 @@ class SDXLAdapter:
                                                            image_embeds=image_embeds, return_negative=True,
                                                            image_size=input_image_size)
         self.scheduler.set_timesteps(num_inference_steps)
+        G = pe.shape[0]                                                              # generations in this call
         if latents is None:
-            latents = self._noise(seed, height, width)
+            latents = self._noise(seed, height, width, G)
         latents = latents.to(self.device, torch.float32) * self.scheduler.init_noise_sigma
-        ehs = torch.cat([pe_neg, pe], dim=0)                                         # order [uncond, text]
+        ehs = torch.cat([pe_neg, pe], dim=0)                                         # order [uncond, text] x G
         pooled = torch.cat([pool_neg, pool], dim=0)
-        out = self._loop.run(0, latents, ehs, pooled, self._time_ids(height, width, 2), self.scheduler,
+        out = self._loop.run(0, latents, ehs, pooled, self._time_ids(height, width, 2 * G), self.scheduler,
                              num_inference_steps, guidance_scale)
         return self._finish(out, output_type)
 
@@ -382,12 +393,13 @@ class SDXLAdapterWithLatentImage(SDXLAdapter):
                                                            image_embeds=image_embeds, return_negative=True,
                                                            image_size=input_image_size)
         self.scheduler.set_timesteps(num_inference_steps)
+        G = pe.shape[0]
         if latents is None:
-            latents = self._noise(seed, height, width)
+            latents = self._noise(seed, height, width, G)
         latents = latents.to(self.device, torch.float32) * self.scheduler.init_noise_sigma
         if image_latents is None:
             if latent_image is None:
-                image_latents = torch.zeros(1, 4, height // 8, width // 8)          # pipeline…:909-910 (no source image)
+                image_latents = torch.zeros(G, 4, height // 8, width // 8)          # pipeline…:909-910 (no source image)
             else:
                 if self.vae is None:
                     raise NotImplementedError("VAE encode of `latent_image` is a 'next' row (SURVEY.md §8f-1): pass "
@@ -397,6 +409,6 @@ class SDXLAdapterWithLatentImage(SDXLAdapter):
         il3 = torch.cat([il, il, torch.zeros_like(il)], dim=0)                       # [img, img, 0]  (:544-546)
         ehs = torch.cat([pe, pe_neg, pe_neg], dim=0)                                 # order [text, image, uncond] (:884)
         pooled = torch.cat([pool, pool_neg, pool_neg], dim=0)
-        out = self._loop.run(1, latents, ehs, pooled, self._time_ids(height, width, 3), self.scheduler,
+        out = self._loop.run(1, latents, ehs, pooled, self._time_ids(height, width, 3 * G), self.scheduler,
                              num_inference_steps, guidance_scale, image_guidance_scale, il3)
         return self._finish(out, output_type)

@@ -1,0 +1,111 @@
+"""End-to-end parity of the SDXLAdapter front ends (BASELINE configs 1/3/4 at mini
+dimensions): visual encoder → get_image_embeds (all branches, incl. the pooling asymmetry) → ResamplerXLV2 → CFG denoise
+loop, against the CPU oracle (oracle/restated_adapter.py)."""
+import pytest
+import torch
+
+from oracle import restated, restated_adapter as ra, restated_unet as ru, weights
+
+pytestmark = pytest.mark.gpu
+
+VIT = dict(image_size=112, patch_size=14, width=256, layers=2, heads=2, mlp_ratio=2.0, n_queries=64, output_dim=256)
+XCFG = dict(weights.MINI_XLV2, embedding_dim=256)            # 16 queries, dim 128, out 64 + 128
+
+
+def relerr(x, ref):
+    x, ref = x.float().cpu(), ref.float().cpu()
+    return ((x - ref).norm() / ref.norm()).item()
+
+
+def _build(dev, dtype, in_ch, cls):
+    from seedx_amd.detokenizer import EulerDiscreteScheduler, ResamplerXLV2
+    from seedx_amd.unet import UNet2DConditionModel
+    from seedx_amd.visual_encoder import VisionTransformerWithAttnPool
+    sd_vit, sd_x = weights.vit_sd(VIT), weights.xlv2_sd(XCFG)
+    ucfg = dict(ru.MINI_UNET, in_channels=in_ch, cross_attention_dim=192, pooled_dim=128)
+    sd_u = ru.unet_sd(ucfg)
+    vit = VisionTransformerWithAttnPool(**VIT)
+    vit.load_state_dict(sd_vit)
+    unet = UNet2DConditionModel(**ucfg)
+    unet.load_state_dict(sd_u)
+    rs = ResamplerXLV2(normalize=False, **XCFG)
+    rs.load_state_dict(sd_x, prefix="resampler.")
+    ad = cls(unet, rs, vit_down=True)
+    ad.init_pipe(vae=None, scheduler=EulerDiscreteScheduler(), visual_encoder=vit, image_transform=None,
+                 discrete_model=None, dtype=dtype, device=dev)
+    return ad, (sd_vit, sd_x, sd_u, ucfg)
+
+
+def test_get_image_embeds_branches(dev):
+    """image_tensor branch: ViT on [img, zeros], 64 tokens, NO pooling; image_embeds branch: cached negative, pooled 64→16."""
+    from seedx_amd.detokenizer import SDXLAdapter
+    ad, (sd_vit, sd_x, _, _) = _build(dev, torch.float16, 4, SDXLAdapter)
+    g = torch.Generator().manual_seed(0)
+    img = torch.randn(1, 3, 112, 112, generator=g)
+    out = ad.get_image_embeds(image_tensor=img)
+    ref = ra.get_image_embeds(sd_vit, VIT, sd_x, XCFG, image_tensor=img)
+    for o, r in zip(out, ref):
+        assert o.shape == r.shape and relerr(o, r) < 3e-3
+    feats = torch.randn(1, 16, 256, generator=g)               # what the LLM's output resampler would produce
+    out = ad.get_image_embeds(image_embeds=feats.to(dev), image_size=112)
+    ref = ra.get_image_embeds(sd_vit, VIT, sd_x, XCFG, image_embeds=feats, vit_down=True)
+    for o, r in zip(out, ref):
+        assert o.shape == r.shape and relerr(o, r) < 3e-3
+    assert (112, True) in ad._neg_cache                        # negative ViT features cached after the first call
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_config1_detokenizer_one_step(dev, dtype):
+    """BASELINE config 1: ViT features of one image → ONE UNet CFG-2 step (Euler), image_tensor branch."""
+    from seedx_amd.detokenizer import SDXLAdapter
+    ad, (sd_vit, sd_x, sd_u, ucfg) = _build(dev, dtype, 4, SDXLAdapter)
+    g = torch.Generator().manual_seed(1)
+    img = torch.randn(1, 3, 112, 112, generator=g)
+    noise = torch.randn(1, 4, 16, 16, generator=g)
+    ref = ra.adapter_generate(sd_vit, VIT, sd_x, XCFG, sd_u, ucfg, noise, 1, image_tensor=img, height=128, width=128)
+    out = ad.generate(image_tensor=img, latents=noise.clone(), num_inference_steps=1, height=128, width=128)
+    e = relerr(out, ref)
+    print(f"config-1 style (1 UNet step) {dtype} rel-L2 {e:.3e}")
+    assert e < (3e-3 if dtype == torch.float16 else 2.5e-2)
+
+
+def test_config3_t2i_from_llm_features_batched(dev):
+    """image_embeds branch → 4-step t2i loop; two generations denoised as ONE UNet batch must equal two single runs."""
+    from seedx_amd.detokenizer import SDXLAdapter
+    ad, (sd_vit, sd_x, sd_u, ucfg) = _build(dev, torch.float16, 4, SDXLAdapter)
+    g = torch.Generator().manual_seed(2)
+    feats = torch.randn(2, 16, 256, generator=g)
+    noise = torch.randn(2, 4, 16, 16, generator=g)
+    refs = [ra.adapter_generate(sd_vit, VIT, sd_x, XCFG, sd_u, ucfg, noise[i:i + 1], 4, image_embeds=feats[i:i + 1],
+                                height=128, width=128) for i in range(2)]
+    both = ad.generate(image_embeds=feats.to(dev), latents=noise.clone(), num_inference_steps=4, height=128, width=128, input_image_size=112)
+    assert both.shape == (2, 4, 16, 16)
+    for i in range(2):
+        e = relerr(both[i:i + 1], refs[i])
+        print(f"config-3 style batched generation {i}: rel-L2 {e:.3e}")
+        assert e < 5e-3
+    single = ad.generate(image_embeds=feats[:1].to(dev), latents=noise[:1].clone(), num_inference_steps=4, height=128, width=128, input_image_size=112)
+    assert relerr(single, refs[0]) < 5e-3
+
+
+def test_config4_edit_with_latent_image(dev):
+    """BASELINE config 4 (edit): 8-channel UNet, [text, image, uncond] order, un-scaled image latents, 3-step loop."""
+    from seedx_amd.detokenizer import SDXLAdapterWithLatentImage
+    ad, (sd_vit, sd_x, sd_u, ucfg) = _build(dev, torch.float16, 8, SDXLAdapterWithLatentImage)
+    g = torch.Generator().manual_seed(3)
+    feats = torch.randn(1, 16, 256, generator=g)
+    noise = torch.randn(1, 4, 16, 16, generator=g)
+    il = torch.randn(1, 4, 16, 16, generator=g)
+    ref = ra.adapter_generate(sd_vit, VIT, sd_x, XCFG, sd_u, ucfg, noise, 3, image_embeds=feats, image_latents=il,
+                              height=128, width=128)
+    out = ad.generate(image_embeds=feats.to(dev), latents=noise.clone(), image_latents=il, num_inference_steps=3, input_image_size=112,
+                      height=128, width=128)
+    e = relerr(out, ref)
+    print(f"config-4 style edit loop rel-L2 {e:.3e}")
+    assert e < 5e-3
+    # no source image → zero image latents (pipeline…:909-910)
+    ref0 = ra.adapter_generate(sd_vit, VIT, sd_x, XCFG, sd_u, ucfg, noise, 2, image_embeds=feats,
+                               image_latents=torch.zeros_like(il), height=128, width=128)
+    out0 = ad.generate(image_embeds=feats.to(dev), latents=noise.clone(), num_inference_steps=2, height=128, width=128,
+                       input_image_size=112)
+    assert relerr(out0, ref0) < 5e-3

@@ -24,7 +24,7 @@ def main():
     dev = torch.device("cuda:0")
     lib = _lib.load()
     dt = torch.bfloat16
-    names = ["128x128/2", "128x80/3", "64x128/3", "64x64/3"]
+    names = ["128x128/2", "128x80/3", "64x128/3", "64x64/3", "256x128/2", "256x128/3"]
     shapes = [(2048, 1280, 1280), (2048, 1280, 5120), (2048, 3840, 1280), (2048, 10240, 1280), (8192, 640, 640),
               (8192, 640, 2560), (8192, 1920, 640), (8192, 5120, 640), (32768, 320, 320), (2048, 1664, 1664),
               (2048, 4992, 1664), (2048, 8192, 1664), (2048, 1664, 8192), (165, 15360, 5120), (165, 5120, 13824),
@@ -33,7 +33,7 @@ def main():
         a = torch.randn(M, K, device=dev).to(dt)
         w = (torch.randn(N, K, device=dev) * 0.05).to(dt)
         row = []
-        for c in range(4):
+        for c in range(6):
             lib.sx_gemm_force_tile(c)
             t = timeit(lambda: ops.gemm(a, w))
             row.append("%s %6.1fus %5.0fTF" % (names[c], t * 1e6, 2 * M * N * K / t / 1e12))
@@ -46,7 +46,7 @@ def main():
         x = torch.randn(B, H, H, Cin, device=dev).to(dt)
         w = (torch.randn(Cout, 9 * Cin, device=dev) * 0.02).to(dt)
         row = []
-        for c in range(4):
+        for c in range(6):
             lib.sx_gemm_force_tile(c)
             t = timeit(lambda: ops.conv3x3(x, w))
             row.append("%s %6.1fus %5.0fTF" % (names[c], t * 1e6, 2 * B * H * H * Cout * 9 * Cin / t / 1e12))
