@@ -31,7 +31,7 @@ struct GemmP {
   const float* residual;
   int M, N, K, ldc, ldr, n_valid, res_mod, bias2d_rows, out_dtype, act, glu;
   int Hin, Win, Cin, Hout, Wout, stride, upsample, ldb2;
-  int tiles_m, tiles_n;
+  int tiles_m, tiles_n, xm, xn;   // tile grid and its XCD partition (xm x xn == 8, or 0 = linear remap)
   unsigned a_bytes, w_bytes;
 };
 
@@ -59,8 +59,24 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
 
-  const int t = xcd_remap(blockIdx.x, gridDim.x);
-  const int tile_m = t % p.tiles_m, tile_n = t / p.tiles_m;
+  // Tile → XCD mapping. Block b is observed on XCD b % 8 (performance heuristic only). Each XCD gets a compact
+  // (tiles_m/xm) x (tiles_n/xn) rectangle of the tile grid, so its private L2 holds A-panel/xm + W-panel/xn instead of
+  // re-streaming whole panels from Infinity Cache / HBM (PMC: profiles/r1_pmc_hbm.json).
+  int tile_m, tile_n;
+  if (p.xm == 0) {
+    const int t = xcd_remap(blockIdx.x, gridDim.x);
+    tile_m = t % p.tiles_m;
+    tile_n = t / p.tiles_m;
+  } else {
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int xr = xcd / p.xn, xc = xcd - xr * p.xn;
+    const int ms = xr * p.tiles_m / p.xm, me = (xr + 1) * p.tiles_m / p.xm;
+    const int ns = xc * p.tiles_n / p.xn, ne = (xc + 1) * p.tiles_n / p.xn;
+    const int rm = me - ms, rn = ne - ns;
+    if (idx >= rm * rn) return;  // padding block of an uneven split (exits before any barrier)
+    tile_m = ms + idx % rm;
+    tile_n = ns + idx / rm;
+  }
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)p.a_bytes, 0x00020000);
@@ -247,12 +263,28 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
 #endif
 }
 
+static int g_xcd_2d = 1;  // 2-D XCD tile partition on/off (tuning hook)
+
 template <typename TT, int BM, int BN, int WM, int WN, int NSTAGE>
 int launch_cfg(const GemmP& p0, int a_mode, hipStream_t st) {
   GemmP p = p0;
   p.tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.N + BN - 1) / BN;
-  const int grid = p.tiles_m * p.tiles_n;
+  int grid = p.tiles_m * p.tiles_n;
+  p.xm = p.xn = 0;
+  if (grid >= 16 && g_xcd_2d) {
+    // choose the 8-way split that minimises fabric traffic  A_bytes * xn + W_bytes * xm  among the least padded ones
+    const double ab = (double)p.M * p.K, wb = (double)p.N * p.K;
+    double best = 1e300;
+    for (int xm = 1; xm <= 8; xm *= 2) {
+      const int xn = 8 / xm;
+      if (xm > p.tiles_m || xn > p.tiles_n) continue;
+      const long padded = 8L * ((p.tiles_m + xm - 1) / xm) * ((p.tiles_n + xn - 1) / xn);
+      const double cost = (ab * xn + wb * xm) * (1.0 + 4.0 * (double)(padded - grid) / grid);
+      if (cost < best) { best = cost; p.xm = xm; p.xn = xn; }
+    }
+    if (p.xm) grid = 8 * ((p.tiles_m + p.xm - 1) / p.xm) * ((p.tiles_n + p.xn - 1) / p.xn);
+  }
   const size_t lds = (size_t)NSTAGE * (BM + (BN + 31) / 32 * 32) * 128;
   if (a_mode == SX_A_LINEAR) {
     auto k = gemm_kernel<TT, BM, BN, WM, WN, NSTAGE, SX_A_LINEAR>;
@@ -291,7 +323,8 @@ inline int pick_tile(int M, int N, bool glu, bool conv, int force) {
 using namespace sxk_gemm;
 
 static int g_force_tile = -1;
-extern "C" int sx_gemm_force_tile(int cfg) {  // tuning / test hook: -1 = automatic
+extern "C" int sx_gemm_force_tile(int cfg) {  // tuning / test hook: -1 = automatic; 100/101 = 2-D XCD partition off/on
+  if (cfg == 100 || cfg == 101) { sxk_gemm::g_xcd_2d = cfg - 100; return SX_OK; }
   g_force_tile = cfg;
   return SX_OK;
 }
