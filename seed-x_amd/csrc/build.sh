@@ -10,7 +10,11 @@ pids=()
 for f in gemm norm attn elementwise decode; do
   src="$HERE/$f.hip"; obj="$HERE/.obj/$f.o"
   if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ "$HERE/sx_common.h" -nt "$obj" ] || [ "$HERE/../../include/seedx_hip.h" -nt "$obj" ]; then
-    $HIPCC $FLAGS -c "$src" -o "$obj" &
+    extra=""
+    # MFMA accumulators in arch VGPRs: the softmax / rescale VALU code touches every accumulator each KV tile, the
+    # default AGPR form costs ~200 v_accvgpr_read/write per tile (attention only; the GEMM touches them once)
+    if [ "$f" = "attn" ] || [ -n "$SX_VGPR_FORM_ALL" ]; then extra="-mllvm -amdgpu-mfma-vgpr-form=1"; fi
+    $HIPCC $FLAGS $extra -c "$src" -o "$obj" &
     pids+=($!)
   fi
 done
