@@ -41,15 +41,16 @@ __device__ __forceinline__ void wait_vmcnt() {
 }
 
 template <typename TT, int BM, int BN, int WM, int WN, int NSTAGE, int AMODE>
-__global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
+__global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const GemmP p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // body uses gfx950-only builtins (LDS-DMA, MFMA); the host pass only needs the stub
   typedef typename TT::vec8 vec8;
-  static_assert(WM * WN == 4, "4 waves per block");
+  constexpr int NW = WM * WN;                     // waves per block: 4 (256 threads) or 8 (512 threads, 2 per SIMD)
+  static_assert(NW == 4 || NW == 8, "4 or 8 waves per block");
   constexpr int TM = BM / WM, TN = BN / WN;       // wave tile
   constexpr int FM = TM / 16, FN = TN / 16;       // 16x16 fragments per wave along m / n
-  constexpr int BNP = (BN + 31) / 32 * 32;        // W rows staged per tile (padded so every wave issues the same count)
-  constexpr int A_PER_WAVE = BM / 32;             // 1-KiB DMA slots (8 rows x 128 B) per wave per k-tile
-  constexpr int B_PER_WAVE = BNP / 32;
+  constexpr int BNP = (BN + 8 * NW - 1) / (8 * NW) * (8 * NW);  // W rows staged per tile (every wave issues the same count)
+  constexpr int A_PER_WAVE = BM / (8 * NW);       // 1-KiB DMA slots (8 rows x 128 B) per wave per k-tile
+  constexpr int B_PER_WAVE = BNP / (8 * NW);
   constexpr int LOADS = A_PER_WAVE + B_PER_WAVE;  // DMA instructions per wave per k-tile (vmcnt unit)
   constexpr int A_BYTES = BM * 128, B_BYTES = BNP * 128, STAGE = A_BYTES + B_BYTES;
   static_assert(LOADS * (NSTAGE - 1) <= 63, "vmcnt range");
@@ -285,15 +286,16 @@ int launch_cfg(const GemmP& p0, int a_mode, hipStream_t st) {
     }
     if (p.xm) grid = 8 * ((p.tiles_m + p.xm - 1) / p.xm) * ((p.tiles_n + p.xn - 1) / p.xn);
   }
-  const size_t lds = (size_t)NSTAGE * (BM + (BN + 31) / 32 * 32) * 128;
+  constexpr int NW = WM * WN;
+  const size_t lds = (size_t)NSTAGE * (BM + (BN + 8 * NW - 1) / (8 * NW) * (8 * NW)) * 128;
   if (a_mode == SX_A_LINEAR) {
     auto k = gemm_kernel<TT, BM, BN, WM, WN, NSTAGE, SX_A_LINEAR>;
     if (lds > 65536) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, p);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(NW * 64), lds, st, p);
   } else {
     auto k = gemm_kernel<TT, BM, BN, WM, WN, NSTAGE, SX_A_CONV3X3>;
     if (lds > 65536) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, p);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(NW * 64), lds, st, p);
   }
   SX_HIP_LAUNCH_CHECK();
   return SX_OK;
@@ -302,7 +304,7 @@ int launch_cfg(const GemmP& p0, int a_mode, hipStream_t st) {
 // tile menu: {BM, BN, relative per-tile efficiency, usable with glu}
 struct TileCfg { int bm, bn; double eff; bool glu_ok; };
 static const TileCfg kTiles[6] = {{128, 128, 1.00, true}, {128, 80, 0.88, false}, {64, 128, 0.85, true}, {64, 64, 0.65, true},
-                                  {256, 128, 1.0, true}, {256, 128, 1.0, true}};
+                                  {256, 256, 1.0, true}, {256, 128, 1.0, true}};
 
 // pick the tile that minimises (rounds over the 256 CUs) x (tile area / efficiency)
 // Rules fitted to the MI355X sweep in tools/bench_gemm_tiles.py (profiles/r1_gemm_tile_sweep.txt):
@@ -313,6 +315,12 @@ static const TileCfg kTiles[6] = {{128, 128, 1.00, true}, {128, 80, 0.88, false}
 inline int pick_tile(int M, int N, bool glu, bool conv, int force) {
   if (force >= 0 && force < 6 && (!glu || kTiles[force].glu_ok)) return force;
   auto tiles = [&](int c) { return (long)((M + kTiles[c].bm - 1) / kTiles[c].bm) * ((N + kTiles[c].bn - 1) / kTiles[c].bn); };
+  if (!conv) {
+    // 8-wave 256x256 tile (2 waves per SIMD, half the LDS / L2 traffic per FLOP): wins once it fills most of a round
+    const long t4 = tiles(4);
+    const double rounds = (double)t4 / 256.0;
+    if (t4 >= 200 && (double)((t4 + 255) / 256) / rounds <= 1.35) return 4;
+  }
   if (tiles(0) >= (conv ? 256 : 384)) return 0;
   if (!glu && !conv && N % 80 == 0 && tiles(1) <= 256 && tiles(1) >= 192) return 1;
   if (M <= 192 && tiles(2) < 256) return 3;
@@ -377,8 +385,8 @@ extern "C" int sx_gemm(const sx_gemm_args* a, void* stream) {
     case 1: return launch_cfg<TT, 128, 80, 4, 1, 3>(p, a->a_mode, st);        \
     case 2: return launch_cfg<TT, 64, 128, 2, 2, 3>(p, a->a_mode, st);        \
     case 3: return launch_cfg<TT, 64, 64, 2, 2, 3>(p, a->a_mode, st);         \
-    case 4: return launch_cfg<TT, 256, 128, 2, 2, 2>(p, a->a_mode, st);       \
-    default: return launch_cfg<TT, 256, 128, 2, 2, 3>(p, a->a_mode, st);      \
+    case 4: return launch_cfg<TT, 256, 256, 2, 4, 2>(p, a->a_mode, st);       \
+    default: return launch_cfg<TT, 256, 128, 4, 2, 2>(p, a->a_mode, st);      \
   }
   if (a->dtype == SX_BF16) { SX_GEMM_DISPATCH(BF16) } else { SX_GEMM_DISPATCH(F16) }
 #undef SX_GEMM_DISPATCH

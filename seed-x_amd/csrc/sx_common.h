@@ -106,7 +106,20 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // activations (fp32 math, exact-erf GELU as torch nn.GELU())
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// exact-erf GELU (torch nn.GELU()). erf by Abramowitz–Stegun 7.1.26 (|abs err| <= 1.5e-7, far below the 16-bit operand
+// rounding): 1 v_rcp + 1 v_exp + ~10 FMAs per element instead of the ~30-instruction libm erff in the GEGLU epilogues
+__device__ __forceinline__ float gelu_erf(float x) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  float pl = fmaf(1.061405429f, t, -1.453152027f);
+  pl = fmaf(pl, t, 1.421413741f);
+  pl = fmaf(pl, t, -0.284496736f);
+  pl = fmaf(pl, t, 0.254829592f);
+  const float e = __builtin_amdgcn_exp2f(-z * z * 1.4426950408889634f);
+  const float erf_abs = fmaf(-pl * t, e, 1.0f);          // erf(|x|/sqrt2)
+  const float h = 0.5f * x;
+  return fmaf(copysignf(erf_abs, x), h, h);               // 0.5 x (1 + erf(x/sqrt2))
+}
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float apply_act(float x, int act) {
   if (act == SX_ACT_GELU) return gelu_erf(x);

@@ -24,7 +24,7 @@ def main():
     dev = torch.device("cuda:0")
     lib = _lib.load()
     dt = torch.bfloat16
-    names = ["128x128/2", "128x80/3", "64x128/3", "64x64/3", "256x128/2", "256x128/3"]
+    names = ["128x128/2", "128x80/3", "64x128/3", "64x64/3", "256x256-8w", "256x128-8w"]
     shapes = [(2048, 1280, 1280), (2048, 1280, 5120), (2048, 3840, 1280), (2048, 10240, 1280), (8192, 640, 640),
               (8192, 640, 2560), (8192, 1920, 640), (8192, 5120, 640), (32768, 320, 320), (2048, 1664, 1664),
               (2048, 4992, 1664), (2048, 8192, 1664), (2048, 1664, 8192), (165, 15360, 5120), (165, 5120, 13824),
