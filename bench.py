@@ -60,7 +60,7 @@ def build_models(dev, dtype):
     vit.load_state_dict(syn.vit_state_dict(syn.FULL_VIT, dev, dtype))
     vit.eval().to(dev, dtype=dtype)
     vit._pack()
-    llm = LlamaForCausalLM(dict(syn.FULL_LLM), max_cache_len=1024)
+    llm = LlamaForCausalLM(dict(syn.FULL_LLM), max_cache_len=1024, max_batch=BATCH)
     llm.load_state_dict(syn.llama_state_dict(syn.FULL_LLM, dev, dtype))
     llm.to(dev, dtype)
     llm._pack()
@@ -100,19 +100,18 @@ BATCH = 1   # generations processed together per step on one GPU (set from --bat
 
 
 def front_half(vit, agent, tok, inp, n_text):
-    """Paths A + B for BATCH requests: ViT on all 2·BATCH crops at once, then each request's greedy decode in turn.
+    """Paths A + B for BATCH requests: ViT on all 2·BATCH crops at once, then the BATCH greedy decodes in lock step.
     Returns the image-generation features [BATCH, 64, 4096]."""
     image, patch_pos, ids, mask = inp
     G = BATCH
     emb = vit(image if G == 1 else image.repeat(G, 1, 1, 1))                    # path A, [2G, 256, 4096]
-    feats = []
-    for g in range(G):
-        out = agent.generate(tok, input_ids=[ids], image_embeds=emb[2 * g:2 * g + 2],
-                             embeds_cmp_mask=torch.tensor([True, True]), ids_cmp_mask=mask, patch_positions=patch_pos,
-                             max_new_tokens=n_text + 66 + 1, eos_token_id=None, force_image_at=n_text)   # path B
+    reqs = [dict(input_ids=[ids], image_embeds=emb[2 * g:2 * g + 2], embeds_cmp_mask=torch.tensor([True, True]),
+                 ids_cmp_mask=mask, patch_positions=patch_pos) for g in range(G)]
+    outs = agent.generate_batch(tok, reqs, max_new_tokens=n_text + 66 + 1, eos_token_id=None,
+                                force_image_at=n_text)                          # path B, G sequences in lock step
+    for out in outs:
         assert out["has_img_output"] and out["img_gen_feat"].shape == (1, 64, 4096), "transcript did not yield an image"
-        feats.append(out["img_gen_feat"])
-    return torch.cat(feats, dim=0)
+    return torch.cat([o["img_gen_feat"] for o in outs], dim=0)
 
 
 def back_half(adapter, feats, steps_unet, seed):

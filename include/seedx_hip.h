@@ -184,6 +184,23 @@ int sx_scatter_rows(const float* src, const int32_t* rows, float* dst, int n, in
 int sx_greedy_next(float* logits, int vocab, const int32_t* img_ids_dev, int n_img, const int32_t* prev_id_dev,
                    int32_t* next_id_dev, int32_t* out_ids, const int32_t* step_dev, void* stream);
 
+/* Lock-step batched decode (G independent sequences, one token each): same kernels with a sequence dimension.
+ * Caches are [G][H][Tmax][D] (cache_seq_stride elements apart), positions / context lengths / step counters / token ids
+ * are per-sequence device arrays, so weights are streamed from HBM once per step for all G sequences. */
+int sx_rope_kv_append_b(void* qkv, void* kcache, void* vcache, const float* cos_tab, const float* sin_tab,
+                        const int32_t* pos0_dev, int G, int T, int H, int D, int Tmax, int64_t cache_seq_stride, int dtype,
+                        void* stream);
+int sx_attn_decode_b(const void* q, const void* kcache, const void* vcache, void* out, float* scratch,
+                     const int32_t* ctx_len_dev, int G, int H, int D, int Tmax, int64_t cache_seq_stride, int nsplit,
+                     float scale, int dtype, void* stream);
+int sx_greedy_next_b(float* logits, int ld_logits, int vocab, const int32_t* img_ids_dev, int n_img,
+                     const int32_t* prev_id_dev, int32_t* next_id_dev, int32_t* out_ids, int ld_out,
+                     const int32_t* step_dev, int G, void* stream);
+/* dst[(g*seq_rows + step[g])][:] = src[g][:] fp32 (per-sequence hidden-state log, seed_x.py:196) */
+int sx_scatter_rows_step(const float* src, const int32_t* step_dev, float* dst, int G, int dim, int seq_rows, void* stream);
+/* p[0..n) += delta */
+int sx_add_i32_n(int32_t* p, int delta, int n, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Elementwise / layout helpers
  * ------------------------------------------------------------------------------------------------ */

@@ -93,10 +93,14 @@ template <typename TT>
 __global__ __launch_bounds__(256) void attn_decode_kernel(const unsigned short* q, const unsigned short* kc,
                                                           const unsigned short* vc, float* scratch,
                                                           const int* ctx_len_dev, int D, int Tmax, int nsplit,
-                                                          float scale) {
+                                                          float scale, long long seq_stride) {
   __shared__ float red[16][132];  // 16 lane-groups x (D<=128 outputs + m + l)
-  const int h = blockIdx.x, sp = blockIdx.y;
-  const int ctx = *ctx_len_dev;
+  const int h = blockIdx.x, sp = blockIdx.y, g = blockIdx.z, H = gridDim.x;
+  const int ctx = ctx_len_dev[g];
+  q += (size_t)g * H * D;
+  kc += (size_t)g * seq_stride;
+  vc += (size_t)g * seq_stride;
+  scratch += (size_t)g * H * nsplit * (D + 2);
   const int chunk = (ctx + nsplit - 1) / nsplit;
   const int t0 = sp * chunk, t1 = min(ctx, t0 + chunk);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -181,8 +185,10 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const unsigned short* 
 
 template <typename TT>
 __global__ void attn_decode_combine_kernel(const float* scratch, unsigned short* out, int D, int nsplit) {
-  const int h = blockIdx.x, d = threadIdx.x;
+  const int h = blockIdx.x, d = threadIdx.x, g = blockIdx.y, H = gridDim.x;
   if (d >= D) return;
+  scratch += (size_t)g * H * nsplit * (D + 2);
+  out += (size_t)g * H * D;
   const float* base = scratch + (size_t)h * nsplit * (D + 2);
   float mg = -INFINITY;
   for (int s = 0; s < nsplit; ++s) mg = fmaxf(mg, base[(size_t)s * (D + 2) + D]);
@@ -199,19 +205,20 @@ __global__ void attn_decode_combine_kernel(const float* scratch, unsigned short*
 // ---- RoPE + KV append ----------------------------------------------------------------------------------------------
 template <typename TT>
 __global__ void rope_kv_append_kernel(unsigned short* qkv, unsigned short* kc, unsigned short* vc, const float* cos_t,
-                                      const float* sin_t, const int* pos0_dev, int T, int H, int D, int Tmax) {
+                                      const float* sin_t, const int* pos0_dev, int T, int H, int D, int Tmax, int G,
+                                      long long seq_stride) {
   const int half = D / 2;
-  const int pos0 = *pos0_dev;
-  const int64_t total = (int64_t)T * H * half;
+  const int64_t total = (int64_t)G * T * H * half;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int j = (int)(i % half);
     const int h = (int)((i / half) % H);
-    const int t = (int)(i / ((int64_t)half * H));
-    const int pos = pos0 + t;
+    const int r = (int)(i / ((int64_t)half * H));     // row of qkv = g*T + t
+    const int g = r / T, t = r - g * T;
+    const int pos = pos0_dev[g] + t;
     // tables are rounded to the activation dtype before use (modeling_llama_xformer.py:128-131)
     const float c = TT::to_f32(TT::from_f32(cos_t[(size_t)pos * half + j]));
     const float s = TT::to_f32(TT::from_f32(sin_t[(size_t)pos * half + j]));
-    unsigned short* row = qkv + (size_t)t * 3 * H * D;
+    unsigned short* row = qkv + (size_t)r * 3 * H * D;
     unsigned short* qh = row + (size_t)h * D;
     const unsigned short* kh = row + (size_t)(H + h) * D;
     const unsigned short* vh = row + (size_t)(2 * H + h) * D;
@@ -219,8 +226,8 @@ __global__ void rope_kv_append_kernel(unsigned short* qkv, unsigned short* kc, u
     qh[j] = TT::from_f32(q1 * c - q2 * s);
     qh[j + half] = TT::from_f32(q2 * c + q1 * s);
     const float k1 = TT::to_f32(kh[j]), k2 = TT::to_f32(kh[j + half]);
-    unsigned short* kd = kc + ((size_t)h * Tmax + pos) * D;
-    unsigned short* vd = vc + ((size_t)h * Tmax + pos) * D;
+    unsigned short* kd = kc + (size_t)g * seq_stride + ((size_t)h * Tmax + pos) * D;
+    unsigned short* vd = vc + (size_t)g * seq_stride + ((size_t)h * Tmax + pos) * D;
     kd[j] = TT::from_f32(k1 * c - k2 * s);
     kd[j + half] = TT::from_f32(k2 * c + k1 * s);
     vd[j] = vh[j];
@@ -245,10 +252,25 @@ __global__ void scatter_rows_kernel(const float* src, const int* rows, float* ds
   }
 }
 
+// dst[(g*seq_rows + step[g])][:] = src[g][:]  (per-sequence hidden-state log of the lock-step batched decode)
+__global__ void scatter_rows_step_kernel(const float* src, const int* step, float* dst, int G, int dim, int seq_rows) {
+  const int64_t total = (int64_t)G * dim;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int g = (int)(i / dim), d = (int)(i % dim);
+    dst[((size_t)g * seq_rows + step[g]) * dim + d] = src[i];
+  }
+}
+
 // ---- greedy next token with the AutoImageTokenGenerationProcessor rule (generation.py:19-31) ------------------------
 __global__ __launch_bounds__(1024) void greedy_next_kernel(float* logits, int vocab, const int* img_ids, int n_img,
                                                            const int* prev_id, int* next_id, int* out_ids,
-                                                           const int* step_dev) {
+                                                           const int* step_dev, int ld_logits, int ld_out) {
+  // one block per sequence
+  logits += (size_t)blockIdx.x * ld_logits;
+  prev_id += blockIdx.x;
+  next_id += blockIdx.x;
+  if (out_ids) out_ids += (size_t)blockIdx.x * ld_out;
+  if (step_dev) step_dev += blockIdx.x;
   __shared__ float smax[16];
   __shared__ int sidx[16];
   __shared__ int forced;
@@ -328,42 +350,54 @@ extern "C" int sx_gemv(const sx_gemv_args* a, void* stream) {
   return SX_OK;
 }
 
-extern "C" int sx_attn_decode(const void* q, const void* kcache, const void* vcache, void* out, float* scratch,
-                              const int32_t* ctx_len_dev, int H, int D, int Tmax, int nsplit, float scale, int dtype,
-                              void* stream) {
+extern "C" int sx_attn_decode_b(const void* q, const void* kcache, const void* vcache, void* out, float* scratch,
+                                const int32_t* ctx_len_dev, int G, int H, int D, int Tmax, int64_t cache_seq_stride,
+                                int nsplit, float scale, int dtype, void* stream) {
   SX_CHECK(q && kcache && vcache && out && scratch && ctx_len_dev, "sx_attn_decode: null pointer");
   SX_CHECK(D % 8 == 0 && D <= 128, "sx_attn_decode: head_dim %d", D);
-  SX_CHECK(nsplit >= 1 && nsplit <= 64, "sx_attn_decode: nsplit");
+  SX_CHECK(nsplit >= 1 && nsplit <= 64 && G >= 1, "sx_attn_decode: nsplit/G");
   if (dtype == SX_BF16) {
-    hipLaunchKernelGGL(attn_decode_kernel<BF16>, dim3(H, nsplit), dim3(256), 0, ST, (const unsigned short*)q,
+    hipLaunchKernelGGL(attn_decode_kernel<BF16>, dim3(H, nsplit, G), dim3(256), 0, ST, (const unsigned short*)q,
                        (const unsigned short*)kcache, (const unsigned short*)vcache, scratch, ctx_len_dev, D, Tmax,
-                       nsplit, scale);
-    hipLaunchKernelGGL(attn_decode_combine_kernel<BF16>, dim3(H), dim3(128), 0, ST, scratch, (unsigned short*)out, D,
+                       nsplit, scale, (long long)cache_seq_stride);
+    hipLaunchKernelGGL(attn_decode_combine_kernel<BF16>, dim3(H, G), dim3(128), 0, ST, scratch, (unsigned short*)out, D,
                        nsplit);
   } else {
-    hipLaunchKernelGGL(attn_decode_kernel<F16>, dim3(H, nsplit), dim3(256), 0, ST, (const unsigned short*)q,
+    hipLaunchKernelGGL(attn_decode_kernel<F16>, dim3(H, nsplit, G), dim3(256), 0, ST, (const unsigned short*)q,
                        (const unsigned short*)kcache, (const unsigned short*)vcache, scratch, ctx_len_dev, D, Tmax,
-                       nsplit, scale);
-    hipLaunchKernelGGL(attn_decode_combine_kernel<F16>, dim3(H), dim3(128), 0, ST, scratch, (unsigned short*)out, D,
+                       nsplit, scale, (long long)cache_seq_stride);
+    hipLaunchKernelGGL(attn_decode_combine_kernel<F16>, dim3(H, G), dim3(128), 0, ST, scratch, (unsigned short*)out, D,
                        nsplit);
   }
   SX_HIP_LAUNCH_CHECK();
   return SX_OK;
 }
+extern "C" int sx_attn_decode(const void* q, const void* kcache, const void* vcache, void* out, float* scratch,
+                              const int32_t* ctx_len_dev, int H, int D, int Tmax, int nsplit, float scale, int dtype,
+                              void* stream) {
+  return sx_attn_decode_b(q, kcache, vcache, out, scratch, ctx_len_dev, 1, H, D, Tmax, 0, nsplit, scale, dtype, stream);
+}
 
-extern "C" int sx_rope_kv_append(void* qkv, void* kcache, void* vcache, const float* cos_tab, const float* sin_tab,
-                                 const int32_t* pos0_dev, int T, int H, int D, int Tmax, int dtype, void* stream) {
+extern "C" int sx_rope_kv_append_b(void* qkv, void* kcache, void* vcache, const float* cos_tab, const float* sin_tab,
+                                   const int32_t* pos0_dev, int G, int T, int H, int D, int Tmax,
+                                   int64_t cache_seq_stride, int dtype, void* stream) {
   SX_CHECK(qkv && kcache && vcache && cos_tab && sin_tab && pos0_dev, "sx_rope_kv_append: null pointer");
-  SX_CHECK(D % 2 == 0, "sx_rope_kv_append: D");
-  const int64_t n = (int64_t)T * H * (D / 2);
+  SX_CHECK(D % 2 == 0 && G >= 1 && T >= 1, "sx_rope_kv_append: D/G/T");
+  const int64_t n = (int64_t)G * T * H * (D / 2);
   if (dtype == SX_BF16)
     hipLaunchKernelGGL(rope_kv_append_kernel<BF16>, gs_grid(n), dim3(256), 0, ST, (unsigned short*)qkv,
-                       (unsigned short*)kcache, (unsigned short*)vcache, cos_tab, sin_tab, pos0_dev, T, H, D, Tmax);
+                       (unsigned short*)kcache, (unsigned short*)vcache, cos_tab, sin_tab, pos0_dev, T, H, D, Tmax, G,
+                       (long long)cache_seq_stride);
   else
     hipLaunchKernelGGL(rope_kv_append_kernel<F16>, gs_grid(n), dim3(256), 0, ST, (unsigned short*)qkv,
-                       (unsigned short*)kcache, (unsigned short*)vcache, cos_tab, sin_tab, pos0_dev, T, H, D, Tmax);
+                       (unsigned short*)kcache, (unsigned short*)vcache, cos_tab, sin_tab, pos0_dev, T, H, D, Tmax, G,
+                       (long long)cache_seq_stride);
   SX_HIP_LAUNCH_CHECK();
   return SX_OK;
+}
+extern "C" int sx_rope_kv_append(void* qkv, void* kcache, void* vcache, const float* cos_tab, const float* sin_tab,
+                                 const int32_t* pos0_dev, int T, int H, int D, int Tmax, int dtype, void* stream) {
+  return sx_rope_kv_append_b(qkv, kcache, vcache, cos_tab, sin_tab, pos0_dev, 1, T, H, D, Tmax, 0, dtype, stream);
 }
 
 extern "C" int sx_embedding(const int32_t* ids, const void* table, float* out, int T, int dim, int dtype,
@@ -387,14 +421,28 @@ extern "C" int sx_scatter_rows(const float* src, const int32_t* rows, float* dst
   return SX_OK;
 }
 
+extern "C" int sx_greedy_next_b(float* logits, int ld_logits, int vocab, const int32_t* img_ids_dev, int n_img,
+                                const int32_t* prev_id_dev, int32_t* next_id_dev, int32_t* out_ids, int ld_out,
+                                const int32_t* step_dev, int G, void* stream) {
+  SX_CHECK(logits && img_ids_dev && prev_id_dev && next_id_dev, "sx_greedy_next: null pointer");
+  SX_CHECK(n_img >= 2 && n_img <= 1024 && G >= 1, "sx_greedy_next: n_img=%d G=%d", n_img, G);
+  SX_CHECK(!out_ids || step_dev, "sx_greedy_next: out_ids needs step_dev");
+  hipLaunchKernelGGL(greedy_next_kernel, dim3(G), dim3(1024), 0, ST, logits, vocab, img_ids_dev, n_img, prev_id_dev,
+                     next_id_dev, out_ids, step_dev, ld_logits, ld_out);
+  SX_HIP_LAUNCH_CHECK();
+  return SX_OK;
+}
 extern "C" int sx_greedy_next(float* logits, int vocab, const int32_t* img_ids_dev, int n_img,
                               const int32_t* prev_id_dev, int32_t* next_id_dev, int32_t* out_ids,
                               const int32_t* step_dev, void* stream) {
-  SX_CHECK(logits && img_ids_dev && prev_id_dev && next_id_dev, "sx_greedy_next: null pointer");
-  SX_CHECK(n_img >= 2 && n_img <= 1024, "sx_greedy_next: n_img=%d", n_img);
-  SX_CHECK(!out_ids || step_dev, "sx_greedy_next: out_ids needs step_dev");
-  hipLaunchKernelGGL(greedy_next_kernel, dim3(1), dim3(1024), 0, ST, logits, vocab, img_ids_dev, n_img, prev_id_dev,
-                     next_id_dev, out_ids, step_dev);
+  return sx_greedy_next_b(logits, 0, vocab, img_ids_dev, n_img, prev_id_dev, next_id_dev, out_ids, 0, step_dev, 1, stream);
+}
+
+extern "C" int sx_scatter_rows_step(const float* src, const int32_t* step_dev, float* dst, int G, int dim, int seq_rows,
+                                    void* stream) {
+  SX_CHECK(src && step_dev && dst && G >= 1, "sx_scatter_rows_step: bad args");
+  hipLaunchKernelGGL(scatter_rows_step_kernel, gs_grid((int64_t)G * dim), dim3(256), 0, ST, src, step_dev, dst, G, dim,
+                     seq_rows);
   SX_HIP_LAUNCH_CHECK();
   return SX_OK;
 }

@@ -175,7 +175,9 @@ __global__ void cfg_euler_kernel(const float* eps, float* lat, float* scaled_nex
   }
 }
 
-__global__ void add_i32_kernel(int* p, int delta) { *p += delta; }
+__global__ void add_i32_kernel(int* p, int delta, int n) {
+  if ((int)threadIdx.x < n) p[threadIdx.x] += delta;
+}
 
 }  // namespace sxk_elementwise
 using namespace sxk_elementwise;
@@ -258,12 +260,13 @@ extern "C" int sx_cfg_euler_step(const float* eps, float* latents, float* scaled
   SX_HIP_LAUNCH_CHECK();
   return SX_OK;
 }
-extern "C" int sx_add_i32(int32_t* p, int delta, void* stream) {
-  SX_CHECK(p, "sx_add_i32: null");
-  hipLaunchKernelGGL(add_i32_kernel, dim3(1), dim3(1), 0, ST, p, delta);
+extern "C" int sx_add_i32_n(int32_t* p, int delta, int n, void* stream) {
+  SX_CHECK(p && n >= 1 && n <= 64, "sx_add_i32: bad args");
+  hipLaunchKernelGGL(add_i32_kernel, dim3(1), dim3(64), 0, ST, p, delta, n);
   SX_HIP_LAUNCH_CHECK();
   return SX_OK;
 }
+extern "C" int sx_add_i32(int32_t* p, int delta, void* stream) { return sx_add_i32_n(p, delta, 1, stream); }
 
 // y = silu(x) cast to 16 bit (time-embedding path: every ResnetBlock2D consumes silu(emb))
 __global__ void silu_cast_kernel(const float* x, void* y, int dt, int64_t n) {

@@ -315,11 +315,12 @@ static const TileCfg kTiles[6] = {{128, 128, 1.00, true}, {128, 80, 0.88, false}
 inline int pick_tile(int M, int N, bool glu, bool conv, int force) {
   if (force >= 0 && force < 6 && (!glu || kTiles[force].glu_ok)) return force;
   auto tiles = [&](int c) { return (long)((M + kTiles[c].bm - 1) / kTiles[c].bm) * ((N + kTiles[c].bn - 1) / kTiles[c].bn); };
-  if (!conv) {
+  {
     // 8-wave 256x256 tile (2 waves per SIMD, half the LDS / L2 traffic per FLOP): wins once it fills most of a round
     const long t4 = tiles(4);
-    const double rounds = (double)t4 / 256.0;
-    if (t4 >= 200 && (double)((t4 + 255) / 256) / rounds <= 1.35) return 4;
+    const double waste = (double)((t4 + 255) / 256) / ((double)t4 / 256.0);
+    if (!conv && t4 >= 200 && waste <= 1.35) return 4;
+    if (conv && ((t4 >= 150 && t4 <= 256) || (t4 > 256 && waste <= 1.15))) return 4;   // tools/bench_conv_b8.py
   }
   if (tiles(0) >= (conv ? 256 : 384)) return 0;
   if (!glu && !conv && N % 80 == 0 && tiles(1) <= 256 && tiles(1) >= 192) return 1;

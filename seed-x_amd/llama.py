@@ -1,15 +1,17 @@
 """Path B — Llama-style decoder on the HIP kernels (prefill on MFMA, single-token decode on the HBM-bound
-GEMV path, device-resident greedy loop captured in a HIP graph).
+GEMV path, device-resident greedy loop captured in a HIP graph, optional lock-step batching of independent sequences).
 
 Mirrors ``src/models/mllm/modeling_llama_xformer.py`` (``LlamaForCausalLM``: ``forward`` :643-746 semantics —
 logits, past_key_values, hidden_states with the LAST entry = post-final-norm state :595-599 —,
 ``get_input_embeddings`` :623) with the reference's state-dict key names. Differences by design:
-  * KV cache is pre-allocated [layer][head][Tmax][hd] and appended in place by the fused RoPE kernel, instead of
+  * KV cache is pre-allocated [layer][seq][head][Tmax][hd] and appended in place by the fused RoPE kernel, instead of
     ``torch.cat`` every step (:215-220)
   * q/k/v and gate/up projections are fused GEMMs (weights concatenated / GLU-packed at load)
   * the 4 NaN/Inf guards (:702-713) and the per-layer ``attention_mask.sum()`` sync (:236) are dropped: prefill and
     multi-token chunks are causal (bottom-right aligned), q_len == 1 attends to the whole cache — same math
   * logits are only produced for the last position (the greedy loop never reads the others)
+  * ``max_batch`` > 1: G independent sequences (separate KV caches / positions) decode in lock step, so the 25.7 GB of
+    weights are streamed from HBM once per step for all G tokens (the reference is batch 1 only, seed_x.py:191)
 """
 import math
 
@@ -47,7 +49,7 @@ class _Embedding:
 
 
 class LlamaForCausalLM:
-    def __init__(self, config, max_cache_len=None):
+    def __init__(self, config, max_cache_len=None, max_batch=1):
         self.config = config if not isinstance(config, dict) else LlamaConfigLite(**config)
         c = self.config
         self.H, self.nh, self.L = c.hidden_size, c.num_attention_heads, c.num_hidden_layers
@@ -55,6 +57,8 @@ class LlamaForCausalLM:
         self.I, self.V = c.intermediate_size, c.vocab_size
         self.Vpad = (self.V + 63) // 64 * 64       # 32330 → 32384: lm_head rows padded with zeros
         self.Tmax = max_cache_len or c.max_position_embeddings
+        self.G = int(max_batch)
+        assert 1 <= self.G <= 8, "lock-step batch is limited to 8 sequences (sx_gemv rows)"
         self.device, self.dtype = None, torch.float16
         self._sd, self._P = None, None
         self._graph = None
@@ -141,61 +145,66 @@ class LlamaForCausalLM:
         inv = 1.0 / (self.config.rope_base ** (torch.arange(0, self.hd, 2).float() / self.hd))
         fr = torch.outer(torch.arange(self.Tmax).float(), inv)           # [Tmax, hd/2] fp32 (:97-113)
         P["cos"], P["sin"] = fr.cos().to(dev).contiguous(), fr.sin().to(dev).contiguous()
-        P["kc"] = torch.zeros((self.L, self.nh, self.Tmax, self.hd), dtype=dt, device=dev)
+        G = self.G
+        P["kc"] = torch.zeros((self.L, G, self.nh, self.Tmax, self.hd), dtype=dt, device=dev)
         P["vc"] = torch.zeros_like(P["kc"])
-        # device-resident loop state
-        P["pos"] = torch.zeros(1, dtype=torch.int32, device=dev)         # position of the next input token
-        P["ctx"] = torch.ones(1, dtype=torch.int32, device=dev)          # pos + 1 (keys visible to that token)
-        P["step"] = torch.zeros(1, dtype=torch.int32, device=dev)        # index into out_ids / hidden buffer
-        P["cur"] = torch.zeros(1, dtype=torch.int32, device=dev)         # current input token id
+        # device-resident loop state, one entry per sequence
+        P["pos"] = torch.zeros(G, dtype=torch.int32, device=dev)         # position of the next input token
+        P["ctx"] = torch.ones(G, dtype=torch.int32, device=dev)          # pos + 1 (keys visible to that token)
+        P["step"] = torch.zeros(G, dtype=torch.int32, device=dev)        # index into out_ids / hidden buffer
+        P["cur"] = torch.zeros(G, dtype=torch.int32, device=dev)         # current input token id
         self._P = P
         self._sd = None
         self._graph = None
         return P
 
     # ---- core passes ---------------------------------------------------------------------------------------------------
-    def reset(self):
+    def reset(self, seq=None):
         P = self._pack()
-        P["pos"].zero_()
-        P["step"].zero_()
-        P["ctx"].fill_(1)               # invariant: ctx == pos + 1 (keys visible to the token at `pos`)
+        s = slice(None) if seq is None else slice(seq, seq + 1)
+        P["pos"][s] = 0
+        P["step"][s] = 0
+        P["ctx"][s] = 1                 # invariant: ctx == pos + 1 (keys visible to the token at `pos`)
 
-    def _layers_multi(self, x, T):
-        """T > 1 tokens at positions pos..pos+T-1 (prefill or a forced-token chunk): MFMA GEMMs + causal flash
-        attention over the cache. x: fp32 [T, H] residual stream. Returns the final residual stream."""
+    def _layers_multi(self, x, T, seq):
+        """T tokens of sequence `seq` at positions pos..pos+T-1 (prefill or a forced-token chunk): MFMA GEMMs + causal
+        flash attention over that sequence's cache. x: fp32 [T, H] residual stream. Returns the final residual stream."""
         P, dt, H, nh, hd = self._P, self.dtype, self.H, self.nh, self.hd
-        pos0 = int(P["pos"].item())
+        pos_v, ctx_v = P["pos"][seq:seq + 1], P["ctx"][seq:seq + 1]
+        pos0 = int(pos_v.item())
         Tk = pos0 + T
         assert Tk <= self.Tmax, f"sequence {Tk} exceeds the KV cache ({self.Tmax})"
         eps = self.config.rms_norm_eps
         scale = 1.0 / math.sqrt(hd)
         for li, lw in enumerate(P["layers"]):
+            kc, vc = P["kc"][li][seq], P["vc"][li][seq]
             h = ops.rmsnorm(x, lw["ln1"], eps, dt)
             qkv = ops.gemm(h, lw["wqkv"])                                             # [T, 3H]
-            ops.rope_kv_append(qkv, P["kc"][li], P["vc"][li], P["cos"], P["sin"], P["pos"], nh, hd)
+            ops.rope_kv_append(qkv, kc, vc, P["cos"], P["sin"], pos_v, nh, hd)
             q4 = qkv.view(1, T, 3, nh, hd)[:, :, 0]
-            k4 = P["kc"][li][:, :Tk].permute(1, 0, 2).unsqueeze(0)                     # [1, Tk, nh, hd] view of the cache
-            v4 = P["vc"][li][:, :Tk].permute(1, 0, 2).unsqueeze(0)
+            k4 = kc[:, :Tk].permute(1, 0, 2).unsqueeze(0)                              # [1, Tk, nh, hd] view of the cache
+            v4 = vc[:, :Tk].permute(1, 0, 2).unsqueeze(0)
             att = ops.attention(q4, k4, v4, scale, causal=True)                       # [1, T, H]
             x = ops.gemm(att.view(T, H), lw["wo"], residual=x, out_dtype=torch.float32)
             h = ops.rmsnorm(x, lw["ln2"], eps, dt)
             g = ops.gemm(h, lw["wgu"], act="silu", glu=True)                          # silu(gate) * up, [T, I]
             x = ops.gemm(g, lw["wd"], residual=x, out_dtype=torch.float32)
-        ops.add_i32(P["pos"], T)
-        ops.add_i32(P["ctx"], T)
+        ops.add_i32(pos_v, T)
+        ops.add_i32(ctx_v, T)
         return x
 
     def _layers_single(self, x):
-        """One token at position *pos (device scalar): weight-streaming GEMVs + split-KV decode attention. No host
-        reads → graph-capturable."""
-        P, dt, H, nh, hd = self._P, self.dtype, self.H, self.nh, self.hd
+        """One token of EVERY sequence (x: fp32 [G, H]) at the device-resident positions: weight-streaming GEMVs with
+        M = G rows + split-KV decode attention per sequence. No host reads → graph-capturable."""
+        P, dt, H, nh, hd, G = self._P, self.dtype, self.H, self.nh, self.hd, self.G
         eps = self.config.rms_norm_eps
         scale = 1.0 / math.sqrt(hd)
         for li, lw in enumerate(P["layers"]):
             h = ops.rmsnorm(x, lw["ln1"], eps, dt)
-            qkv = ops.gemv(h, lw["wqkv"])                                             # [1, 3H]
-            ops.rope_kv_append(qkv, P["kc"][li], P["vc"][li], P["cos"], P["sin"], P["pos"], nh, hd)
-            att = ops.attn_decode(qkv[0, :H].view(nh, hd), P["kc"][li], P["vc"][li], P["ctx"], scale)
+            qkv = ops.gemv(h, lw["wqkv"])                                             # [G, 3H]
+            ops.rope_kv_append_b(qkv, P["kc"][li], P["vc"][li], P["cos"], P["sin"], P["pos"], G, 1, nh, hd)
+            q = qkv[:, :H] if G == 1 else qkv[:, :H].contiguous()                    # [G, H] (plumbing copy for G > 1)
+            att = ops.attn_decode_b(q.view(G, nh, hd), P["kc"][li], P["vc"][li], P["ctx"], scale)
             x = ops.gemv(att, lw["wo"], residual=x, out_dtype=torch.float32)
             h = ops.rmsnorm(x, lw["ln2"], eps, dt)
             g = ops.gemv(h, lw["wgu"], act="silu", glu=True)
@@ -204,17 +213,16 @@ class LlamaForCausalLM:
         ops.add_i32(P["ctx"], 1)
         return x
 
-    def forward_embeds(self, inputs_embeds, need_logits=True):
-        """inputs_embeds: fp32 [T, H] on the GPU, appended at the current cache position.
+    def forward_embeds(self, inputs_embeds, need_logits=True, seq=0):
+        """inputs_embeds: fp32 [T, H] on the GPU, appended to sequence `seq` at its current cache position.
         Returns (logits fp32 [Vpad] of the LAST position or None, final-norm hidden states fp32 [T, H])."""
         P = self._pack()
         x = inputs_embeds.to(device=self.device, dtype=torch.float32).contiguous()
         T = x.shape[0]
-        if T == 1:
+        if T == 1 and self.G == 1:
             x = self._layers_single(x)
         else:
-            # ctx counts keys visible to the LAST token of the chunk; _layers_multi advances both by T
-            x = self._layers_multi(x, T)
+            x = self._layers_multi(x, T, seq)
         hn = ops.rmsnorm(x, P["norm"], self.config.rms_norm_eps, torch.float32)      # :595
         logits = None
         if need_logits:
@@ -224,43 +232,45 @@ class LlamaForCausalLM:
     # reference-style entry (prefill + cached steps through inputs_embeds / input_ids), batch 1
     def forward(self, input_ids=None, inputs_embeds=None, past_key_values=None, use_cache=True,
                 output_hidden_states=False, return_dict=True, **_):
-        """Subset of the reference forward (:643-746) that the inference path uses: batch 1; the KV cache lives in
-        the module (``past_key_values=None`` resets it, anything else continues). Returns a dict with ``logits``
-        [1, 1, V] (last position only), ``hidden_states`` = (final-norm states [1, T, H],) and ``past_key_values``
-        = a token standing for the internal cache."""
+        """Subset of the reference forward (:643-746) that the inference path uses: batch 1 (sequence 0); the KV cache
+        lives in the module (``past_key_values=None`` resets it, anything else continues). Returns a dict with
+        ``logits`` [1, 1, V] (last position only), ``hidden_states`` = (final-norm states [1, T, H],) and
+        ``past_key_values`` = a token standing for the internal cache."""
         self._pack()
         if past_key_values is None:
-            self.reset()
+            self.reset(0)
         if inputs_embeds is None:
             inputs_embeds = self.get_input_embeddings()(input_ids)
         x = inputs_embeds.reshape(-1, self.H)
-        logits, hn = self.forward_embeds(x)
+        logits, hn = self.forward_embeds(x, seq=0)
         out = {"logits": logits[: self.V].view(1, 1, -1), "past_key_values": "internal-cache",
                "hidden_states": (hn.view(1, -1, self.H),) if output_hidden_states else None}
         return out
 
     __call__ = forward
 
-    # ---- device-resident greedy decode step ---------------------------------------------------------------------
+    # ---- device-resident greedy decode step (all sequences in lock step) -----------------------------------------------
     def _decode_step_body(self, img_ids_dev, out_ids, hid_buf):
-        """cur → embedding → 40 layers → final norm → lm_head → logits rule + argmax → cur. Also records the
-        post-norm hidden state of the INPUT token at hid_buf[step] (what seed_x.py:196 collects) and the new id at
-        out_ids[step]; then step += 1. Everything stays on the device."""
+        """cur[G] → embedding → 40 layers → final norm → lm_head → logits rule + argmax → cur[G]. Records the post-norm
+        hidden state of each INPUT token at hid_buf[g, step[g]] (what seed_x.py:196 collects) and the new id at
+        out_ids[g, step[g]]; then step += 1. Everything stays on the device."""
         P = self._P
-        x = ops.embedding(P["cur"], P["embed"])                                        # [1, H] fp32
+        x = ops.embedding(P["cur"], P["embed"])                                        # [G, H] fp32
         x = self._layers_single(x)
         hn = ops.rmsnorm(x, P["norm"], self.config.rms_norm_eps, torch.float32)
-        ops.scatter_rows(hn, P["step"], hid_buf)
-        logits = ops.gemv(ops.cast(hn, self.dtype), P["lm_head"], out_dtype=torch.float32)
-        ops.greedy_next(logits, self.V, img_ids_dev, P["cur"], P["cur"], out_ids, P["step"])
+        ops.scatter_rows_step(hn, P["step"], hid_buf)
+        logits = ops.gemv(ops.cast(hn, self.dtype), P["lm_head"], out_dtype=torch.float32)   # [G, Vpad]
+        ops.greedy_next_b(logits, self.V, img_ids_dev, P["cur"], out_ids, P["step"])
         ops.add_i32(P["step"], 1)
 
     def decode_step(self, img_ids_dev, out_ids, hid_buf, use_graph=True):
+        """out_ids: int32 [G, rows]; hid_buf: fp32 [G, rows, H]."""
         self._pack()
+        assert out_ids.shape[0] == self.G and hid_buf.shape[0] == self.G and hid_buf.shape[1] == out_ids.shape[1]
         if not use_graph:
             self._decode_step_body(img_ids_dev, out_ids, hid_buf)
             return
-        key = (img_ids_dev.data_ptr(), out_ids.data_ptr(), hid_buf.data_ptr())
+        key = (img_ids_dev.data_ptr(), out_ids.data_ptr(), hid_buf.data_ptr(), tuple(out_ids.shape))
         if self._graph is None or self._graph[0] != key:
             # warm-up on a side stream (allocator / lazy module load), then capture one token step
             P = self._P

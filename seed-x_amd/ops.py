@@ -392,7 +392,45 @@ def silu_cast(x, dtype):
 
 
 def add_i32(p, delta):
-    check(_lib.load().sx_add_i32(_p(p), int(delta), _stream()), "sx_add_i32")
+    check(_lib.load().sx_add_i32_n(_p(p), int(delta), p.numel(), _stream()), "sx_add_i32_n")
+
+
+# ---- lock-step batched decode (G sequences, one token each) ---------------------------------------------------------
+def rope_kv_append_b(qkv, kcache, vcache, cos_tab, sin_tab, pos_dev, G, T, H, D):
+    """qkv [G*T, 3HD]; kcache/vcache [G, H, Tmax, D]; pos_dev int32 [G]."""
+    lib = _lib.load()
+    assert qkv.is_contiguous() and qkv.shape == (G * T, 3 * H * D) and kcache.is_contiguous() and kcache.shape[0] == G
+    check(lib.sx_rope_kv_append_b(_p(qkv), _p(kcache), _p(vcache), _p(cos_tab), _p(sin_tab), _p(pos_dev), G, T, H, D,
+                                  kcache.shape[2], kcache.stride(0), _DT[qkv.dtype], _stream()), "sx_rope_kv_append_b")
+
+
+def attn_decode_b(q, kcache, vcache, ctx_dev, scale, nsplit=8):
+    """q [G, H, D]; caches [G, H, Tmax, D]; ctx_dev int32 [G]. Returns [G, H*D]."""
+    lib = _lib.load()
+    G, H, D = q.shape
+    out = torch.empty((G, H * D), dtype=q.dtype, device=q.device)
+    scratch = torch.empty((G, H, nsplit, D + 2), dtype=torch.float32, device=q.device)
+    check(lib.sx_attn_decode_b(_p(q), _p(kcache), _p(vcache), _p(out), _p(scratch), _p(ctx_dev), G, H, D, kcache.shape[2],
+                               kcache.stride(0), nsplit, float(scale), _DT[q.dtype], _stream()), "sx_attn_decode_b")
+    return out
+
+
+def greedy_next_b(logits, vocab, img_ids_dev, cur_dev, out_ids, step_dev):
+    """logits fp32 [G, ld]; cur_dev int32 [G] (in: previous id, out: next id); out_ids int32 [G, ld_out]; step_dev [G]."""
+    lib = _lib.load()
+    G = logits.shape[0]
+    assert logits.dtype == torch.float32 and logits.stride(1) == 1
+    check(lib.sx_greedy_next_b(_p(logits), logits.stride(0), vocab, _p(img_ids_dev), img_ids_dev.numel(), _p(cur_dev),
+                               _p(cur_dev), _p(out_ids), out_ids.stride(0) if out_ids is not None else 0, _p(step_dev), G,
+                               _stream()), "sx_greedy_next_b")
+
+
+def scatter_rows_step(src, step_dev, dst):
+    """dst [G, rows, dim] fp32; dst[g, step[g]] = src[g]."""
+    lib = _lib.load()
+    G, rows, dim = dst.shape
+    assert src.shape == (G, dim) and src.is_contiguous() and dst.is_contiguous()
+    check(lib.sx_scatter_rows_step(_p(src), _p(step_dev), _p(dst), G, dim, rows, _stream()), "sx_scatter_rows_step")
 
 
 def cfg_euler_step(eps, latents, scaled_next, sigmas_dev, step_dev, nb, C_lat, ld_scaled, gs, igs, mode):

@@ -2,10 +2,11 @@
 
 Same constructor / ``from_pretrained`` / ``generate`` signature and return dict as the reference. The greedy loop
 of HF ``GenerationMixin.generate`` [ext, transformers 4.30.2] plus ``AutoImageTokenGenerationProcessor``
-(generation.py:9-31) is restated as a device-resident loop: one hipGraph replay per token, a single 4-byte
+(generation.py:9-31) is restated as a device-resident loop: one hipGraph replay per token, a single small
 read-back per token for the EOS / ``<img>`` test (the reference performs ≥45 device→host syncs per token).
 When ``<img>`` is emitted the 64 forced ``<img_i>`` tokens are run as ONE 65-token causal chunk on the MFMA path
 (identical math, 64× the arithmetic intensity).
+``generate_batch`` runs G independent requests in lock step (one weight stream from HBM per token step for all G).
 """
 import torch
 
@@ -61,33 +62,27 @@ class ContinuousLVLM:
         return self
 
     # ------------------------------------------------------------------------------------------------------------
-    @torch.no_grad()
-    def generate(self, tokenizer, prompt=None, input_ids=None, image_embeds=None, embeds_cmp_mask=None,
-                 ids_cmp_mask=None, logits_processor=None, num_img_gen_tokens=64, temperature=0.7, num_beams=1,
-                 max_new_tokens=120, top_p=0.5, dtype=torch.float16, device='cuda', patch_positions=None,
-                 eos_token_id="auto", force_image_at=None):
-        """Greedy (do_sample=False, num_beams=1 — temperature/top_p are inert in the reference too, seed_x.py:175-189).
-        ``eos_token_id``: "auto" → tokenizer.eos_token_id; None disables the EOS stop (fixed-length benchmarking)."""
-        assert logits_processor is None, "the AutoImageTokenGenerationProcessor rule is fused on the device"
-        assert num_beams == 1
+    def _prompt_embeds(self, tokenizer, req):
+        """embed_tokens + input resampler + patch-position term + scatter (seed_x.py:154-173) for ONE request."""
         llm = self.llm
-        dev = llm.device
-        if prompt is not None:
-            input_ids = tokenizer(prompt, return_tensors="pt").input_ids
+        dev, H = llm.device, llm.H
+        input_ids = req.get("input_ids")
+        if req.get("prompt") is not None:
+            input_ids = tokenizer(req["prompt"], return_tensors="pt").input_ids
         if isinstance(input_ids, torch.Tensor):
             input_ids = input_ids.reshape(-1).tolist()
         else:
             input_ids = list(input_ids[0]) if len(input_ids) and isinstance(input_ids[0], (list, tuple)) else list(input_ids)
-        T = len(input_ids)
-        H = llm.H
         ids_dev = torch.tensor(input_ids, dtype=torch.int32, device=dev)
         x = ops.embedding(ids_dev, llm._pack()["embed"])                                    # [T, H] fp32 (:158)
-
+        image_embeds = req.get("image_embeds")
         if image_embeds is not None:
+            embeds_cmp_mask, ids_cmp_mask = req.get("embeds_cmp_mask"), req.get("ids_cmp_mask")
             assert embeds_cmp_mask is not None and ids_cmp_mask is not None
             lm = self.input_resampler(image_embeds.to(dev))                                 # [n, nq, H] fp32 (:164)
             n, nq, _ = lm.shape
             if self.add_patch_pos:                                                          # :165-171
+                patch_positions = req.get("patch_positions")
                 assert patch_positions is not None
                 pp = patch_positions.detach().float().cpu()
                 rel = torch.mm(torch.cat([pp, 1 - pp], dim=-1) / 2, self.patch_pos_embed)   # host glue, [n, H]
@@ -98,71 +93,120 @@ class ContinuousLVLM:
             assert rows.numel() == len(sel) * nq, "ids_cmp_mask / embeds_cmp_mask mismatch"
             src = lm if len(sel) == n else lm[torch.tensor(sel, device=dev)]
             ops.scatter_rows(src.reshape(-1, H).contiguous(), rows.to(dev), x)              # :173
+        return input_ids, x
 
+    @torch.no_grad()
+    def generate_batch(self, tokenizer, requests, num_img_gen_tokens=64, max_new_tokens=120, eos_token_id="auto",
+                       force_image_at=None):
+        """G = len(requests) = llm.G independent requests decoded in lock step. Each request is a dict with the
+        ``generate`` keyword arguments (input_ids | prompt, image_embeds, embeds_cmp_mask, ids_cmp_mask,
+        patch_positions). Returns one reference-style result dict per request."""
+        llm = self.llm
+        dev, H, G = llm.device, llm.H, len(requests)
+        P = llm._pack()
+        assert G == llm.G, f"the LLM was built for max_batch={llm.G} lock-step sequences, got {G} requests"
         img_ids = tokenizer.encode(''.join([BOI_TOKEN] + [IMG_TOKEN.format(i) for i in range(num_img_gen_tokens)]
                                            + [EOI_TOKEN]), add_special_tokens=False)        # generation.py:15-17
         boi_id, eoi_id = img_ids[0], img_ids[-1]
         if eos_token_id == "auto":
             eos_token_id = getattr(tokenizer, "eos_token_id", None)
         img_ids_dev = torch.tensor(img_ids, dtype=torch.int32, device=dev)
-        out_ids = torch.full((max_new_tokens + 2,), -1, dtype=torch.int32, device=dev)
-        hid = torch.zeros((max_new_tokens + 2, H), dtype=torch.float32, device=dev)        # row k = state at input new[k-1]
+        nchunk = num_img_gen_tokens + 1
+        rows = 2 * max_new_tokens + nchunk + 8          # finished sequences keep stepping until the slowest one ends
+        out_ids = torch.full((G, rows), -1, dtype=torch.int32, device=dev)
+        hid = torch.zeros((G, rows, H), dtype=torch.float32, device=dev)                    # row k = state at input new[k-1]
 
-        # ---- prefill + first token --------------------------------------------------------------------------
+        # ---- prefill every request, first token -----------------------------------------------------------------
         llm.reset()
-        P = llm._P
-        logits, _ = llm.forward_embeds(x)
-        P["cur"].fill_(input_ids[-1])
-        ops.greedy_next(logits, llm.V, img_ids_dev, P["cur"], P["cur"], out_ids, P["step"])
+        logits = torch.empty((G, llm.Vpad), dtype=torch.float32, device=dev)
+        last_ids = []
+        for g, req in enumerate(requests):
+            input_ids, x = self._prompt_embeds(tokenizer, req)
+            assert len(input_ids) + rows <= llm.Tmax, "KV cache too small for prompt + max_new_tokens"
+            lg, _ = llm.forward_embeds(x, seq=g)
+            logits[g] = lg
+            last_ids.append(input_ids[-1])
+        P["cur"].copy_(torch.tensor(last_ids, dtype=torch.int32))
+        ops.greedy_next_b(logits, llm.V, img_ids_dev, P["cur"], out_ids, P["step"])
         ops.add_i32(P["step"], 1)
-        n_new = 1
-        cur = int(P["cur"].item())
+        n_new = [1] * G
+        cur = P["cur"].tolist()
 
-        def maybe_force(cur):
+        def force(g):
             # synthetic-weights benchmarking only: random-init weights never emit <img>, so the transcript is pinned by
             # overwriting generated token #force_image_at with <img> AFTER its full forward/lm_head/argmax has run
             # (no work is skipped). Never set with real checkpoints.
-            if force_image_at is not None and n_new - 1 == force_image_at:
-                P["cur"].fill_(boi_id)
-                out_ids[n_new - 1] = boi_id
-                return boi_id
-            return cur
-        cur = maybe_force(cur)
-        # ---- token loop -------------------------------------------------------------------------------------------
-        while n_new < max_new_tokens and not (eos_token_id is not None and cur == eos_token_id):
-            nchunk = num_img_gen_tokens + 1
-            if self.chunk_forced_image_tokens and cur == boi_id and n_new + nchunk <= max_new_tokens:
-                # inputs [<img>, <img_0> … <img_63>] as one causal chunk; outputs are forced (generation.py:23-26)
-                chunk = torch.tensor([boi_id] + img_ids[1:-1], dtype=torch.int32, device=dev)
-                xe = ops.embedding(chunk, P["embed"])
-                _, hn = llm.forward_embeds(xe, need_logits=False)
-                hid[n_new:n_new + nchunk] = hn                                               # plumbing copy
-                out_ids[n_new:n_new + nchunk] = torch.tensor(img_ids[1:], dtype=torch.int32, device=dev)
-                n_new += nchunk
-                P["step"].fill_(n_new)
-                P["cur"].fill_(eoi_id)
-                cur = eoi_id
-                continue
-            llm.decode_step(img_ids_dev, out_ids, hid, use_graph=self.use_graph)
-            n_new += 1
-            cur = maybe_force(int(P["cur"].item()))
+            if force_image_at is not None and n_new[g] - 1 == force_image_at:
+                P["cur"][g] = boi_id
+                out_ids[g, n_new[g] - 1] = boi_id
+                cur[g] = boi_id
 
-        generate_ids = out_ids[:n_new].cpu().long()
-        last_hidden = hid[1:n_new]                                                           # seed_x.py:196-197
-        eoi_indices = torch.where(generate_ids == eoi_id)[0].tolist()                        # :199
-        num_gen_imgs = len(eoi_indices)
-        text_mask = torch.ones_like(generate_ids, dtype=torch.bool)
-        has_img_output = num_gen_imgs > 0
-        img_gen_feat = None
-        if has_img_output:
-            feats = []
-            for e in eoi_indices:
-                feats.append(last_hidden[e - num_img_gen_tokens:e])                          # :204
-                text_mask[e - num_img_gen_tokens:e] = False
-            img_gen_feat = self.output_resampler(torch.stack(feats))                         # :209-210
-            img_gen_feat = ops.cast(img_gen_feat.contiguous(), self.dtype)
-        text_mask[generate_ids == boi_id] = False
-        text_ids = generate_ids[text_mask]
-        text = tokenizer.decode(text_ids, skip_special_tokens=False)                         # :214-216
-        return {'text': text, 'has_img_output': has_img_output, 'img_gen_feat': img_gen_feat,
-                'num_gen_imgs': num_gen_imgs, 'generate_ids': generate_ids, 'last_hidden_states': last_hidden}
+        def finished(g):
+            return n_new[g] >= max_new_tokens or (eos_token_id is not None and cur[g] == eos_token_id)
+        for g in range(G):
+            force(g)
+        done = [finished(g) for g in range(G)]
+        final_n = [n_new[g] if done[g] else None for g in range(G)]
+        # ---- token loop ---------------------------------------------------------------------------------------------
+        while not all(done):
+            for g in range(G):
+                if not done[g] and self.chunk_forced_image_tokens and cur[g] == boi_id and n_new[g] + nchunk <= max_new_tokens:
+                    # inputs [<img>, <img_0> … <img_63>] as one causal chunk; outputs are forced (generation.py:23-26)
+                    chunk = torch.tensor([boi_id] + img_ids[1:-1], dtype=torch.int32, device=dev)
+                    xe = ops.embedding(chunk, P["embed"])
+                    _, hn = llm.forward_embeds(xe, need_logits=False, seq=g)
+                    hid[g, n_new[g]:n_new[g] + nchunk] = hn                                  # plumbing copy
+                    out_ids[g, n_new[g]:n_new[g] + nchunk] = torch.tensor(img_ids[1:], dtype=torch.int32, device=dev)
+                    n_new[g] += nchunk
+                    P["step"][g] = n_new[g]
+                    P["cur"][g] = eoi_id
+                    cur[g] = eoi_id
+                    if finished(g):
+                        done[g], final_n[g] = True, n_new[g]
+            if all(done):
+                break
+            llm.decode_step(img_ids_dev, out_ids, hid, use_graph=self.use_graph)            # one token for every sequence
+            cur = P["cur"].tolist()                                                          # the only read-back per step
+            for g in range(G):
+                if done[g]:
+                    continue
+                n_new[g] += 1
+                force(g)
+                if finished(g):
+                    done[g], final_n[g] = True, n_new[g]
+
+        results = []
+        for g in range(G):
+            n = final_n[g]
+            generate_ids = out_ids[g, :n].cpu().long()
+            last_hidden = hid[g, 1:n]                                                        # seed_x.py:196-197
+            eoi_indices = torch.where(generate_ids == eoi_id)[0].tolist()                    # :199
+            text_mask = torch.ones_like(generate_ids, dtype=torch.bool)
+            img_gen_feat = None
+            if eoi_indices:
+                feats = []
+                for e in eoi_indices:
+                    feats.append(last_hidden[e - num_img_gen_tokens:e])                      # :204
+                    text_mask[e - num_img_gen_tokens:e] = False
+                img_gen_feat = self.output_resampler(torch.stack(feats))                     # :209-210
+                img_gen_feat = ops.cast(img_gen_feat.contiguous(), self.dtype)
+            text_mask[generate_ids == boi_id] = False
+            text = tokenizer.decode(generate_ids[text_mask], skip_special_tokens=False)      # :214-216
+            results.append({'text': text, 'has_img_output': len(eoi_indices) > 0, 'img_gen_feat': img_gen_feat,
+                            'num_gen_imgs': len(eoi_indices), 'generate_ids': generate_ids,
+                            'last_hidden_states': last_hidden})
+        return results
+
+    @torch.no_grad()
+    def generate(self, tokenizer, prompt=None, input_ids=None, image_embeds=None, embeds_cmp_mask=None,
+                 ids_cmp_mask=None, logits_processor=None, num_img_gen_tokens=64, temperature=0.7, num_beams=1,
+                 max_new_tokens=120, top_p=0.5, dtype=torch.float16, device='cuda', patch_positions=None,
+                 eos_token_id="auto", force_image_at=None):
+        """Reference signature (seed_x.py:130-145). Greedy (do_sample=False, num_beams=1 — temperature/top_p are inert in
+        the reference too, :175-189). ``eos_token_id``: "auto" → tokenizer.eos_token_id; None disables the EOS stop."""
+        assert logits_processor is None, "the AutoImageTokenGenerationProcessor rule is fused on the device"
+        assert num_beams == 1
+        assert self.llm.G == 1, "this LLM was built for lock-step batches: use generate_batch()"
+        req = dict(prompt=prompt, input_ids=input_ids, image_embeds=image_embeds, embeds_cmp_mask=embeds_cmp_mask,
+                   ids_cmp_mask=ids_cmp_mask, patch_positions=patch_positions)
+        return self.generate_batch(tokenizer, [req], num_img_gen_tokens, max_new_tokens, eos_token_id, force_image_at)[0]

@@ -165,13 +165,13 @@ def test_llm_prefill_logits_vs_oracle(dev, dtype):
         llm(inputs_embeds=x.to(dev))
         llm._P["cur"].fill_(7)
         llm._P["step"].fill_(1)
-        out_ids = torch.full((16,), -1, dtype=torch.int32, device=dev)
-        hid = torch.zeros((16, cfg["hidden_size"]), device=dev)
+        out_ids = torch.full((1, 16), -1, dtype=torch.int32, device=dev)
+        hid = torch.zeros((1, 16, cfg["hidden_size"]), device=dev)
         for _ in range(6):
             llm.decode_step(img_ids, out_ids, hid, use_graph=use_graph)
         res.append((out_ids.clone(), hid.clone()))
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
-    assert (res[0][0][1:7] >= 0).all()
+    assert (res[0][0][0, 1:7] >= 0).all()
 
 
 # ---------------------------------------------------------------------------------------------------------
