@@ -265,7 +265,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
     ap.add_argument("--unet-steps", type=int, default=50)
     ap.add_argument("--text-tokens", type=int, default=61)
-    ap.add_argument("--overlap", type=int, default=1,
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay (profiling aid)")
+    ap.add_argument("--overlap", type=int, default=0,
                     help="1: pipeline consecutive requests on two streams (LLM decode of request i+1 under the UNet of request i)")
     ap.add_argument("--batch", type=int, default=1, help="independent generations processed together per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -284,6 +285,9 @@ def main():
     with torch.no_grad():
         vit, agent, adapter = build_models(dev, dtype)
         inp = make_inputs(dev)
+        if a.no_graph:
+            agent.use_graph = False
+            adapter._loop.use_graph = False
         seeds = du.shard_seeds(ctx, a.steps)      # independent requests, round-robin over ranks
         pipe = Pipeline(vit, agent, adapter, tok, inp, a.unet_steps, a.text_tokens) if a.overlap else None
 

@@ -301,31 +301,33 @@ int launch_cfg(const GemmP& p0, int a_mode, hipStream_t st) {
   return SX_OK;
 }
 
-// tile menu: {BM, BN, relative per-tile efficiency, usable with glu}
-struct TileCfg { int bm, bn; double eff; bool glu_ok; };
-static const TileCfg kTiles[6] = {{128, 128, 1.00, true}, {128, 80, 0.88, false}, {64, 128, 0.85, true}, {64, 64, 0.65, true},
-                                  {256, 256, 1.0, true}, {256, 128, 1.0, true}};
+// tile menu + cost model. One launch runs ceil(tiles / slots) rounds over the chip (slots = 256 CUs x co-resident blocks) and
+// a round costs a + b*K microseconds (prologue/epilogue + per-k-tile time). The constants are a least-squares fit of the
+// MI355X sweep tools/bench_tile_model.py (profiles/r1_tile_model.jsonl): every tile config forced over the UNet linear and
+// conv shapes at CFG batch 2..16, the ViT-G and the Llama shapes. Picking argmin of the model is within 0.4 % (linear) /
+// 0.0 % (conv) of the per-shape best config on that sweep; the N = k*320 channel counts of the SDXL UNet are why the
+// 256x320 / 256x160 tiles exist (they split N without a ragged last tile and land on whole rounds of 256 tiles).
+struct TileCfg { int bm, bn; bool glu_ok; int slots; float a_lin, b_lin, a_conv, b_conv; };
+static const int kNumTiles = 7;
+static const TileCfg kTiles[kNumTiles] = {
+    {128, 128, true, 512, 9.50f, 0.00979f, 13.66f, 0.01376f},  {128, 80, false, 256, 3.99f, 0.00725f, 3.79f, 0.01106f},
+    {64, 128, true, 256, 1.70f, 0.00476f, 0.10f, 0.00568f},    {64, 64, true, 256, 0.58f, 0.00337f, 0.10f, 0.00360f},
+    {256, 256, true, 256, 13.61f, 0.01984f, 16.43f, 0.02363f}, {256, 320, false, 256, 20.69f, 0.02429f, 25.02f, 0.02848f},
+    {256, 160, false, 256, 9.60f, 0.01534f, 13.43f, 0.01882f}};
 
-// pick the tile that minimises (rounds over the 256 CUs) x (tile area / efficiency)
-// Rules fitted to the MI355X sweep in tools/bench_gemm_tiles.py (profiles/r1_gemm_tile_sweep.txt):
-//   >= 1.5 rounds of 128x128 tiles over the 256 CUs → 128x128 (2 co-resident blocks per CU hide the DMA latency)
-//   linear, N % 80 == 0 and one round of 128x80 tiles fills the chip (M=2048, N=1280 of the UNet) → 128x80
-//   few row tiles (M <= 192: LLM prefill / forced-token chunk) → 64x64 to maximise the tile count
-//   otherwise → 64x128 with the 3-deep ring
-inline int pick_tile(int M, int N, bool glu, bool conv, int force) {
-  if (force >= 0 && force < 6 && (!glu || kTiles[force].glu_ok)) return force;
-  auto tiles = [&](int c) { return (long)((M + kTiles[c].bm - 1) / kTiles[c].bm) * ((N + kTiles[c].bn - 1) / kTiles[c].bn); };
-  {
-    // 8-wave 256x256 tile (2 waves per SIMD, half the LDS / L2 traffic per FLOP): wins once it fills most of a round
-    const long t4 = tiles(4);
-    const double waste = (double)((t4 + 255) / 256) / ((double)t4 / 256.0);
-    if (!conv && t4 >= 200 && waste <= 1.35) return 4;
-    if (conv && ((t4 >= 150 && t4 <= 256) || (t4 > 256 && waste <= 1.15))) return 4;   // tools/bench_conv_b8.py
+inline int pick_tile(int M, int N, int K, bool glu, bool conv, int force) {
+  if (force >= 0 && force < kNumTiles && (!glu || kTiles[force].glu_ok)) return force;
+  int best = 2;
+  float best_t = 1e30f;
+  for (int c = 0; c < kNumTiles; ++c) {
+    const TileCfg& t = kTiles[c];
+    if (glu && !t.glu_ok) continue;
+    const long tiles = (long)((M + t.bm - 1) / t.bm) * ((N + t.bn - 1) / t.bn);
+    const long rounds = (tiles + t.slots - 1) / t.slots;
+    const float us = (float)rounds * (conv ? t.a_conv + t.b_conv * (float)K : t.a_lin + t.b_lin * (float)K);
+    if (us < best_t) { best_t = us; best = c; }
   }
-  if (tiles(0) >= (conv ? 256 : 384)) return 0;
-  if (!glu && !conv && N % 80 == 0 && tiles(1) <= 256 && tiles(1) >= 192) return 1;
-  if (M <= 192 && tiles(2) < 256) return 3;
-  return 2;
+  return best;
 }
 
 }  // namespace sxk_gemm
@@ -379,7 +381,7 @@ extern "C" int sx_gemm(const sx_gemm_args* a, void* stream) {
   p.a_bytes = (unsigned)a_bytes;
   p.w_bytes = (unsigned)w_bytes;
   hipStream_t st = (hipStream_t)stream;
-  const int cfg = pick_tile(a->M, a->N, a->glu != 0, a->a_mode == SX_A_CONV3X3, g_force_tile);
+  const int cfg = pick_tile(a->M, a->N, a->K, a->glu != 0, a->a_mode == SX_A_CONV3X3, g_force_tile);
 #define SX_GEMM_DISPATCH(TT)                                                  \
   switch (cfg) {                                                              \
     case 0: return launch_cfg<TT, 128, 128, 2, 2, 2>(p, a->a_mode, st);       \
@@ -387,7 +389,8 @@ extern "C" int sx_gemm(const sx_gemm_args* a, void* stream) {
     case 2: return launch_cfg<TT, 64, 128, 2, 2, 3>(p, a->a_mode, st);        \
     case 3: return launch_cfg<TT, 64, 64, 2, 2, 3>(p, a->a_mode, st);         \
     case 4: return launch_cfg<TT, 256, 256, 2, 4, 2>(p, a->a_mode, st);       \
-    default: return launch_cfg<TT, 256, 128, 4, 2, 2>(p, a->a_mode, st);      \
+    case 5: return launch_cfg<TT, 256, 320, 2, 4, 2>(p, a->a_mode, st);       \
+    default: return launch_cfg<TT, 256, 160, 4, 2, 2>(p, a->a_mode, st);      \
   }
   if (a->dtype == SX_BF16) { SX_GEMM_DISPATCH(BF16) } else { SX_GEMM_DISPATCH(F16) }
 #undef SX_GEMM_DISPATCH

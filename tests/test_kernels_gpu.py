@@ -45,7 +45,7 @@ def test_gemm_plain(dev, dtype, M, N, K):
     assert out16.dtype == dtype and relerr(out16, ref) < TOL[dtype]
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6])
 @pytest.mark.parametrize("M,N,K", [(300, 272, 192), (2048, 1280, 640), (128, 80, 64), (77, 336, 1024)])
 def test_gemm_every_tile_config(dev, tile, M, N, K):
     """Each tile shape / pipeline depth (128x128x2, 128x80x3, 64x128x3, 64x64x3) forced in turn, linear and conv."""
