@@ -209,6 +209,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const GemmP p) {
 #pragma unroll
     for (int i = 0; i < FN; ++i) bv[i] = *(const f32x4_t*)(p.bias + ncol[i]);
   }
+  const bool wide = p.out_dtype != SX_F32 && !p.glu && (p.ldc & 7) == 0 && (((size_t)p.C) & 15) == 0;
+  bool pair_ok[(FN + 1) / 2];
+#pragma unroll
+  for (int i = 0; i < (FN + 1) / 2; ++i) {
+    const int lim = p.n_valid < p.N ? p.n_valid : p.N;
+    pair_ok[i] = (2 * i + 1 < FN) && (n0 + wn * TN + i * 32 + 32 <= lim);  // wave-uniform: the whole 32-col pair is stored
+  }
 #pragma unroll
   for (int j = 0; j < FM; ++j) {
     const int m = m0 + wm * TM + j * 16 + (lane & 15);
@@ -233,8 +240,42 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const GemmP p) {
         rv[i] = *(const f32x4_t*)(rr + c);
       }
     }
+    if (wide) {
+      // 16-bit output, no GLU: two neighbouring n-fragments hold cols [nb, nb+16) and [nb+16, nb+32) as 4 per lane.
+      // v_permlane16_swap trades the odd 16-lane rows of fragment i with the even rows of fragment i+1, after which a
+      // lane owns 8 CONSECUTIVE columns → one 16-B store instead of two 8-B stores (the epilogue is store-issue bound)
+#pragma unroll
+      for (int i = 0; i + 1 < FN; i += 2) {
+        if (!pair_ok[i >> 1]) continue;
+        u32x2_t o[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          f32x4_t x = v[i + h];
+          if (p.act != SX_ACT_NONE) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x[r] = apply_act(x[r], p.act);
+          }
+          x += rv[i + h];
+          if (p.out_dtype == SX_BF16) {
+            o[h][0] = pack2<BF16>(x[0], x[1]);
+            o[h][1] = pack2<BF16>(x[2], x[3]);
+          } else {
+            o[h][0] = pack2<F16>(x[0], x[1]);
+            o[h][1] = pack2<F16>(x[2], x[3]);
+          }
+        }
+        const auto s0 = __builtin_amdgcn_permlane16_swap(o[0][0], o[1][0], false, false);
+        const auto s1 = __builtin_amdgcn_permlane16_swap(o[0][1], o[1][1], false, false);
+        if (!mok) continue;
+        const u32x4_t w4 = {s0[0], s1[0], s0[1], s1[1]};
+        const int q = lane >> 4;
+        const int col = n0 + wn * TN + i * 16 + (q & 1) * 16 + (q >> 1) * 8;
+        *(u32x4_t*)((unsigned short*)p.C + (size_t)m * p.ldc + col) = w4;
+      }
+    }
 #pragma unroll
     for (int i = 0; i < FN; ++i) {
+      if (wide && pair_ok[i >> 1]) continue;  // stored by the 16-B path above
       if (p.glu) {
         if (i & 1) continue;
         const f32x4_t g = v[(i + 1) < FN ? (i + 1) : i];
