@@ -49,7 +49,9 @@ class BenchTokenizer:
         return " ".join(str(int(i)) for i in ids)
 
 
-def build_models(dev, dtype):
+def build_models(dev, dtype, llm_comm=None, cfg_comm=None):
+    """llm_comm / cfg_comm: tensor-parallel Llama and CFG-parallel UNet communicators (tools/bench_tp_latency.py only;
+    the throughput bench leaves them None = one full replica per GPU)."""
     from seedx_amd import synthetic as syn
     from seedx_amd.detokenizer import EulerDiscreteScheduler, ResamplerXLV2, SDXLAdapter
     from seedx_amd.llama import LlamaForCausalLM
@@ -60,7 +62,7 @@ def build_models(dev, dtype):
     vit.load_state_dict(syn.vit_state_dict(syn.FULL_VIT, dev, dtype))
     vit.eval().to(dev, dtype=dtype)
     vit._pack()
-    llm = LlamaForCausalLM(dict(syn.FULL_LLM), max_cache_len=1024, max_batch=BATCH)
+    llm = LlamaForCausalLM(dict(syn.FULL_LLM), max_cache_len=1024, max_batch=BATCH, comm=llm_comm)
     llm.load_state_dict(syn.llama_state_dict(syn.FULL_LLM, dev, dtype))
     llm.to(dev, dtype)
     llm._pack()
@@ -75,6 +77,7 @@ def build_models(dev, dtype):
     res = ResamplerXLV2(normalize=False, **syn.FULL_XLV2)
     res.load_state_dict(syn.xlv2_state_dict(syn.FULL_XLV2, dev, dtype), prefix="resampler.")
     adapter = SDXLAdapter(unet, res, vit_down=True)
+    adapter.comm = cfg_comm
     adapter.init_pipe(vae=None, scheduler=EulerDiscreteScheduler(), visual_encoder=vit, image_transform=None,
                       discrete_model=None, dtype=dtype, device=dev)
     unet._pack()

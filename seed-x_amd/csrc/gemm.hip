@@ -32,6 +32,7 @@ struct GemmP {
   int M, N, K, ldc, ldr, n_valid, res_mod, bias2d_rows, out_dtype, act, glu;
   int Hin, Win, Cin, Hout, Wout, stride, upsample, ldb2;
   int tiles_m, tiles_n, xm, xn;   // tile grid and its XCD partition (xm x xn == 8, or 0 = linear remap)
+  int gm;                         // tile-rows per group of the in-XCD traversal
   unsigned a_bytes, w_bytes;
 };
 
@@ -75,8 +76,15 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const GemmP p) {
     const int ns = xc * p.tiles_n / p.xn, ne = (xc + 1) * p.tiles_n / p.xn;
     const int rm = me - ms, rn = ne - ns;
     if (idx >= rm * rn) return;  // padding block of an uneven split (exits before any barrier)
-    tile_m = ms + idx % rm;
-    tile_n = ns + idx / rm;
+    // grouped order inside the rectangle: the ~32 blocks resident on an XCD at one time form a gm x (32/gm) patch (not a
+    // 32 x 1 column), and consecutive rounds keep the same gm A tile-rows while sweeping n → per round the XCD's L2 pulls
+    // gm + 32/gm operand tile-rows instead of 33 (PMC: FETCH_SIZE of the GEGLU GEMM 8.8x → see profiles/r1_pmc_summary.json)
+    const int per_group = p.gm * rn;
+    const int g = idx / per_group, first = g * p.gm;
+    const int gsz = (rm - first) < p.gm ? (rm - first) : p.gm;
+    const int r = idx - g * per_group;
+    tile_m = ms + first + r % gsz;
+    tile_n = ns + r / gsz;
   }
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
@@ -305,6 +313,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const GemmP p) {
 #endif
 }
 
+static int g_gm = 0;      // tuning hook: tile-rows per traversal group (0 = default)
 static int g_xcd_2d = 1;  // 2-D XCD tile partition on/off (tuning hook)
 
 template <typename TT, int BM, int BN, int WM, int WN, int NSTAGE>
@@ -314,6 +323,7 @@ int launch_cfg(const GemmP& p0, int a_mode, hipStream_t st) {
   p.tiles_n = (p.N + BN - 1) / BN;
   int grid = p.tiles_m * p.tiles_n;
   p.xm = p.xn = 0;
+  p.gm = 1;
   if (grid >= 16 && g_xcd_2d) {
     // choose the 8-way split that minimises fabric traffic  A_bytes * xn + W_bytes * xm  among the least padded ones
     const double ab = (double)p.M * p.K, wb = (double)p.N * p.K;
@@ -326,6 +336,7 @@ int launch_cfg(const GemmP& p0, int a_mode, hipStream_t st) {
       if (cost < best) { best = cost; p.xm = xm; p.xn = xn; }
     }
     if (p.xm) grid = 8 * ((p.tiles_m + p.xm - 1) / p.xm) * ((p.tiles_n + p.xn - 1) / p.xn);
+    p.gm = g_gm > 0 ? g_gm : 8;   // tools/bench_gm.py: 8 is best or within 1 % on every multi-round shape
   }
   constexpr int NW = WM * WN;
   const size_t lds = (size_t)NSTAGE * (BM + (BN + 8 * NW - 1) / (8 * NW) * (8 * NW)) * 128;
@@ -377,6 +388,7 @@ using namespace sxk_gemm;
 static int g_force_tile = -1;
 extern "C" int sx_gemm_force_tile(int cfg) {  // tuning / test hook: -1 = automatic; 100/101 = 2-D XCD partition off/on
   if (cfg == 100 || cfg == 101) { sxk_gemm::g_xcd_2d = cfg - 100; return SX_OK; }
+  if (cfg >= 300 && cfg <= 364) { sxk_gemm::g_gm = cfg - 300; return SX_OK; }
   g_force_tile = cfg;
   return SX_OK;
 }

@@ -170,10 +170,16 @@ class EulerDiscreteScheduler:
 
 # ---------------------------------------------------------------------------------------------------------------
 class _DenoiseLoop:
-    """Device-resident CFG + Euler loop around UNet.forward_nhwc, one HIP graph replay per step."""
+    """Device-resident CFG + Euler loop around UNet.forward_nhwc, one HIP graph replay per step.
 
-    def __init__(self, unet, use_graph=True):
+    ``comm`` with world == nb (2 for t2i, 3 for edit): CFG-parallel — rank r runs guidance branch r of every generation
+    (UNet batch G instead of nb·G), the eps of all branches are all-gathered once per step (G·H·W·4 fp32 per rank) and
+    the CFG + Euler update is replicated, so every rank carries identical latents (parallel.py)."""
+
+    def __init__(self, unet, use_graph=True, comm=None):
+        from .parallel import Comm
         self.unet, self.use_graph = unet, use_graph
+        self.comm = comm or Comm()
         self._graph_key, self._graph, self._state = None, None, None
         self._ctx_static = None
 
@@ -208,6 +214,10 @@ class _DenoiseLoop:
             self._graph, self._graph_key = None, key
             self._ctx_static = None
         S = self._state
+        comm = self.comm
+        cfgp = comm.world > 1
+        assert not cfgp or comm.world == nb, f"CFG-parallel needs one rank per guidance branch ({nb}), got {comm.world}"
+        lo, hi = (comm.rank * G, (comm.rank + 1) * G) if cfgp else (0, NB)      # this rank's rows of the [branch][gen] batch
         S["ts"].copy_(ts_dev); S["sig"].copy_(sig_dev)
         S["ehs"].copy_(prompt_embeds.to(dev).float()); S["pooled"].copy_(pooled.to(dev).float())
         S["tid"].copy_(time_ids.to(dev).float())
@@ -219,7 +229,7 @@ class _DenoiseLoop:
             il = image_latents_nchw.to(dev, torch.float32)                       # [3·G,4,H,W] = [enc, enc, 0] (:544-546)
             S["scaled"][:, :, Cl:] = il.permute(0, 2, 3, 1).reshape(NB, HW, Cl)
         unet._ctx_key = None
-        ctx = unet.prepare_context(S["ehs"])                                      # step-invariant cross-attn K/V
+        ctx = unet.prepare_context(S["ehs"][lo:hi])                               # step-invariant cross-attn K/V
         if self._graph is not None and self._ctx_static is not None:
             for per_s, per_n in zip(self._ctx_static, ctx):                       # the graph holds these addresses
                 for (ka, va), (kb, vb) in zip(per_s, per_n):
@@ -230,13 +240,15 @@ class _DenoiseLoop:
             self._ctx_static = ctx
 
         def step_body():
-            temb = unet.time_embeddings(S["ts"], S["step"], S["pooled"], S["tid"], NB)
-            eps = unet.forward_nhwc(S["scaled"], temb, ctx, NB, H, W)
+            temb = unet.time_embeddings(S["ts"], S["step"], S["pooled"][lo:hi], S["tid"][lo:hi], hi - lo)
+            eps = unet.forward_nhwc(S["scaled"][lo:hi], temb, ctx, hi - lo, H, W)
+            if cfgp:
+                eps = comm.all_gather(eps).reshape(NB, HW, -1)                    # [nb, G, HW, C] → [branch][generation]
             ops.cfg_euler_step(eps, S["lat"], S["scaled"], S["sig"], S["step"], nb, Cl, cin, guidance_scale,
                                image_guidance_scale, mode)
             ops.add_i32(S["step"], 1)
 
-        if not self.use_graph:
+        if not self.use_graph or not comm.graph_safe:
             for _ in range(num_steps):
                 step_body()
         else:
@@ -308,7 +320,7 @@ class SDXLAdapter:
         self.discrete_model = discrete_model
         self.image_transform = image_transform
         self.to(self.device, self.dtype)
-        self._loop = _DenoiseLoop(self.unet, self.use_graph)
+        self._loop = _DenoiseLoop(self.unet, self.use_graph, comm=getattr(self, "comm", None))
 
     def _negative_embeds(self, image_size, pooled):
         """ViT features of an all-zero image: constant per model → cached (the reference recomputes a full ViT forward

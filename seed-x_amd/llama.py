@@ -12,12 +12,17 @@ logits, past_key_values, hidden_states with the LAST entry = post-final-norm sta
   * logits are only produced for the last position (the greedy loop never reads the others)
   * ``max_batch`` > 1: G independent sequences (separate KV caches / positions) decode in lock step, so the 25.7 GB of
     weights are streamed from HBM once per step for all G tokens (the reference is batch 1 only, seed_x.py:191)
+  * ``comm`` with world > 1: Megatron tensor parallelism (parallel.py) — this rank owns nh/tp heads (their q/k/v rows, KV
+    cache and o_proj columns), I/tp FFN rows (gate/up rows, down_proj columns) and Vpad/tp lm_head rows; the fp32
+    residual stream is all-reduced after o_proj and down_proj (rank 0's GEMM epilogue adds the residual), the logits are
+    all-gathered in front of the replicated greedy rule, so every rank holds identical tokens and loop state
 """
 import math
 
 import torch
 
 from . import ops
+from .parallel import Comm, llama_tp_shard
 
 
 def glu_pack_rows(lin, gate):
@@ -49,13 +54,18 @@ class _Embedding:
 
 
 class LlamaForCausalLM:
-    def __init__(self, config, max_cache_len=None, max_batch=1):
+    def __init__(self, config, max_cache_len=None, max_batch=1, comm=None):
         self.config = config if not isinstance(config, dict) else LlamaConfigLite(**config)
         c = self.config
         self.H, self.nh, self.L = c.hidden_size, c.num_attention_heads, c.num_hidden_layers
         self.hd = self.H // self.nh
         self.I, self.V = c.intermediate_size, c.vocab_size
-        self.Vpad = (self.V + 63) // 64 * 64       # 32330 → 32384: lm_head rows padded with zeros
+        self.comm = comm or Comm()
+        tp = self.tp = self.comm.world
+        self.Vpad = (self.V + 64 * tp - 1) // (64 * tp) * (64 * tp)   # 32330 → 32384: lm_head rows padded with zeros
+        assert self.nh % tp == 0 and self.I % (16 * tp) == 0, f"tp={tp} does not divide heads {self.nh} / FFN {self.I}"
+        self.nh_l, self.I_l, self.V_l = self.nh // tp, self.I // tp, self.Vpad // tp
+        self.H_l = self.nh_l * self.hd
         self.Tmax = max_cache_len or c.max_position_embeddings
         self.G = int(max_batch)
         assert 1 <= self.G <= 8, "lock-step batch is limited to 8 sequences (sx_gemv rows)"
@@ -131,22 +141,25 @@ class LlamaForCausalLM:
         f32 = lambda t: t.detach().to(dev, torch.float32).contiguous()
         w16 = lambda t: t.detach().to(dev, dt).contiguous()
         P = {"embed": w16(sd["model.embed_tokens.weight"]), "norm": f32(sd["model.norm.weight"]), "layers": []}
-        lm = torch.zeros(self.Vpad, self.H, dtype=dt, device=dev)
-        lm[:self.V] = sd["lm_head.weight"].detach().to(dev, dt)
+        r, tp = self.comm.rank, self.tp
+        v0, v1 = r * self.V_l, min((r + 1) * self.V_l, self.V)          # this rank's vocab rows (tail rows stay zero)
+        lm = torch.zeros(self.V_l, self.H, dtype=dt, device=dev)
+        if v1 > v0:
+            lm[:v1 - v0] = sd["lm_head.weight"][v0:v1].detach().to(dev, dt)
         P["lm_head"] = lm
         for i in range(self.L):
             p = f"model.layers.{i}."
-            qkv = torch.cat([sd[p + f"self_attn.{n}.weight"].detach() for n in ("q_proj", "k_proj", "v_proj")], dim=0)
-            gu = glu_pack_rows(sd[p + "mlp.up_proj.weight"].detach().to(dev, dt), sd[p + "mlp.gate_proj.weight"].detach().to(dev, dt))
+            sh = llama_tp_shard(sd, p, r, tp, self.nh, self.hd)
+            qkv = torch.cat([sh["q"].detach(), sh["k"].detach(), sh["v"].detach()], dim=0)
+            gu = glu_pack_rows(sh["up"].detach().to(dev, dt), sh["gate"].detach().to(dev, dt))
             P["layers"].append(dict(
                 ln1=f32(sd[p + "input_layernorm.weight"]), ln2=f32(sd[p + "post_attention_layernorm.weight"]),
-                wqkv=w16(qkv), wo=w16(sd[p + "self_attn.o_proj.weight"]), wgu=gu,
-                wd=w16(sd[p + "mlp.down_proj.weight"])))
+                wqkv=w16(qkv), wo=w16(sh["o"]), wgu=gu, wd=w16(sh["down"])))
         inv = 1.0 / (self.config.rope_base ** (torch.arange(0, self.hd, 2).float() / self.hd))
         fr = torch.outer(torch.arange(self.Tmax).float(), inv)           # [Tmax, hd/2] fp32 (:97-113)
         P["cos"], P["sin"] = fr.cos().to(dev).contiguous(), fr.sin().to(dev).contiguous()
         G = self.G
-        P["kc"] = torch.zeros((self.L, G, self.nh, self.Tmax, self.hd), dtype=dt, device=dev)
+        P["kc"] = torch.zeros((self.L, G, self.nh_l, self.Tmax, self.hd), dtype=dt, device=dev)   # this rank's heads
         P["vc"] = torch.zeros_like(P["kc"])
         # device-resident loop state, one entry per sequence
         P["pos"] = torch.zeros(G, dtype=torch.int32, device=dev)         # position of the next input token
@@ -169,7 +182,8 @@ class LlamaForCausalLM:
     def _layers_multi(self, x, T, seq):
         """T tokens of sequence `seq` at positions pos..pos+T-1 (prefill or a forced-token chunk): MFMA GEMMs + causal
         flash attention over that sequence's cache. x: fp32 [T, H] residual stream. Returns the final residual stream."""
-        P, dt, H, nh, hd = self._P, self.dtype, self.H, self.nh, self.hd
+        P, dt, H, nh, hd = self._P, self.dtype, self.H_l, self.nh_l, self.hd     # local heads under tensor parallelism
+        comm, lead = self.comm, self.comm.rank == 0
         pos_v, ctx_v = P["pos"][seq:seq + 1], P["ctx"][seq:seq + 1]
         pos0 = int(pos_v.item())
         Tk = pos0 + T
@@ -185,10 +199,10 @@ class LlamaForCausalLM:
             k4 = kc[:, :Tk].permute(1, 0, 2).unsqueeze(0)                              # [1, Tk, nh, hd] view of the cache
             v4 = vc[:, :Tk].permute(1, 0, 2).unsqueeze(0)
             att = ops.attention(q4, k4, v4, scale, causal=True)                       # [1, T, H]
-            x = ops.gemm(att.view(T, H), lw["wo"], residual=x, out_dtype=torch.float32)
+            x = comm.all_reduce(ops.gemm(att.view(T, H), lw["wo"], residual=x if lead else None, out_dtype=torch.float32))
             h = ops.rmsnorm(x, lw["ln2"], eps, dt)
-            g = ops.gemm(h, lw["wgu"], act="silu", glu=True)                          # silu(gate) * up, [T, I]
-            x = ops.gemm(g, lw["wd"], residual=x, out_dtype=torch.float32)
+            g = ops.gemm(h, lw["wgu"], act="silu", glu=True)                          # silu(gate) * up, [T, I/tp]
+            x = comm.all_reduce(ops.gemm(g, lw["wd"], residual=x if lead else None, out_dtype=torch.float32))
         ops.add_i32(pos_v, T)
         ops.add_i32(ctx_v, T)
         return x
@@ -196,7 +210,8 @@ class LlamaForCausalLM:
     def _layers_single(self, x):
         """One token of EVERY sequence (x: fp32 [G, H]) at the device-resident positions: weight-streaming GEMVs with
         M = G rows + split-KV decode attention per sequence. No host reads → graph-capturable."""
-        P, dt, H, nh, hd, G = self._P, self.dtype, self.H, self.nh, self.hd, self.G
+        P, dt, H, nh, hd, G = self._P, self.dtype, self.H_l, self.nh_l, self.hd, self.G
+        comm, lead = self.comm, self.comm.rank == 0
         eps = self.config.rms_norm_eps
         scale = 1.0 / math.sqrt(hd)
         for li, lw in enumerate(P["layers"]):
@@ -205,10 +220,10 @@ class LlamaForCausalLM:
             ops.rope_kv_append_b(qkv, P["kc"][li], P["vc"][li], P["cos"], P["sin"], P["pos"], G, 1, nh, hd)
             q = qkv[:, :H] if G == 1 else qkv[:, :H].contiguous()                    # [G, H] (plumbing copy for G > 1)
             att = ops.attn_decode_b(q.view(G, nh, hd), P["kc"][li], P["vc"][li], P["ctx"], scale)
-            x = ops.gemv(att, lw["wo"], residual=x, out_dtype=torch.float32)
+            x = comm.all_reduce(ops.gemv(att, lw["wo"], residual=x if lead else None, out_dtype=torch.float32))
             h = ops.rmsnorm(x, lw["ln2"], eps, dt)
             g = ops.gemv(h, lw["wgu"], act="silu", glu=True)
-            x = ops.gemv(g, lw["wd"], residual=x, out_dtype=torch.float32)
+            x = comm.all_reduce(ops.gemv(g, lw["wd"], residual=x if lead else None, out_dtype=torch.float32))
         ops.add_i32(P["pos"], 1)
         ops.add_i32(P["ctx"], 1)
         return x
@@ -227,6 +242,8 @@ class LlamaForCausalLM:
         logits = None
         if need_logits:
             logits = ops.linear(ops.cast(hn[-1:].contiguous(), self.dtype), P["lm_head"], out_dtype=torch.float32)[0]
+            if self.tp > 1:
+                logits = self.comm.all_gather(logits).reshape(-1)                     # [tp, V/tp] → [Vpad], vocab order
         return logits, hn
 
     # reference-style entry (prefill + cached steps through inputs_embeds / input_ids), batch 1
@@ -259,7 +276,9 @@ class LlamaForCausalLM:
         x = self._layers_single(x)
         hn = ops.rmsnorm(x, P["norm"], self.config.rms_norm_eps, torch.float32)
         ops.scatter_rows_step(hn, P["step"], hid_buf)
-        logits = ops.gemv(ops.cast(hn, self.dtype), P["lm_head"], out_dtype=torch.float32)   # [G, Vpad]
+        logits = ops.gemv(ops.cast(hn, self.dtype), P["lm_head"], out_dtype=torch.float32)   # [G, Vpad / tp]
+        if self.tp > 1:
+            logits = self.comm.all_gather(logits).permute(1, 0, 2).reshape(self.G, self.Vpad).contiguous()
         ops.greedy_next_b(logits, self.V, img_ids_dev, P["cur"], out_ids, P["step"])
         ops.add_i32(P["step"], 1)
 
@@ -267,7 +286,7 @@ class LlamaForCausalLM:
         """out_ids: int32 [G, rows]; hid_buf: fp32 [G, rows, H]."""
         self._pack()
         assert out_ids.shape[0] == self.G and hid_buf.shape[0] == self.G and hid_buf.shape[1] == out_ids.shape[1]
-        if not use_graph:
+        if not use_graph or not self.comm.graph_safe:
             self._decode_step_body(img_ids_dev, out_ids, hid_buf)
             return
         key = (img_ids_dev.data_ptr(), out_ids.data_ptr(), hid_buf.data_ptr(), tuple(out_ids.shape))

@@ -1,0 +1,154 @@
+"""Tensor-parallel plumbing for the latency-oriented multi-GPU mode (second form).
+
+Throughput mode needs none of this: generations are independent, so `bench.py` runs one replica per GPU with no
+data-path collective. The classes here serve the OTHER sharding the north-star names — one generation
+spread over several GPUs of a node:
+
+  * Llama decoder, Megatron layout: q/k/v/gate/up column-parallel (heads / FFN rows split), o/down row-parallel, ONE
+    all-reduce of the fp32 residual stream after each row-parallel GEMM (2 per layer), lm_head vocab-parallel with an
+    all-gather of the [G, V/tp] logits in front of the (replicated, deterministic) greedy rule.
+  * SDXL UNet, CFG-parallel: the nb guidance branches of one denoise step run on nb ranks, one all-gather of the
+    [G, H·W, 4] eps per step (256 KB at 1024 px) in front of the replicated CFG + Euler update.
+
+`Comm` is the only thing the model code sees. `TorchDistComm` maps it to torch.distributed (backend "nccl" = RCCL over
+xGMI on the GPU box, "gloo" in the CPU tests). `ThreadComm` runs `world` virtual ranks as threads of ONE process on ONE
+GPU — the single-GPU box the kernels are validated on cannot host a real multi-rank RCCL group, and the sharding
+arithmetic (which rows / columns / heads each rank owns, where the reductions sit) is what has to be proven.
+"""
+import threading
+
+import torch
+
+
+class Comm:
+    """Single-rank communicator: every collective is the identity."""
+    rank, world = 0, 1
+    graph_safe = True     # collectives may be captured into a HIP graph
+
+    def all_reduce(self, t):
+        return t
+
+    def all_gather(self, t):
+        """t: [...] → [world, ...] (rank-major)."""
+        return t.unsqueeze(0)
+
+    def barrier(self):
+        pass
+
+
+class TorchDistComm(Comm):
+    """torch.distributed process group (RCCL on GPUs, gloo on CPU). Collectives are enqueued by c10d on its own stream
+    and ordered against the caller's current stream by events; the model code needs no explicit synchronisation."""
+    graph_safe = False    # not validated under HIP-graph capture on this pool → TP decode runs eager launches
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self._dist, self.group = dist, group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+
+    def all_reduce(self, t):
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self.group)
+        return t
+
+    def all_gather(self, t):
+        out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        if t.is_cuda:
+            self._dist.all_gather_into_tensor(out, t.contiguous(), group=self.group)
+        else:                                          # gloo: list form
+            parts = [torch.empty_like(t) for _ in range(self.world)]
+            self._dist.all_gather(parts, t.contiguous(), group=self.group)
+            out = torch.stack(parts, dim=0)
+        return out
+
+    def barrier(self):
+        self._dist.barrier(group=self.group)
+
+
+class _ThreadShared:
+    def __init__(self, world):
+        self.world = world
+        self.bufs = [None] * world
+        self.barrier = threading.Barrier(world)
+
+
+class ThreadComm(Comm):
+    """`world` virtual ranks = threads of one process sharing one GPU (validation only; see module docstring)."""
+    graph_safe = False
+
+    def __init__(self, shared, rank):
+        self._sh, self.rank, self.world = shared, rank, shared.world
+
+    @staticmethod
+    def make(world):
+        sh = _ThreadShared(world)
+        return [ThreadComm(sh, r) for r in range(world)]
+
+    def _exchange(self, t):
+        sh = self._sh
+        sh.bufs[self.rank] = t
+        if t.is_cuda:
+            torch.cuda.synchronize()
+        sh.barrier.wait()
+        parts = [b.clone() for b in sh.bufs]
+        if t.is_cuda:
+            torch.cuda.synchronize()
+        sh.barrier.wait()                 # everyone has read everyone's buffer → safe to overwrite in place
+        return parts
+
+    def all_reduce(self, t):
+        parts = self._exchange(t)
+        acc = parts[0]
+        for q in parts[1:]:
+            acc = acc + q                 # same order on every rank → bit-identical results
+        t.copy_(acc)
+        return t
+
+    def all_gather(self, t):
+        return torch.stack(self._exchange(t.contiguous()), dim=0)
+
+    def barrier(self):
+        self._sh.barrier.wait()
+
+
+def run_virtual_ranks(world, fn):
+    """Run fn(comm) on `world` ThreadComm ranks; returns the per-rank results (re-raises the first failure)."""
+    comms = ThreadComm.make(world)
+    out, err = [None] * world, [None] * world
+
+    def work(r):
+        try:
+            out[r] = fn(comms[r])
+        except BaseException as e:  # noqa: BLE001 — surfaced below; abort the barrier so the peers do not hang
+            err[r] = e
+            comms[r]._sh.barrier.abort()
+
+    ts = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    for e in err:
+        if e is not None and not isinstance(e, threading.BrokenBarrierError):
+            raise e
+    for e in err:
+        if e is not None:
+            raise e
+    return out
+
+
+# ---- Megatron sharding of the reference Llama state dict (pure tensor slicing; CPU-testable) ------------------------------
+def llama_tp_shard(sd, layer_prefix, rank, tp, nh, hd):
+    """Rank `rank`'s slices of one decoder layer. Column-parallel: q/k/v rows of heads [rank·nh/tp, (rank+1)·nh/tp),
+    gate/up rows [rank·I/tp, …); row-parallel: the matching COLUMNS of o_proj / down_proj. Σ_r o_r·att_r = o·att."""
+    assert nh % tp == 0
+    hl = nh // tp * hd
+    hs = slice(rank * hl, (rank + 1) * hl)
+    p = layer_prefix
+    I = sd[p + "mlp.gate_proj.weight"].shape[0]
+    assert I % (16 * tp) == 0, "FFN rows per rank must keep the 16-row GLU packing"
+    il = I // tp
+    isl = slice(rank * il, (rank + 1) * il)
+    return {"q": sd[p + "self_attn.q_proj.weight"][hs], "k": sd[p + "self_attn.k_proj.weight"][hs],
+            "v": sd[p + "self_attn.v_proj.weight"][hs], "o": sd[p + "self_attn.o_proj.weight"][:, hs],
+            "gate": sd[p + "mlp.gate_proj.weight"][isl], "up": sd[p + "mlp.up_proj.weight"][isl],
+            "down": sd[p + "mlp.down_proj.weight"][:, isl]}

@@ -224,3 +224,74 @@ def test_two_rank_gloo_aggregation(tmp_path):
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     rec = json.loads(line)
     assert rec["t"] == 2.0 and rec["total"] == 6 and rec["seeds"] == [0, 2, 4]
+
+
+# ---- tensor-parallel host logic (parallel.py) ------------------------------------------------------------------------
+def test_llama_tp_shard_reconstructs_full_layer():
+    """Megatron slices of one decoder layer: column-parallel outputs concatenate, row-parallel partial products sum, to
+    the unsharded result (pure tensor arithmetic on the CPU; the GPU path consumes exactly these slices)."""
+    from seedx_amd.parallel import llama_tp_shard
+    torch.manual_seed(0)
+    nh, hd, I = 4, 16, 96
+    H = nh * hd
+    p = "model.layers.0."
+    sd = {p + f"self_attn.{n}.weight": torch.randn(H, H, dtype=torch.float64) for n in ("q_proj", "k_proj", "v_proj", "o_proj")}
+    sd.update({p + "mlp.gate_proj.weight": torch.randn(I, H, dtype=torch.float64),
+               p + "mlp.up_proj.weight": torch.randn(I, H, dtype=torch.float64),
+               p + "mlp.down_proj.weight": torch.randn(H, I, dtype=torch.float64)})
+    x = torch.randn(5, H, dtype=torch.float64)
+    full_q = x @ sd[p + "self_attn.q_proj.weight"].T
+    att = torch.randn(5, H, dtype=torch.float64)
+    full_o = att @ sd[p + "self_attn.o_proj.weight"].T
+    act = torch.nn.functional.silu(x @ sd[p + "mlp.gate_proj.weight"].T) * (x @ sd[p + "mlp.up_proj.weight"].T)
+    full_d = act @ sd[p + "mlp.down_proj.weight"].T
+    for tp in (1, 2):
+        shards = [llama_tp_shard(sd, p, r, tp, nh, hd) for r in range(tp)]
+        assert torch.allclose(torch.cat([x @ s_["q"].T for s_ in shards], dim=1), full_q)
+        hl = H // tp
+        assert torch.allclose(sum(att[:, r * hl:(r + 1) * hl] @ shards[r]["o"].T for r in range(tp)), full_o)
+        part = [torch.nn.functional.silu(x @ s_["gate"].T) * (x @ s_["up"].T) for s_ in shards]
+        assert torch.allclose(sum(part[r] @ shards[r]["down"].T for r in range(tp)), full_d)
+    with pytest.raises(AssertionError):
+        llama_tp_shard(sd, p, 0, 3, nh, hd)          # 4 heads do not split 3 ways
+
+
+def _tp_comm_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from seedx_amd.parallel import TorchDistComm
+    c = TorchDistComm()
+    t = torch.full((3, 4), float(rank + 1))
+    c.all_reduce(t)
+    g = c.all_gather(torch.tensor([rank * 10.0, rank * 10.0 + 1]))
+    c.barrier()
+    q.put((rank, t.tolist(), g.tolist()))
+    dist.destroy_process_group()
+
+
+def test_torchdist_comm_two_ranks_gloo():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    ps = [ctx.Process(target=_tp_comm_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p_ in ps:
+        p_.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p_ in ps:
+        p_.join(60)
+    for rank, red, gat in res:
+        assert red == [[3.0] * 4] * 3
+        assert gat == [[0.0, 1.0], [10.0, 11.0]]
+
+
+def test_thread_comm_virtual_ranks_cpu():
+    from seedx_amd.parallel import run_virtual_ranks
+
+    def fn(comm):
+        t = torch.full((2,), float(comm.rank + 1))
+        comm.all_reduce(t)
+        return t.tolist(), comm.all_gather(torch.tensor([float(comm.rank)])).flatten().tolist()
+    out = run_virtual_ranks(3, fn)
+    assert all(o == ([6.0, 6.0], [0.0, 1.0, 2.0]) for o in out)
