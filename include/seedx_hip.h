@@ -77,12 +77,15 @@ typedef struct sx_gemm_args {
   int32_t ld_bias2d; /* row stride of bias2d in floats (0 = N): lets one GEMM produce every resnet's time add    */
 } sx_gemm_args;
 int sx_gemm(const sx_gemm_args* args, void* stream);
-/* tuning/test hook: force tile config 0..3 (128x128, 128x80, 64x128, 64x64); -1 = automatic */
+/* tuning/test hook: force tile config 0..6 (128x128, 128x80, 64x128, 64x64, 256x256, 256x320, 256x160); -1 = automatic
+ * (cost model); 100/101 = 2-D XCD partition off/on; 300+g = g tile-rows per in-XCD traversal group (300 = default) */
 int sx_gemm_force_tile(int cfg);
 
-/* batch-1..8 row GEMV for single-token decode (HBM-bound weight streaming, no MFMA).
+/* 1..16-row GEMV for single-token decode of up to 16 lock-step sequences (HBM-bound weight streaming).
  * replaces: the same nn.Linear calls at q_len == 1 (modeling_llama_xformer.py:204-206,239,166-167,707).
- * y[m][n_out] = epi( x[m][K] · W[N][K]^T ), x 16-bit, y out_dtype, residual fp32. glu packing as above. */
+ * y[m][n_out] = epi( x[m][K] · W[N][K]^T ), x 16-bit, y out_dtype, residual fp32. glu packing as above.
+ * M <= 4 (or K % 64 != 0 / N % 32 != 0, then M <= 8): one wave per 2 rows, VALU dot products.
+ * M >= 5: the weight rows feed a 16x16x32 MFMA against x^T padded to 16 columns (cost independent of M). */
 typedef struct sx_gemv_args {
   const void* x;
   const void* W;
@@ -92,6 +95,8 @@ typedef struct sx_gemv_args {
   int32_t dtype, out_dtype, act, glu;
 } sx_gemv_args;
 int sx_gemv(const sx_gemv_args* args, void* stream);
+/* test hook: 1 = always take the VALU path (lets the tests compare both), 0 = automatic */
+int sx_gemv_force_valu(int on);
 
 /* ------------------------------------------------------------------------------------------------
  * Normalisations (row reductions with wave shuffles, fp32 statistics)

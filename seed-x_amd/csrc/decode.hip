@@ -88,6 +88,117 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvP p) {
   }
 }
 
+// ---- skinny GEMM for 2..16 activation rows (lock-step batched decode): y[M][N] = x[M][K] · W[N][K]^T on MFMA -----------------
+// The VALU GEMV above costs M FMAs per weight element and turns compute-bound at M = 8 (≈2x its M = 1 time). Here the
+// weight rows are the 16x16x32 MFMA's row operand and x^T (M padded to 16 columns) its column operand, so any M <= 16
+// costs the same and the kernel stays on the HBM roofline. Block = 4 waves = 4-way split of K; a wave owns R 16-row groups
+// (R = 2 = exactly one GLU group [16 linear | 16 gate]) and streams 128 contiguous bytes of each row per k-step (two 16-B
+// non-temporal loads per lane; each load instruction covers one 64-B half line of 16 rows: lane group g = lane >> 4 reads
+// bytes [16g, 16g + 16) of it, which is exactly the MFMA's k-slot layout, no shuffle). 4 k-steps are in flight per wave
+// (8-16 KB). Partial sums meet in LDS; wave 0 runs the fused epilogue (act / GLU / fp32 residual / store).
+template <typename TT, int R, int NWV>
+__global__ __launch_bounds__(NWV * 64) void gemm_skinny_kernel(const GemvP p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef typename TT::vec8 vec8;
+  __shared__ float red[NWV][R][64][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int n0 = blockIdx.x * 16 * R;
+  const int nks = p.K >> 6;
+  const int ks0 = wave * nks / NWV, ks1 = (wave + 1) * nks / NWV;
+  const bool mvalid = r < p.M;
+  const unsigned short* xp = p.x + (size_t)(mvalid ? r : 0) * p.K + 8 * g;
+  const unsigned short* wp[R];
+#pragma unroll
+  for (int q = 0; q < R; ++q) wp[q] = p.W + (size_t)(n0 + q * 16 + r) * p.K + 8 * g;
+  f32x4_t acc[R];
+#pragma unroll
+  for (int q = 0; q < R; ++q) acc[q] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  const u32x4_t zero = {0u, 0u, 0u, 0u};
+  constexpr int U = 4;
+  int ks = ks0;
+  for (; ks + U <= ks1; ks += U) {
+    u32x4_t wa[U][R], wb[U][R], xa[U], xb[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t k = (size_t)(ks + u) * 64;
+#pragma unroll
+      for (int q = 0; q < R; ++q) {
+        wa[u][q] = __builtin_nontemporal_load((const u32x4_t*)(wp[q] + k));
+        wb[u][q] = __builtin_nontemporal_load((const u32x4_t*)(wp[q] + k + 32));
+      }
+      xa[u] = *(const u32x4_t*)(xp + k);
+      xb[u] = *(const u32x4_t*)(xp + k + 32);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const vec8 a = __builtin_bit_cast(vec8, mvalid ? xa[u] : zero), b = __builtin_bit_cast(vec8, mvalid ? xb[u] : zero);
+#pragma unroll
+      for (int q = 0; q < R; ++q) {
+        acc[q] = TT::mfma16(__builtin_bit_cast(vec8, wa[u][q]), a, acc[q]);
+        acc[q] = TT::mfma16(__builtin_bit_cast(vec8, wb[u][q]), b, acc[q]);
+      }
+    }
+  }
+  for (; ks < ks1; ++ks) {
+    const size_t k = (size_t)ks * 64;
+    const u32x4_t xa = *(const u32x4_t*)(xp + k), xb = *(const u32x4_t*)(xp + k + 32);
+    const vec8 a = __builtin_bit_cast(vec8, mvalid ? xa : zero), b = __builtin_bit_cast(vec8, mvalid ? xb : zero);
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+      const u32x4_t wa = __builtin_nontemporal_load((const u32x4_t*)(wp[q] + k));
+      const u32x4_t wb = __builtin_nontemporal_load((const u32x4_t*)(wp[q] + k + 32));
+      acc[q] = TT::mfma16(__builtin_bit_cast(vec8, wa), a, acc[q]);
+      acc[q] = TT::mfma16(__builtin_bit_cast(vec8, wb), b, acc[q]);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < R; ++q)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[wave][q][lane][e] = acc[q][e];
+  __syncthreads();
+  if (wave != 0) return;
+  // lane holds y[m = r][n0 + q*16 + 4g + e], e = 0..3
+  f32x4_t v[R];
+#pragma unroll
+  for (int q = 0; q < R; ++q)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < NWV; ++w) t += red[w][q][lane][e];
+      v[q][e] = t;
+    }
+  if (!mvalid) return;
+  const int ncols = p.glu ? p.N / 2 : p.N;
+#pragma unroll
+  for (int q = 0; q < (R == 2 ? 2 : 1); ++q) {
+    f32x4_t o;
+    int col;
+    if (p.glu) {
+      if (q == 1) break;
+      col = blockIdx.x * 16 + 4 * g;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = v[0][e] * apply_act(v[R - 1][e], p.act);
+    } else {
+      col = n0 + q * 16 + 4 * g;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = apply_act(v[q][e], p.act);
+    }
+    const size_t off = (size_t)r * ncols + col;
+    if (p.residual) o += *(const f32x4_t*)(p.residual + off);
+    if (p.out_dtype == SX_F32) {
+      *(f32x4_t*)((float*)p.y + off) = o;
+    } else {
+      u32x2_t w2;
+      if (p.out_dtype == SX_BF16) { w2[0] = pack2<BF16>(o[0], o[1]); w2[1] = pack2<BF16>(o[2], o[3]); }
+      else { w2[0] = pack2<F16>(o[0], o[1]); w2[1] = pack2<F16>(o[2], o[3]); }
+      *(u32x2_t*)((unsigned short*)p.y + off) = w2;
+    }
+  }
+#endif
+}
+
 // ---- decode attention: grid (H, nsplit); 16-lane groups own one key row per iteration ---------------------------
 template <typename TT>
 __global__ __launch_bounds__(256) void attn_decode_kernel(const unsigned short* q, const unsigned short* kc,
@@ -324,16 +435,33 @@ inline dim3 gs_grid(int64_t n) {
 using namespace sxk_decode;
 
 #define ST ((hipStream_t)stream)
+static int g_force_valu_gemv = 0;   // test hook (sx_gemv_force_valu): compare the two GEMV paths
+extern "C" int sx_gemv_force_valu(int on) { g_force_valu_gemv = on; return SX_OK; }   // 1 = VALU only, 2 = MFMA whenever legal
 
 extern "C" int sx_gemv(const sx_gemv_args* a, void* stream) {
   SX_CHECK(a && a->x && a->W && a->y, "sx_gemv: null pointer");
   SX_CHECK(a->dtype == SX_F16 || a->dtype == SX_BF16, "sx_gemv: dtype");
-  SX_CHECK(a->M >= 1 && a->M <= 8, "sx_gemv: M=%d must be 1..8", a->M);
+  SX_CHECK(a->M >= 1 && a->M <= 16, "sx_gemv: M=%d must be 1..16", a->M);
   SX_CHECK(a->K % 8 == 0 && a->N > 0, "sx_gemv: K %% 8");
   SX_CHECK(!a->glu || a->N % 32 == 0, "sx_gemv: glu needs N %% 32 == 0");
   GemvP p;
   p.x = (const unsigned short*)a->x; p.W = (const unsigned short*)a->W; p.y = a->y; p.residual = a->residual;
   p.M = a->M; p.N = a->N; p.K = a->K; p.out_dtype = a->out_dtype; p.act = a->act; p.glu = a->glu;
+  // MI355X (tools/bench_gemv.py, 13B shapes): VALU path 6.5 / 4.7 / 3.0 TB/s at M = 1 / 4 / 8, MFMA path 4.0-4.4 TB/s at any M
+  const bool mfma_ok = a->M >= 2 && a->K % 64 == 0 && a->K >= 256 && a->N % 32 == 0;
+  if (mfma_ok && g_force_valu_gemv != 1 && (a->M >= 5 || g_force_valu_gemv == 2)) {
+    // MFMA skinny GEMM: R = 2 row groups per wave for GLU (one packed group) or when that still gives >= 256 blocks
+    const bool r2 = a->glu || a->N / 32 >= 256;
+    const dim3 grid(r2 ? a->N / 32 : a->N / 16), block(256);
+#define SX_SK_GO(TT)                                                                        \
+    if (r2) hipLaunchKernelGGL((gemm_skinny_kernel<TT, 2, 4>), grid, block, 0, ST, p);      \
+    else hipLaunchKernelGGL((gemm_skinny_kernel<TT, 1, 4>), grid, block, 0, ST, p);
+    if (a->dtype == SX_BF16) { SX_SK_GO(BF16) } else { SX_SK_GO(F16) }
+#undef SX_SK_GO
+    SX_HIP_LAUNCH_CHECK();
+    return SX_OK;
+  }
+  SX_CHECK(a->M <= 8, "sx_gemv: M=%d > 8 needs K %% 64 == 0 and N %% 32 == 0 (MFMA path)", a->M);
   const int pairs = (a->N + 1) / 2;
   const dim3 grid((pairs + 3) / 4), block(256);
   const int mr = a->M == 1 ? 1 : (a->M == 2 ? 2 : (a->M <= 4 ? 4 : 8));

@@ -68,7 +68,7 @@ class LlamaForCausalLM:
         self.H_l = self.nh_l * self.hd
         self.Tmax = max_cache_len or c.max_position_embeddings
         self.G = int(max_batch)
-        assert 1 <= self.G <= 8, "lock-step batch is limited to 8 sequences (sx_gemv rows)"
+        assert 1 <= self.G <= 16, "lock-step batch is limited to 16 sequences (sx_gemv rows)"
         self.device, self.dtype = None, torch.float16
         self._sd, self._P = None, None
         self._graph = None

@@ -273,6 +273,36 @@ def test_gemv(dev, dtype, M, N, K):
     assert relerr(out, F.silu(x.float() @ w.float().t())) < TOL[dtype]
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,K", [(2, 512, 256), (8, 5120, 5120), (5, 8192, 1728), (16, 640, 832), (8, 32384, 512)])
+def test_gemv_mfma_rows(dev, dtype, M, N, K):
+    """2..16 activation rows take the MFMA skinny-GEMM path (R = 1 and R = 2 row groups, ragged k split); it must agree
+    with the fp32 reference and with the VALU path on the same inputs."""
+    from seedx_amd import _lib, ops
+    x, w = rnd((M, K), dtype, dev, seed=38), rnd((N, K), dtype, dev, 0.05, seed=39)
+    res = rnd((M, N), torch.float32, dev, seed=40)
+    ref = x.float() @ w.float().t()
+    lib = _lib.load()
+    lib.sx_gemv_force_valu(2)                         # MFMA path for every M >= 2 (auto picks it from M = 5)
+    try:
+        out = ops.gemv(x, w, residual=res, out_dtype=torch.float32)
+        assert relerr(out, ref + res) < 5e-5
+        assert relerr(ops.gemv(x, w, act="silu"), F.silu(ref)) < TOL[dtype]
+        if M <= 8:
+            lib.sx_gemv_force_valu(1)
+            valu = ops.gemv(x, w, residual=res, out_dtype=torch.float32)
+            assert relerr(out, valu) < 2e-5
+            lib.sx_gemv_force_valu(2)
+        # GLU: packed [16 linear | 16 gate] groups, out = lin * silu(gate)
+        I = N // 2
+        lin, gate = w[:I], w[I:2 * I]
+        packed = torch.cat([lin.view(I // 16, 16, K), gate.view(I // 16, 16, K)], dim=1).reshape(2 * I, K).contiguous()
+        g = ops.gemv(x, packed, act="silu", glu=True, out_dtype=torch.float32)
+        assert relerr(g, (x.float() @ lin.float().t()) * F.silu(x.float() @ gate.float().t())) < 5e-5
+    finally:
+        lib.sx_gemv_force_valu(0)
+
+
 @pytest.mark.parametrize("ctx", [1, 17, 166, 1000])
 def test_attn_decode(dev, ctx):
     from seedx_amd import ops
