@@ -6,7 +6,7 @@ One "step" = ONE full generation on one GPU, with every input already resident i
     greedy decode of 128 new tokens (61 text tokens with lm_head + logits rule, then <img> + 64 forced image tokens
     + </img>; EOS disabled so the length is fixed) → output resampler → ResamplerXLV2 (CFG batch 2; the all-zero-image
     negative ViT features are a per-model constant and cached) → 50-step SDXL UNet CFG(7.5)+Euler at 128x128 latents
-    (= 1024x1024 px). The VAE decode is a "next" row and is NOT part of the step.
+    (= 1024x1024 px) → SDXL VAE decoder → [3, 1024, 1024] image in [0, 1] (`--no-vae` stops at the latents).
 Synthetic data: seeded random image / prompt ids, random-init weights of the real architecture (no checkpoints exist
 here). N > 1 GPUs: one process per GPU (torchrun), independent generations per rank (no data-path collective; weak
 scaling); value = total generations of all ranks / max-over-ranks wall time.
@@ -31,6 +31,7 @@ PEAK_TFLOPS_16BIT = 2500.0   # dense bf16/fp16 MFMA peak, MI355X_MICROARCH.md
 FLOP_VIT_CROP = 4.219e12
 FLOP_LLM_TOKEN = 25.71e9
 FLOP_UNET_SAMPLE = 6.747e12
+FLOP_VAE_DECODE = 10.47e12   # SDXL VAE decoder at 128x128 latents (conv/linear/attention MACs x 2)
 
 
 class BenchTokenizer:
@@ -47,6 +48,9 @@ class BenchTokenizer:
 
     def decode(self, ids, skip_special_tokens=False):
         return " ".join(str(int(i)) for i in ids)
+
+
+USE_VAE = True   # set from --no-vae
 
 
 def build_models(dev, dtype, llm_comm=None, cfg_comm=None):
@@ -78,7 +82,14 @@ def build_models(dev, dtype, llm_comm=None, cfg_comm=None):
     res.load_state_dict(syn.xlv2_state_dict(syn.FULL_XLV2, dev, dtype), prefix="resampler.")
     adapter = SDXLAdapter(unet, res, vit_down=True)
     adapter.comm = cfg_comm
-    adapter.init_pipe(vae=None, scheduler=EulerDiscreteScheduler(), visual_encoder=vit, image_transform=None,
+    vae = None
+    if USE_VAE:
+        from seedx_amd.vae import AutoencoderKL
+        vae = AutoencoderKL()                                                    # SDXL vae/config.json defaults
+        vae.load_state_dict(syn.vae_state_dict(vae, dev, dtype))
+        vae.to(dev, dtype)
+        vae._pack()
+    adapter.init_pipe(vae=vae, scheduler=EulerDiscreteScheduler(), visual_encoder=vit, image_transform=None,
                       discrete_model=None, dtype=dtype, device=dev)
     unet._pack()
     torch.cuda.empty_cache()
@@ -120,10 +131,10 @@ def front_half(vit, agent, tok, inp, n_text):
 def back_half(adapter, feats, steps_unet, seed):
     """Path C for BATCH requests as one UNet batch of 2·BATCH CFG samples (enqueue-only: no host sync inside)."""
     G = feats.shape[0]
-    lat = adapter.generate(image_embeds=feats, num_inference_steps=steps_unet, seed=[seed * G + g for g in range(G)],
-                           output_type="latent")
-    assert lat.shape[0] == G
-    return lat
+    out = adapter.generate(image_embeds=feats, num_inference_steps=steps_unet, seed=[seed * G + g for g in range(G)],
+                           output_type="pt" if USE_VAE else "latent")
+    assert out.shape == ((G, 3, 1024, 1024) if USE_VAE else (G, 4, 128, 128))
+    return out
 
 
 def one_generation(vit, agent, adapter, tok, inp, steps_unet, n_text, seed):
@@ -273,11 +284,14 @@ def main():
                     help="1: pipeline consecutive requests on two streams (LLM decode of request i+1 under the UNet of request i)")
     ap.add_argument("--batch", type=int, default=8,
                     help="independent generations processed together per GPU per step (1 = single-request latency mode)")
+    ap.add_argument("--no-vae", action="store_true", help="stop at the denoised latents (no VAE decode)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     a = ap.parse_args()
     global BATCH
     BATCH = a.batch
+    global USE_VAE
+    USE_VAE = not a.no_vae
     from seedx_amd import dist_utils as du
     ctx = du.init("nccl")                       # RCCL over xGMI; only barrier + max-reduce of the wall time
     rank, world, local = ctx.rank, ctx.world, ctx.local
@@ -324,11 +338,14 @@ def main():
                "dtype": a.dtype, "data": "synthetic (seeded random image/prompt, random-init weights of the real dims)",
                "config": {"workload": "SEED-X-I: 1x448px image (2 crops ViT-G) -> 165-token prefill -> 128 greedy tokens "
                                       "(%d text + <img> + 64 forced + </img>) -> %d-step SDXL-UNet CFG-2 de-tokenize "
-                                      "@1024x1024 (VAE decode excluded)" % (a.text_tokens, a.unet_steps),
+                                      "@1024x1024 -> %s" % (a.text_tokens, a.unet_steps,
+                                                            "SDXL VAE decode to a [3,1024,1024] image" if USE_VAE
+                                                            else "latents (VAE decode skipped)"),
                           "parallelism": "replica x%d (independent generations, no data-path collective)" % world,
                           "batch_per_gpu": a.batch,
                           "request_pipelining": bool(a.overlap)},
-               "flops_per_generation": 2 * FLOP_VIT_CROP + (165 + 128) * FLOP_LLM_TOKEN + 2 * a.unet_steps * FLOP_UNET_SAMPLE,
+               "flops_per_generation": 2 * FLOP_VIT_CROP + (165 + 128) * FLOP_LLM_TOKEN + 2 * a.unet_steps * FLOP_UNET_SAMPLE
+               + (FLOP_VAE_DECODE if USE_VAE else 0.0),
                "generations_per_step": a.batch}
         rec["model_tflops"] = rec["flops_per_generation"] * rec["value"] / world / 1e12
         if roof is not None:

@@ -107,6 +107,13 @@ int sx_gemv_force_valu(int on);
 int sx_layernorm(const void* x, int in_dtype, void* y, int out_dtype, const float* gamma, const float* beta,
                  int rows, int cols, float eps, int rms, void* stream);
 
+/* Row softmax y = softmax(scale * x) over the last dim, fp32 in → 16-bit out (probabilities feed the P·V GEMM).
+ * replaces: the softmax inside diffusers Attention [ext] of the VAE decoder's mid block (one 512-wide head over
+ * (H/8)·(W/8) pixels — head_dim 512 does not fit the flash kernel, so scores go through sx_gemm; reference call site
+ * pipeline_stable_diffusion_xl_t2i_edit.py:973). */
+int sx_softmax_rows(const float* x, int64_t ldx, void* y, int64_t ldy, int rows, int cols, float scale, int out_dtype,
+                    void* stream);
+
 /* GroupNorm(+SiLU) over NHWC activations x[B][HW][C] (fp32 in). replaces diffusers
  * ResnetBlock2D.norm1/norm2 + nonlinearity, Transformer2DModel.norm, conv_norm_out [ext].
  * stats: scratch fp64 [B][groups][2] (zeroed by the call). y: 16-bit normalised output.

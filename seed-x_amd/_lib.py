@@ -57,6 +57,7 @@ SIGNATURES = {
     "sx_gemv": [C.POINTER(GemvArgs), c_vp],
     "sx_gemv_force_valu": [c_i32],
     "sx_layernorm": [c_vp, c_i32, c_vp, c_i32, c_vp, c_vp, c_i32, c_i32, c_f32, c_i32, c_vp],
+    "sx_softmax_rows": [c_vp, c_i64, c_vp, c_i64, c_i32, c_i32, c_f32, c_i32, c_vp],
     "sx_groupnorm": [c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_i32, c_vp],
     "sx_transpose_v": [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64, c_i64, c_i64, c_vp],
     "sx_attention": [C.POINTER(AttnArgs), c_vp],

@@ -245,6 +245,46 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* x, void* y, 
   }
 }
 
+// ---- row softmax (VAE mid-block attention: one 512-wide head over 16384 pixels, scores materialised by the GEMM) ---------------
+// y[r][c] = exp(scale·x[r][c] − max_r) / Σ_c …, fp32 in → 16-bit out. Block per row, three streaming passes over the row
+// (64 KB at C = 16384: it stays in L2 between passes), float4 loads, block reductions through LDS.
+template <typename TT>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* x, long ldx, unsigned short* y, long ldy, int C,
+                                                           float scale) {
+  __shared__ float red[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float4* xr = (const float4*)(x + (size_t)blockIdx.x * ldx);
+  unsigned short* yr = y + (size_t)blockIdx.x * ldy;
+  const int n4 = C >> 2;
+  const float sl2 = scale * 1.4426950408889634f;   // exp(s·x − m) = exp2(s·log2e·x − m')
+  float m = -INFINITY;
+  for (int i = tid; i < n4; i += 256) {
+    const float4 v = xr[i];
+    m = fmaxf(fmaxf(m, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+  }
+  m = wave_max(m);
+  if (lane == 0) red[wave] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) * sl2;   // scale > 0
+  __syncthreads();
+  float sum = 0.f;
+  for (int i = tid; i < n4; i += 256) {
+    const float4 v = xr[i];
+    sum += exp2f(v.x * sl2 - m) + exp2f(v.y * sl2 - m) + exp2f(v.z * sl2 - m) + exp2f(v.w * sl2 - m);
+  }
+  sum = wave_sum(sum);
+  if (lane == 0) red[wave] = sum;
+  __syncthreads();
+  const float inv = 1.f / (red[0] + red[1] + red[2] + red[3]);
+  for (int i = tid; i < n4; i += 256) {
+    const float4 v = xr[i];
+    u32x2_t o;
+    o[0] = pack2<TT>(exp2f(v.x * sl2 - m) * inv, exp2f(v.y * sl2 - m) * inv);
+    o[1] = pack2<TT>(exp2f(v.z * sl2 - m) * inv, exp2f(v.w * sl2 - m) * inv);
+    *(u32x2_t*)(yr + 4 * i) = o;
+  }
+}
+
 }  // namespace sxk_norm
 using namespace sxk_norm;
 
@@ -318,6 +358,21 @@ extern "C" int sx_groupnorm(const float* x, void* y, void* raw16, int out_dtype,
   SX_HIP_LAUNCH_CHECK();
   hipLaunchKernelGGL(gn_apply_kernel, grid, block, 0, st, x, y, raw16, out_dtype, gamma, beta, stats, HW, C, groups,
                      eps, silu, rows_per_block);
+  SX_HIP_LAUNCH_CHECK();
+  return SX_OK;
+}
+
+extern "C" int sx_softmax_rows(const float* x, int64_t ldx, void* y, int64_t ldy, int rows, int cols, float scale,
+                               int out_dtype, void* stream) {
+  SX_CHECK(x && y, "sx_softmax_rows: null pointer");
+  SX_CHECK(rows > 0 && cols > 0 && cols % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0, "sx_softmax_rows: rows=%d cols=%d", rows, cols);
+  SX_CHECK(scale > 0.f, "sx_softmax_rows: scale must be positive");
+  SX_CHECK(out_dtype == SX_F16 || out_dtype == SX_BF16, "sx_softmax_rows: output must be 16-bit");
+  hipStream_t st = (hipStream_t)stream;
+  if (out_dtype == SX_BF16)
+    hipLaunchKernelGGL(softmax_rows_kernel<BF16>, dim3(rows), dim3(256), 0, st, x, (long)ldx, (unsigned short*)y, (long)ldy, cols, scale);
+  else
+    hipLaunchKernelGGL(softmax_rows_kernel<F16>, dim3(rows), dim3(256), 0, st, x, (long)ldx, (unsigned short*)y, (long)ldy, cols, scale);
   SX_HIP_LAUNCH_CHECK();
   return SX_OK;
 }

@@ -371,11 +371,24 @@ class SDXLAdapter:
         return torch.cat(out, dim=0)
 
     def _finish(self, latents, output_type):
-        if output_type == "latent" or self.vae is None:
+        """pipeline…:965-986: "latent" → latents; otherwise VAE-decode (latents / scaling_factor) and post-process like
+        VaeImageProcessor.postprocess [ext]: "pt" → [B,3,H,W] in [0,1]; "np" → [B,H,W,3]; "pil" → list of PIL images."""
+        if output_type == "latent":
             return latents
+        if self.vae is None:
+            raise RuntimeError(f"output_type={output_type!r} needs a VAE (init_pipe(vae=...)); use output_type='latent'")
         scaling = getattr(getattr(self.vae, "config", None), "scaling_factor", 0.13025)
-        img = self.vae.decode(latents / scaling)                                     # pipeline…:965-977
-        return getattr(img, "sample", img)
+        img = self.vae.decode(latents / scaling, return_dict=False)[0]
+        if output_type == "raw":                                                     # decoder output, no post-processing
+            return img
+        img = (img / 2 + 0.5).clamp(0, 1)
+        if output_type == "pt":
+            return img
+        arr = img.permute(0, 2, 3, 1).float().cpu().numpy()
+        if output_type == "np":
+            return arr
+        from PIL import Image
+        return [Image.fromarray((a * 255).round().astype("uint8")) for a in arr]
 
     def generate(self, image_pil=None, image_tensor=None, image_embeds=None, seed=None, height=1024, width=1024,
                  guidance_scale=7.5, num_inference_steps=30, input_image_size=448, output_type="latent", latents=None,

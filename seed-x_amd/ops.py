@@ -187,6 +187,17 @@ def groupnorm(x, gamma, beta, groups, eps, silu, out_dtype, want_raw=False):
     return (y, raw) if want_raw else y
 
 
+def softmax_rows(x, scale, out_dtype):
+    """softmax(scale · x) over the last dim; x fp32 [R, C] (row stride free) → 16-bit [R, C]."""
+    lib = _lib.load()
+    assert x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
+    R, Cc = x.shape
+    y = torch.empty((R, Cc), dtype=out_dtype, device=x.device)
+    check(lib.sx_softmax_rows(_p(x), x.stride(0), _p(y), y.stride(0), R, Cc, float(scale), _DT[out_dtype], _stream()),
+          "sx_softmax_rows")
+    return y
+
+
 # ---------------------------------------------------------------------------------------------------------
 # Attention
 # ---------------------------------------------------------------------------------------------------------

@@ -210,3 +210,20 @@ def unet_state_dict(cfg, device, dtype=torch.float16, seed=1238):
                 (1.3 if ("to_q" in name or "to_k" in name) else 1.0)
             sd[name] = G.normal(shape, gain / math.sqrt(fan_in))
     return sd
+
+
+def vae_state_dict(vae, device, dtype=torch.float16, seed=1239):
+    """Random-init decoder weights for a seedx_amd.vae.AutoencoderKL instance (its own key/shape inventory)."""
+    G = _Gen(device, dtype, seed)
+    sd = {}
+    for name, shape in vae.param_shapes().items():
+        if name.endswith(".bias"):
+            sd[name] = G.vec(shape[0], 0.02)
+        elif len(shape) == 1:
+            sd[name] = G.gamma(shape[0])
+        else:
+            fan_in = 1
+            for s_ in shape[1:]:
+                fan_in *= s_
+            sd[name] = G.normal(shape, (0.4 if "conv2." in name or "to_out.0" in name else 1.0) / math.sqrt(fan_in))
+    return sd
