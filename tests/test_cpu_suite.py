@@ -295,3 +295,33 @@ def test_thread_comm_virtual_ranks_cpu():
         return t.tolist(), comm.all_gather(torch.tensor([float(comm.rank)])).flatten().tolist()
     out = run_virtual_ranks(3, fn)
     assert all(o == ([6.0, 6.0], [0.0, 1.0, 2.0]) for o in out)
+
+
+# ---- VAE decoder host logic ------------------------------------------------------------------------------------------
+def test_vae_inventory_matches_oracle_and_param_count():
+    from oracle import restated_vae as rv
+    from seedx_amd.vae import AutoencoderKL
+    assert rv.vae_decoder_param_count(rv.FULL_VAE) == 49_490_179 + 20          # SDXL decoder + post_quant_conv
+    m = AutoencoderKL()
+    assert m.param_shapes() == rv.vae_decoder_param_shapes(rv.FULL_VAE)
+    mini = AutoencoderKL(block_out_channels=(64, 128), layers_per_block=1)
+    assert mini.param_shapes() == rv.vae_decoder_param_shapes(rv.MINI_VAE)
+    # pre-0.19 diffusers attention names are mapped; encoder keys are ignored; a missing decoder key raises
+    sd = rv.vae_sd(rv.MINI_VAE)
+    a = "decoder.mid_block.attentions.0."
+    for new, old in (("to_q", "query"), ("to_k", "key"), ("to_v", "value"), ("to_out.0", "proj_attn")):
+        sd[a + old + ".weight"] = sd.pop(a + new + ".weight")[:, :, None, None]
+        sd[a + old + ".bias"] = sd.pop(a + new + ".bias")
+    sd["encoder.conv_in.weight"] = torch.zeros(1)
+    missing, _ = mini.load_state_dict(sd)
+    assert missing == [] and mini._sd[a + "to_q.weight"].dim() == 2
+    sd.pop("decoder.conv_in.bias")
+    with pytest.raises(KeyError):
+        mini.load_state_dict(sd)
+
+
+def test_vae_oracle_decode_shapes_cpu():
+    from oracle import restated_vae as rv
+    sd = rv.vae_sd(rv.MINI_VAE)
+    y = rv.vae_decode(sd, rv.MINI_VAE, torch.randn(1, 4, 8, 8, generator=torch.Generator().manual_seed(0)))
+    assert y.shape == (1, 3, 16, 16) and torch.isfinite(y).all()
