@@ -72,9 +72,11 @@ typedef struct sx_gemm_args {
   int32_t a_mode;      /* SX_A_*                                                                     */
   /* conv geometry (a_mode == SX_A_CONV3X3): M = B*Hout*Wout, K = 9*Cin */
   int32_t B, Hin, Win, Cin, Hout, Wout;
-  int32_t stride;   /* 1 or 2 (pad is always 1)                                                      */
+  int32_t stride;   /* 1 or 2 (padding: see pad_mode)                                                */
   int32_t upsample; /* 1 = input is nearest-2x upsampled on the fly (Hout = 2*Hin)                   */
   int32_t ld_bias2d; /* row stride of bias2d in floats (0 = N): lets one GEMM produce every resnet's time add    */
+  int32_t pad_mode; /* 0 = zero pad 1 on every side; 1 = pad 0 top/left and 1 bottom/right (diffusers Downsample2D with
+                       padding=0 + F.pad(x, (0,1,0,1)): the stride-2 convs of the VAE encoder [ext])                 */
 } sx_gemm_args;
 int sx_gemm(const sx_gemm_args* args, void* stream);
 /* tuning/test hook: force tile config 0..6 (128x128, 128x80, 64x128, 64x64, 256x256, 256x320, 256x160); -1 = automatic

@@ -21,7 +21,7 @@ class GemmArgs(C.Structure):
                 ("res_mod", c_i32), ("bias2d_rows", c_i32), ("dtype", c_i32), ("out_dtype", c_i32),
                 ("act", c_i32), ("glu", c_i32), ("a_mode", c_i32),
                 ("B", c_i32), ("Hin", c_i32), ("Win", c_i32), ("Cin", c_i32), ("Hout", c_i32), ("Wout", c_i32),
-                ("stride", c_i32), ("upsample", c_i32), ("ld_bias2d", c_i32)]
+                ("stride", c_i32), ("upsample", c_i32), ("ld_bias2d", c_i32), ("pad_mode", c_i32)]
 
 
 class GemvArgs(C.Structure):

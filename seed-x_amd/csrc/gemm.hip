@@ -30,7 +30,7 @@ struct GemmP {
   const float* bias2d;
   const float* residual;
   int M, N, K, ldc, ldr, n_valid, res_mod, bias2d_rows, out_dtype, act, glu;
-  int Hin, Win, Cin, Hout, Wout, stride, upsample, ldb2;
+  int Hin, Win, Cin, Hout, Wout, stride, upsample, ldb2, pad;
   int tiles_m, tiles_n, xm, xn;   // tile grid and its XCD partition (xm x xn == 8, or 0 = linear remap)
   int gm;                         // tile-rows per group of the in-XCD traversal
   unsigned a_bytes, w_bytes;
@@ -108,8 +108,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const GemmP p) {
       const int b = row / hw, rem = row - b * hw;
       const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
       a_b[i] = (row < p.M) ? b * p.Hin : -(1 << 28);  // invalid rows fail the range test below
-      a_y[i] = oy * p.stride - 1;
-      a_x[i] = ox * p.stride - 1;
+      a_y[i] = oy * p.stride - p.pad;
+      a_x[i] = ox * p.stride - p.pad;
       a_off[i] = 0;
     }
   }
@@ -414,14 +414,18 @@ extern "C" int sx_gemm(const sx_gemm_args* a, void* stream) {
   p.n_valid = a->n_valid > 0 ? a->n_valid : n_out;
   p.bias2d_rows = a->bias2d_rows; p.out_dtype = a->out_dtype; p.act = a->act; p.glu = a->glu;
   p.ldb2 = a->ld_bias2d > 0 ? a->ld_bias2d : a->N;
+  p.pad = 1;
   uint64_t a_bytes;
   if (a->a_mode == SX_A_CONV3X3) {
     SX_CHECK(a->Cin % 64 == 0 && a->K == 9 * a->Cin, "sx_gemm conv: Cin=%d K=%d", a->Cin, a->K);
     SX_CHECK(a->stride == 1 || a->stride == 2, "sx_gemm conv: stride");
     SX_CHECK(a->M == a->B * a->Hout * a->Wout, "sx_gemm conv: M != B*Hout*Wout");
     const int hv = a->upsample ? 2 * a->Hin : a->Hin, wv = a->upsample ? 2 * a->Win : a->Win;
-    SX_CHECK(a->Hout == (hv + 2 - 3) / a->stride + 1 && a->Wout == (wv + 2 - 3) / a->stride + 1,
+    SX_CHECK(a->pad_mode == 0 || a->pad_mode == 1, "sx_gemm conv: pad_mode");
+    const int padsum = a->pad_mode ? 1 : 2;
+    SX_CHECK(a->Hout == (hv + padsum - 3) / a->stride + 1 && a->Wout == (wv + padsum - 3) / a->stride + 1,
              "sx_gemm conv: output geometry mismatch");
+    p.pad = a->pad_mode ? 0 : 1;
     p.Hin = a->Hin; p.Win = a->Win; p.Cin = a->Cin; p.Hout = a->Hout; p.Wout = a->Wout;
     p.stride = a->stride; p.upsample = a->upsample;
     a_bytes = (uint64_t)a->B * a->Hin * a->Win * a->Cin * 2;

@@ -427,8 +427,8 @@ class SDXLAdapterWithLatentImage(SDXLAdapter):
                 image_latents = torch.zeros(G, 4, height // 8, width // 8)          # pipeline…:909-910 (no source image)
             else:
                 if self.vae is None:
-                    raise NotImplementedError("VAE encode of `latent_image` is a 'next' row (SURVEY.md §8f-1): pass "
-                                              "`image_latents` = vae.encode(img).latent_dist.mode() (NOT scaled, :523)")
+                    raise RuntimeError("`latent_image` needs a VAE with encoder weights (init_pipe(vae=...)); or pass "
+                                       "`image_latents` = vae.encode(img).latent_dist.mode() (NOT scaled, :523)")
                 image_latents = self.vae.encode(latent_image).latent_dist.mode()
         il = image_latents.to(self.device, torch.float32)
         il3 = torch.cat([il, il, torch.zeros_like(il)], dim=0)                       # [img, img, 0]  (:544-546)

@@ -86,17 +86,18 @@ def gemm(a, w, bias=None, bias2d=None, bias2d_rows=0, residual=None, res_mod=0, 
 
 
 def conv3x3(x, w, bias=None, bias2d=None, residual=None, stride=1, upsample=False, out_dtype=None, act=None,
-            n_valid=0):
+            n_valid=0, pad_mode=0):
     """3x3 / pad 1 convolution as implicit GEMM. x: [B, H, W, Cin] 16-bit NHWC contiguous; w: [Cout, 9*Cin]
     ((ky,kx,cin)-ordered). Returns [B, Hout*Wout, Cout] (NHWC flattened). bias2d: [B, Cout] fp32 per-sample add.
-    residual: fp32 [B*Hout*Wout, Cout]."""
+    residual: fp32 [B*Hout*Wout, Cout]. pad_mode 1 = pad only bottom/right (VAE encoder's stride-2 convs)."""
     lib = _lib.load()
     assert x.dim() == 4 and x.is_contiguous() and w.is_contiguous()
     B, H, W, Cin = x.shape
     Cout, K = w.shape
     assert K == 9 * Cin
     hv, wv = (2 * H, 2 * W) if upsample else (H, W)
-    Hout, Wout = (hv + 2 - 3) // stride + 1, (wv + 2 - 3) // stride + 1
+    padsum = 1 if pad_mode else 2
+    Hout, Wout = (hv + padsum - 3) // stride + 1, (wv + padsum - 3) // stride + 1
     M = B * Hout * Wout
     out_dtype = out_dtype or x.dtype
     n_store = n_valid if n_valid else Cout
@@ -123,6 +124,7 @@ def conv3x3(x, w, bias=None, bias2d=None, residual=None, stride=1, upsample=Fals
     args.B, args.Hin, args.Win, args.Cin, args.Hout, args.Wout = B, H, W, Cin, Hout, Wout
     args.stride = stride
     args.upsample = 1 if upsample else 0
+    args.pad_mode = pad_mode
     check(lib.sx_gemm(C.byref(args), _stream()), "sx_gemm(conv3x3)")
     return out.view(B, Hout * Wout, n_store)
 

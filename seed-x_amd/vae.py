@@ -15,7 +15,9 @@ emits 16-bit probabilities, V^T comes straight out of a GEMM with swapped operan
 P·V (softmax rows sum to 1). Images are decoded one at a time: at 1024 px one image already gives every launch ≥ 4096
 tiles, and it keeps the operand descriptors under 2 GiB.
 
-Only the decoder is built; ``encode`` (edit pipeline, :505-527) raises NotImplementedError.
+``encode(image).latent_dist.mode()`` (edit pipeline, :505-527) runs the encoder the same way (its stride-2 Downsample2D
+convs pad only bottom/right: sx_gemm pad_mode 1); ``sample()`` of the posterior is not offered (the reference only calls
+``mode()``). Encoder weights are optional in the state dict: without them ``encode`` raises.
 """
 import json
 import math
@@ -43,6 +45,7 @@ class AutoencoderKL:
                                       scaling_factor=scaling_factor, force_upcast=force_upcast)
         self.device, self.dtype = None, torch.bfloat16
         self._sd, self._P = None, None
+        self.has_encoder = False
 
     # ---- reference-compatible plumbing ---------------------------------------------------------------------------------
     @classmethod
@@ -98,6 +101,44 @@ class AutoencoderKL:
         conv("decoder.conv_out", c.out_channels, boc[0], 3)
         return S
 
+    def encoder_param_shapes(self):
+        """{state-dict key: shape} of what encode() needs (encoder.* + quant_conv.*)."""
+        c = self.config
+        boc, top, lc = c.block_out_channels, c.block_out_channels[-1], c.latent_channels
+        S = {}
+
+        def conv(n, co, ci, k):
+            S[n + ".weight"], S[n + ".bias"] = (co, ci, k, k), (co,)
+
+        def vec(n, ch):
+            S[n + ".weight"], S[n + ".bias"] = (ch,), (ch,)
+
+        def resnet(n, ci, co):
+            vec(n + ".norm1", ci)
+            conv(n + ".conv1", co, ci, 3)
+            vec(n + ".norm2", co)
+            conv(n + ".conv2", co, co, 3)
+            if ci != co:
+                conv(n + ".conv_shortcut", co, ci, 1)
+        conv("encoder.conv_in", boc[0], c.in_channels, 3)
+        prev = boc[0]
+        for i, co in enumerate(boc):
+            for j in range(c.layers_per_block):
+                resnet(f"encoder.down_blocks.{i}.resnets.{j}", prev if j == 0 else co, co)
+            prev = co
+            if i != len(boc) - 1:
+                conv(f"encoder.down_blocks.{i}.downsamplers.0.conv", co, co, 3)
+        resnet("encoder.mid_block.resnets.0", top, top)
+        a = "encoder.mid_block.attentions.0."
+        vec(a + "group_norm", top)
+        for s_ in ("to_q", "to_k", "to_v", "to_out.0"):
+            S[a + s_ + ".weight"], S[a + s_ + ".bias"] = (top, top), (top,)
+        resnet("encoder.mid_block.resnets.1", top, top)
+        vec("encoder.conv_norm_out", top)
+        conv("encoder.conv_out", 2 * lc, top, 3)
+        conv("quant_conv", 2 * lc, 2 * lc, 1)
+        return S
+
     def expected_keys(self):
         return list(self.param_shapes())
 
@@ -106,15 +147,19 @@ class AutoencoderKL:
         Pre-0.19 diffusers checkpoints name the attention projections query/key/value/proj_attn: mapped here."""
         old = {"query": "to_q", "key": "to_k", "value": "to_v", "proj_attn": "to_out.0"}
         sd = dict(sd)
-        a = "decoder.mid_block.attentions.0."
-        for o, n in old.items():
-            for s in (".weight", ".bias"):
-                if a + o + s in sd and a + n + s not in sd:
-                    t = sd.pop(a + o + s)
-                    sd[a + n + s] = t.reshape(t.shape[0], -1) if s == ".weight" else t
+        for a in ("decoder.mid_block.attentions.0.", "encoder.mid_block.attentions.0."):
+            for o, n in old.items():
+                for s in (".weight", ".bias"):
+                    if a + o + s in sd and a + n + s not in sd:
+                        t = sd.pop(a + o + s)
+                        sd[a + n + s] = t.reshape(t.shape[0], -1) if s == ".weight" else t
         missing = [k for k in self.expected_keys() if k not in sd]
         if missing and strict:
             raise KeyError(f"AutoencoderKL: missing keys {missing[:6]} (+{max(0, len(missing) - 6)})")
+        enc = [k for k in self.encoder_param_shapes() if k not in sd]
+        self.has_encoder = not enc
+        if enc and any(k.startswith("encoder.") for k in sd) and strict:   # a partial encoder is a broken checkpoint
+            raise KeyError(f"AutoencoderKL: incomplete encoder, missing {enc[:6]} (+{max(0, len(enc) - 6)})")
         self._sd, self._P = sd, None
         return missing, []
 
@@ -203,6 +248,41 @@ class AutoencoderKL:
         bo = torch.zeros(16, dtype=torch.float32, device=dev)
         bo[:wo.shape[0]] = f32("decoder.conv_out.bias")
         P["conv_out"] = (wop, bo)
+        if self.has_encoder:
+            E = {}
+            ci = c.in_channels
+            self.enc_kpad = (9 * ci + 63) // 64 * 64
+            w = sd["encoder.conv_in.weight"].detach().to(dev, dt).permute(0, 2, 3, 1).reshape(boc[0], -1)
+            wp = torch.zeros(boc[0], self.enc_kpad, dtype=dt, device=dev)
+            wp[:, :w.shape[1]] = w
+            E["conv_in"] = (wp, f32("encoder.conv_in.bias"))
+            E["down"] = []
+            for i in range(len(boc)):
+                blk = dict(res=[resnet(f"encoder.down_blocks.{i}.resnets.{j}") for j in range(c.layers_per_block)], down=None)
+                if i != len(boc) - 1:
+                    n = f"encoder.down_blocks.{i}.downsamplers.0.conv"
+                    blk["down"] = (conv16(n + ".weight"), f32(n + ".bias"))
+                E["down"].append(blk)
+            a = "encoder.mid_block.attentions.0."
+            E["mid"] = dict(r0=resnet("encoder.mid_block.resnets.0"), r1=resnet("encoder.mid_block.resnets.1"),
+                            gn=(f32(a + "group_norm.weight"), f32(a + "group_norm.bias")),
+                            wq=lin16(a + "to_q.weight"), bq=f32(a + "to_q.bias"),
+                            wk=lin16(a + "to_k.weight"), bk=f32(a + "to_k.bias"),
+                            wv=lin16(a + "to_v.weight"), bv=f32(a + "to_v.bias"),
+                            wo=lin16(a + "to_out.0.weight"), bo=f32(a + "to_out.0.bias"))
+            E["norm_out"] = (f32("encoder.conv_norm_out.weight"), f32("encoder.conv_norm_out.bias"))
+            wo = conv16("encoder.conv_out.weight")                                  # [2*lc, 9*top]
+            wop = torch.zeros(16, wo.shape[1], dtype=dt, device=dev)
+            wop[:wo.shape[0]] = wo
+            bo = torch.zeros(16, dtype=torch.float32, device=dev)
+            bo[:wo.shape[0]] = f32("encoder.conv_out.bias")
+            E["conv_out"] = (wop, bo)
+            wq = torch.zeros(16, 64, dtype=dt, device=dev)                          # quant_conv 1x1 as a K-padded GEMM
+            wq[:2 * lc, :2 * lc] = sd["quant_conv.weight"].detach().to(dev, dt).reshape(2 * lc, 2 * lc)
+            bq = torch.zeros(16, dtype=torch.float32, device=dev)
+            bq[:2 * lc] = f32("quant_conv.bias")
+            E["quant"] = (wq, bq)
+            P["enc"] = E
         self._P, self._sd = P, None
         return P
 
@@ -269,6 +349,44 @@ class AutoencoderKL:
         out = torch.cat([self._decode_one(z[b:b + 1].contiguous()) for b in range(z.shape[0])], dim=0)
         return DecoderOutput(out) if return_dict else (out,)
 
-    def encode(self, *a, **k):
-        raise NotImplementedError("AutoencoderKL.encode (edit pipeline's source-image latents) is not built yet; pass "
-                                  "pre-encoded image latents to SDXLAdapterWithLatentImage.generate")
+    def _encode_one(self, img_nchw):
+        """img: fp32 [1, 3, H, W] in [-1, 1] → mean of the posterior, fp32 [1, latent, H/8, W/8]."""
+        P, dt, c = self._P, self.dtype, self.config
+        E = P["enc"]
+        _, ci, H, W = img_nchw.shape
+        nb = len(c.block_out_channels)
+        assert H % (1 << (nb - 1)) == 0 and W % (1 << (nb - 1)) == 0
+        x = ops.nchw_to_nhwc(img_nchw)                                               # [1, HW, 3] fp32
+        col = ops.im2col3x3_small(x.view(1, H, W, ci), self.enc_kpad, dt)
+        x = ops.gemm(col, E["conv_in"][0], bias=E["conv_in"][1], out_dtype=torch.float32).view(1, H * W, -1)
+        for blk in E["down"]:
+            for r in blk["res"]:
+                x = self._resnet(r, x, H, W)
+            if blk["down"] is not None:                                              # Downsample2D(padding=0) + F.pad(0,1,0,1)
+                Ci = x.shape[-1]
+                x = ops.conv3x3(ops.cast(x, dt).view(1, H, W, Ci), blk["down"][0], bias=blk["down"][1], stride=2,
+                                pad_mode=1, out_dtype=torch.float32)
+                H, W = H // 2, W // 2
+        x = self._resnet(E["mid"]["r0"], x, H, W)
+        x = self._mid_attention(E["mid"], x)
+        x = self._resnet(E["mid"]["r1"], x, H, W)
+        hN = ops.groupnorm(x, E["norm_out"][0], E["norm_out"][1], c.norm_num_groups, EPS, True, dt)
+        lc2 = 2 * c.latent_channels
+        y = ops.conv3x3(hN.view(1, H, W, x.shape[-1]), E["conv_out"][0], bias=E["conv_out"][1], out_dtype=torch.float32,
+                        n_valid=lc2)                                                 # [1, HW, 8] moments before quant_conv
+        pad = torch.zeros((H * W, 64), dtype=torch.float32, device=y.device)
+        ops.copy2d(y.view(H * W, lc2), pad, 0)
+        m = ops.gemm(ops.cast(pad, dt), E["quant"][0], bias=E["quant"][1], out_dtype=torch.float32, n_valid=lc2)
+        return ops.nhwc_to_nchw(m.view(1, H * W, lc2), c.latent_channels, H, W)     # mean = first latent_channels columns
+
+    @torch.no_grad()
+    def encode(self, x, return_dict=True):
+        """x: [B, 3, H, W] in [-1, 1]. Returns an object with ``.latent_dist.mode()`` (the reference's only use, :520-523)."""
+        if not self.has_encoder:
+            raise NotImplementedError("this AutoencoderKL was loaded without encoder.* / quant_conv.* weights")
+        self._pack()
+        x = x.to(device=self.device, dtype=torch.float32)
+        mean = torch.cat([self._encode_one(x[b:b + 1].contiguous()) for b in range(x.shape[0])], dim=0)
+        dist = SimpleNamespace(mode=lambda: mean, mean=mean)
+        out = SimpleNamespace(latent_dist=dist)
+        return out if return_dict else (dist,)

@@ -318,6 +318,10 @@ def test_vae_inventory_matches_oracle_and_param_count():
     sd.pop("decoder.conv_in.bias")
     with pytest.raises(KeyError):
         mini.load_state_dict(sd)
+    # encoder inventory: 34 163 592 + quant_conv 72; whole AutoencoderKL = the published 83 653 863
+    assert rv.vae_encoder_param_count(rv.FULL_VAE) == 34_163_592 + 72
+    assert rv.vae_encoder_param_count(rv.FULL_VAE) + rv.vae_decoder_param_count(rv.FULL_VAE) == 83_653_863
+    assert m.encoder_param_shapes() == rv.vae_encoder_param_shapes(rv.FULL_VAE)
 
 
 def test_vae_oracle_decode_shapes_cpu():
