@@ -306,15 +306,18 @@ def test_vae_inventory_matches_oracle_and_param_count():
     assert m.param_shapes() == rv.vae_decoder_param_shapes(rv.FULL_VAE)
     mini = AutoencoderKL(block_out_channels=(64, 128), layers_per_block=1)
     assert mini.param_shapes() == rv.vae_decoder_param_shapes(rv.MINI_VAE)
-    # pre-0.19 diffusers attention names are mapped; encoder keys are ignored; a missing decoder key raises
+    # pre-0.19 diffusers attention names are mapped; the encoder is optional but must be complete; a missing decoder key raises
     sd = rv.vae_sd(rv.MINI_VAE)
     a = "decoder.mid_block.attentions.0."
     for new, old in (("to_q", "query"), ("to_k", "key"), ("to_v", "value"), ("to_out.0", "proj_attn")):
         sd[a + old + ".weight"] = sd.pop(a + new + ".weight")[:, :, None, None]
         sd[a + old + ".bias"] = sd.pop(a + new + ".bias")
-    sd["encoder.conv_in.weight"] = torch.zeros(1)
     missing, _ = mini.load_state_dict(sd)
-    assert missing == [] and mini._sd[a + "to_q.weight"].dim() == 2
+    assert missing == [] and mini._sd[a + "to_q.weight"].dim() == 2 and not mini.has_encoder
+    with pytest.raises(KeyError):                                   # a partial encoder is a broken checkpoint
+        mini.load_state_dict(dict(sd, **{"encoder.conv_in.weight": torch.zeros(1)}))
+    mini.load_state_dict(dict(sd, **rv.vae_encoder_sd(rv.MINI_VAE)))
+    assert mini.has_encoder
     sd.pop("decoder.conv_in.bias")
     with pytest.raises(KeyError):
         mini.load_state_dict(sd)
