@@ -27,7 +27,7 @@ struct AttnP {
 };
 
 template <typename TT, int DP>
-__global__ __launch_bounds__(256) void attn_kernel(const AttnP p) {
+__global__ __launch_bounds__(256, (DP <= 64 ? 4 : 1)) void attn_kernel(const AttnP p) {  // D=64: 4 waves per SIMD (<= 128 VGPRs)
 #if defined(__HIP_DEVICE_COMPILE__)  // body uses gfx950-only builtins (LDS-DMA, MFMA); the host pass only needs the stub
   typedef typename TT::vec8 vec8;
   typedef typename TT::vec4 vec4;
@@ -171,10 +171,15 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnP p) {
           if (kv >= p.Skv || kv > kmax) s[jb][r] = -INFINITY;
         }
     }
-    float mloc = -INFINITY;
+    // the softmax is VALU-bound at head_dim 64 (32 exp + ~90 other VALU ops per lane per tile against 16 MFMAs): row max as
+    // two v_max3 chains (16 ops, no canonicalising copies), row sum as one v_dot2 per packed pair (16 ops instead of 32 adds)
+    float mloc = -INFINITY, mloc2 = -INFINITY;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, fmaxf(s[0][r], s[1][r]));
-    mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+    for (int r = 0; r < 16; r += 2) {
+      mloc = max3f(mloc, s[0][r], s[1][r]);
+      mloc2 = max3f(mloc2, s[0][r + 1], s[1][r + 1]);
+    }
+    mloc = max3f(mloc, mloc2, __shfl_xor(fmaxf(mloc, mloc2), 32, 64));
     const float m_new = fmaxf(m_run, mloc);
     const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
     const float alpha = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f((m_run - m_safe) * c);
@@ -191,8 +196,8 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnP p) {
         for (int j = 0; j < 4; ++j) {
           const float p0 = __builtin_amdgcn_exp2f(fmaf(s[jb][8 * s2 + 2 * j], c, mc));
           const float p1 = __builtin_amdgcn_exp2f(fmaf(s[jb][8 * s2 + 2 * j + 1], c, mc));
-          psum += p0 + p1;
           w[j] = pack2<TT>(p0, p1);
+          psum = TT::pair_sum(w[j], psum);          // sums the ROUNDED probabilities, i.e. exactly what P·V multiplies
         }
         __builtin_memcpy(&pb[2 * jb + s2], w, 16);
       }

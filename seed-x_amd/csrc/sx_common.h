@@ -57,6 +57,16 @@ struct BF16 {
   static __device__ __forceinline__ f32x16_t mfma32(vec8 a, vec8 b, f32x16_t c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
   }
+  // acc + lo + hi of a packed pair in ONE VALU op (v_dot2c_f32_bf16 against {1, 1})
+  static __device__ __forceinline__ float pair_sum(unsigned w, float acc) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef __bf16 e2_t __attribute__((ext_vector_type(2)));
+    const e2_t ones = {(__bf16)1.0f, (__bf16)1.0f};
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(e2_t, w), ones, acc, false);
+#else
+    return acc;
+#endif
+  }
 };
 struct F16 {
   typedef _Float16 elem;
@@ -79,7 +89,27 @@ struct F16 {
   static __device__ __forceinline__ f32x16_t mfma32(vec8 a, vec8 b, f32x16_t c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
   }
+  static __device__ __forceinline__ float pair_sum(unsigned w, float acc) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef _Float16 e2_t __attribute__((ext_vector_type(2)));
+    const e2_t ones = {(_Float16)1.0f, (_Float16)1.0f};
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(e2_t, w), ones, acc, false);
+#else
+    return acc;
+#endif
+  }
 };
+
+// max(a, b, c) in one VALU op. fmaxf() costs an extra canonicalising v_max per operand under IEEE semantics.
+__device__ __forceinline__ float max3f(float a, float b, float c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+#else
+  return a;
+#endif
+}
 
 // pack two floats -> two 16-bit values in one dword (vector convert → v_cvt_pk_bf16_f32 / v_cvt_f16_f32 pairs)
 template <typename TT>
