@@ -6,7 +6,8 @@
 //   * S^T = K · Q^T with v_mfma_f32_32x32x16: the lane that owns query q = lane&31 holds 16 of the 32
 //     scores of a key block in registers → row max / row sum are lane-local plus ONE lane^32 exchange
 //   * O^T = V^T · P^T reuses the score registers directly as the MFMA B operand: the contraction order
-//     over keys is permuted (k-slot (hi,j) ↔ key 4*hi + {0..3, 8..11}[j]) identically on the V^T side, so
+//     over keys is permuted by loading the K rows of a tile in the order r ↔ key swap_bits23(r): lane-half hi then owns
+//     the keys 8hi..8hi+7 of every 16-key step = one 16-B piece of a V^T row (single ds_read_b128), so
 //     no cross-lane shuffle / LDS round trip of P is needed
 //   * V is transposed once per call by sx_transpose_v (V^T rows are key-contiguous), so both MFMA
 //     operands are plain "k-contiguous" LDS rows read with ds_read_b128 / ds_read_b64, XOR-swizzled
@@ -77,7 +78,10 @@ __global__ __launch_bounds__(256, (DP <= 64 ? 4 : 1)) void attn_kernel(const Att
     const int pos = lane % KCH;
     const int key = (KCH == 16) ? (r & 15) : ((r >> 1) & 7);
     const int c = pos ^ key;
-    k_row[i] = r;
+    // LDS row r holds KEY perm(r) = r with bits 2 and 3 swapped: the 32x32 MFMA leaves lane-half `hi` with S^T rows
+    // {4hi+i, 8+4hi+i, ...}; with this order those are the keys 8hi .. 8hi+7 of each 16-key step, i.e. ONE contiguous
+    // 16-B piece of a V^T row, so the P·V operand is a single ds_read_b128 (no 8-B halves to stitch with v_mov)
+    k_row[i] = (r & ~0xC) | ((r & 4) << 1) | ((r & 8) >> 1);
     k_off[i] = (c * 8 < p.D) ? (unsigned)(c * 16) : 0x80000000u;
   }
   // V^T: slot s holds 8 rows (d) of 128 B; lane -> (row_in_slot = lane>>3, pos = lane&7), key = (d>>1)&7
@@ -133,14 +137,14 @@ __global__ __launch_bounds__(256, (DP <= 64 ? 4 : 1)) void attn_kernel(const Att
   // K frag (A operand): row = 32jb + (lane&31), logical chunk = 2ks + hi
   const int kkey = (KCH == 16) ? (lq & 15) : ((lq >> 1) & 7);
   const unsigned k_rd = (unsigned)lq * KROW;
-  // V^T frag (A operand of O^T): row d = 32dt + (lane&31); 8-B reads at chunk (4jb+2s2), (4jb+2s2+1), half hi
+  // V^T frag (A operand of O^T): row d = 32dt + (lane&31); keys 16kk + 8hi .. +7 = 16-B chunk (2kk + hi)
   const int vkey = (lq >> 1) & 7;
-  const unsigned v_rd = (unsigned)lq * 128u + (unsigned)hi * 8u;
+  const unsigned v_rd = (unsigned)lq * 128u;
 
   if (nt > 0) stage(0, 0);
   __syncthreads();
-  for (int kvt = 0; kvt < nt; ++kvt) {
-    const int cur = kvt & 1;
+  // one KV tile; `cur` is a literal at both call sites, so every LDS offset folds into the ds_read immediates
+  auto tile = [&](const int cur, const int kvt) {
     if (kvt + 1 < nt) stage(cur ^ 1, kvt + 1);
     const unsigned char* sK = smem + cur * STAGE;
     const unsigned char* sV = sK + K_BYTES;
@@ -167,7 +171,7 @@ __global__ __launch_bounds__(256, (DP <= 64 ? 4 : 1)) void attn_kernel(const Att
       for (int jb = 0; jb < 2; ++jb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int kv = kv0 + 32 * jb + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          const int kv = kv0 + 32 * jb + (r & 3) + 4 * ((r >> 2) & 1) + 8 * hi + 16 * (r >> 3);  // key of S^T row (see k_row)
           if (kv >= p.Skv || kv > kmax) s[jb][r] = -INFINITY;
         }
     }
@@ -214,16 +218,15 @@ __global__ __launch_bounds__(256, (DP <= 64 ? 4 : 1)) void attn_kernel(const Att
     for (int dt = 0; dt < NDT; ++dt) {
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {  // kk = 2jb + s2 : 16 keys
-        const unsigned char* vr = sV + dt * 32 * 128 + v_rd;
-        const u32x2_t lo = *(const u32x2_t*)(vr + (((2 * kk) ^ vkey) << 4));
-        const u32x2_t hh = *(const u32x2_t*)(vr + (((2 * kk + 1) ^ vkey) << 4));
-        u32x4_t raw = {lo[0], lo[1], hh[0], hh[1]};
-        vec8 vf;
-        __builtin_memcpy(&vf, &raw, 16);
+        const vec8 vf = *(const vec8*)(sV + dt * 32 * 128 + v_rd + (((2 * kk + hi) ^ vkey) << 4));
         o[dt] = TT::mfma32(vf, pb[kk], o[dt]);
       }
     }
     __syncthreads();
+  };
+  for (int kvt = 0; kvt < nt; kvt += 2) {
+    tile(0, kvt);
+    if (kvt + 1 < nt) tile(1, kvt + 1);
   }
 
   // ---- epilogue: O[q][d] = o / l ------------------------------------------------------------------------
