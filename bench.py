@@ -110,7 +110,7 @@ def make_inputs(dev, seed=0):
     return image, patch_pos, ids, mask
 
 
-BATCH = 8   # generations processed together per step on one GPU (set from --batch)
+BATCH = 16  # generations processed together per step on one GPU (set from --batch)
 
 
 def front_half(vit, agent, tok, inp, n_text):
@@ -282,7 +282,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay (profiling aid)")
     ap.add_argument("--overlap", type=int, default=0,
                     help="1: pipeline consecutive requests on two streams (LLM decode of request i+1 under the UNet of request i)")
-    ap.add_argument("--batch", type=int, default=8,
+    ap.add_argument("--batch", type=int, default=16,
                     help="independent generations processed together per GPU per step (1 = single-request latency mode)")
     ap.add_argument("--no-vae", action="store_true", help="stop at the denoised latents (no VAE decode)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
