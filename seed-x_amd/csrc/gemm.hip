@@ -4,9 +4,10 @@
 //
 // Replaces every nn.Linear / nn.Conv2d(3x3) on the SEED-X hot path (see include/seedx_hip.h for the
 // reference call sites). Design:
-//   * block = 4 waves laid out WM x WN over a BM x BN x 64 tile; each wave owns (BM/WM)x(BN/WN) as
-//     16x16x32 MFMA fragments. Tile shapes: 128x128 (2x2), 128x80 (4x1: N = 320/640/1280 of the SDXL UNet
-//     divide into exactly k·256 tiles), 64x128, 64x64 — picked per problem to fill the 256 CUs
+//   * block = 4 or 8 waves (8 = 2 per SIMD) laid out WM x WN over a BM x BN x 64 tile; each wave owns (BM/WM)x(BN/WN) as
+//     16x16x32 MFMA fragments. Tile menu: 128x128 (2x2), 128x80 (4x1), 64x128, 64x64 with 4 waves; 256x256 (2x4), 256x320
+//     (2x4), 256x160 (4x2) with 8 waves. N of the SDXL UNet is k*320, so the x320 / x160 / x80 tiles split it without a
+//     ragged last tile and land on whole rounds of 256 tiles; pick_tile() takes the argmin of a fitted cost model
 //   * A and W tiles are DMA'd HBM→LDS with `buffer_load_dwordx4 … lds` (no VGPR round trip); rows
 //     beyond M / N and zero-padding taps of the convolution use the buffer descriptor's range check
 //     (offset >= num_records returns 0), so there is no edge code in the main loop
@@ -17,7 +18,8 @@
 //     across the barrier and is retired with a COUNTED `s_waitcnt vmcnt(N)` (never a drain in steady state)
 //   * operands are swapped in the MFMA (D = Wfrag · Afrag^T) so a lane ends up with 4 CONSECUTIVE output
 //     columns of one row → vector bias/residual loads and 8/16-byte stores in the fused epilogue
-//   * 1-D grid with a bijective XCD remap: consecutive tiles (same W panel) share one XCD's L2
+//   * 1-D grid; block b runs on XCD b % 8, each XCD owns a compact rectangle of the tile grid and walks it in groups of
+//     8 tile-rows, so its private 4-MB L2 serves most operand re-reads (small grids: bijective XCD remap)
 #include "sx_common.h"
 
 namespace sxk_gemm {
