@@ -188,7 +188,12 @@ def gemm_roofline(vit, agent, adapter, tok, inp, steps_unet, n_text):
             s.record()
             r = real(args_ref, stream)
             e.record()
-            rec.append((2.0 * a.M * a.N * a.K, s, e))
+            n_out = a.N // 2 if a.glu else a.N
+            n_st = a.n_valid if a.n_valid else n_out
+            a_bytes = 2.0 * (a.B * a.Hin * a.Win * a.Cin if a.a_mode == 1 else a.M * a.K)   # operands once + output once
+            byt = a_bytes + 2.0 * a.N * a.K + a.M * n_st * (4.0 if a.out_dtype == 2 else 2.0) \
+                + (4.0 * a.M * n_st if a.residual else 0.0)
+            rec.append((2.0 * a.M * a.N * a.K, s, e, byt))
             return r
 
     agent.use_graph, adapter._loop.use_graph = False, False
@@ -199,12 +204,25 @@ def gemm_roofline(vit, agent, adapter, tok, inp, steps_unet, n_text):
     finally:
         lib.sx_gemm = real
         agent.use_graph, adapter._loop.use_graph = True, True
-    ms = [s.elapsed_time(e) for _, s, e in rec]
-    fl = sum(f for f, _, _ in rec)
+    ms = [s.elapsed_time(e) for _, s, e, _ in rec]
+    fl = sum(r_[0] for r_ in rec)
+    alg_bytes = sum(r_[3] for r_ in rec)
     tot_s = sum(ms) * 1e-3
     n = len(rec)
+    # traffic: bytes per launch from the rocprofv3 --pmc passes of THIS command (tools/bench_pmc_traffic.py; graph replay
+    # crashes the counter collection on this pool, so the passes run the same step with eager launches). Only quoted
+    # when the stored profile was taken at the batch size being run.
+    traffic, tnote = None, "no PMC profile for this batch size"
+    try:
+        prof = json.load(open(os.path.join(ROOT, "profiles", "r1_bench_pmc_traffic.json")))
+        if prof.get("batch_per_gpu") == BATCH:
+            traffic, tnote = prof["traffic_bytes_per_launch"], prof["method"]
+    except (OSError, ValueError, KeyError):
+        pass
     return {"bound": "mfma", "achieved": fl / tot_s / 1e12, "peak": PEAK_TFLOPS_16BIT, "unit": "TFLOP/s",
-            "frac": fl / tot_s / 1e12 / PEAK_TFLOPS_16BIT, "traffic": None, "kernel": "sxk_gemm::gemm_kernel<*>",
+            "frac": fl / tot_s / 1e12 / PEAK_TFLOPS_16BIT, "traffic": traffic, "traffic_unit": "bytes/launch",
+            "traffic_source": tnote, "algorithmic_bytes_per_launch": alg_bytes / n,
+            "kernel": "sxk_gemm::gemm_kernel<*>",
             "launches_per_step": n, "avg_launch_us": tot_s / n * 1e6, "avg_launch_gflop": fl / n / 1e9,
             "gemm_time_s_per_step": tot_s}
 
