@@ -332,3 +332,94 @@ def test_vae_oracle_decode_shapes_cpu():
     sd = rv.vae_sd(rv.MINI_VAE)
     y = rv.vae_decode(sd, rv.MINI_VAE, torch.randn(1, 4, 8, 8, generator=torch.Generator().manual_seed(0)))
     assert y.shape == (1, 3, 16, 16) and torch.isfinite(y).all()
+
+
+# ---- on-disk checkpoint formats: every from_pretrained() against files written in the layout the
+# ---- reference's configs point at (tiny synthetic weights; packing to the GPU is exercised by the -m gpu tests) --------
+def test_from_pretrained_reads_reference_checkpoint_layouts(tmp_path):
+    import json
+    from safetensors.torch import save_file
+    from oracle import restated_vae as rv
+    from seedx_amd.detokenizer import EulerDiscreteScheduler, ResamplerXLV2, SDXLAdapter
+    from seedx_amd.llama import LlamaForCausalLM
+    from seedx_amd.seed_x import ContinuousLVLM
+    from seedx_amd.unet import UNet2DConditionModel
+    from seedx_amd.vae import AutoencoderKL
+    from seedx_amd.visual_encoder import Resampler, VisionTransformerWithAttnPool
+
+    # (1) pretrained/QwenViT/qwen_vit_G.pt: torch pickle of the visual state dict (reload_qwen_vit.py:9-13)
+    vcfg = weights.MINI_VIT
+    vsd = weights.vit_sd(vcfg)
+    torch.save(vsd, tmp_path / "qwen_vit_G.pt")
+    vit = VisionTransformerWithAttnPool.from_pretrained(pretrained_model_path=str(tmp_path / "qwen_vit_G.pt"), **vcfg)
+    assert set(vit.expected_keys()) - {"attn_pool.pos_embed"} <= set(vsd)
+
+    # (2) HF Llama directory: config.json + safetensors shard (llm_seed_x_i.yaml:1-3)
+    lcfg = weights.MINI_LLM
+    ldir = tmp_path / "llm"
+    ldir.mkdir()
+    json.dump(dict(lcfg, architectures=["LlamaForCausalLM"], model_type="llama"), open(ldir / "config.json", "w"))
+    lsd = {k: v.contiguous() for k, v in weights.llama_sd(lcfg).items()}
+    save_file(lsd, str(ldir / "model-00001-of-00001.safetensors"))
+    llm = LlamaForCausalLM.from_pretrained(str(ldir), torch_dtype=torch.bfloat16, max_cache_len=64)
+    assert llm.H == lcfg["hidden_size"] and llm.L == lcfg["num_hidden_layers"] and llm.dtype == torch.bfloat16
+    assert set(llm.expected_keys()) <= set(llm._sd)
+
+    # (3) agent/pytorch_model.bin: input_resampler.* / output_resampler.* / patch_pos_embed (seed_x.py:231-233)
+    asd = weights.agent_sd(lcfg, 128, in_grid=4, out_grid=4)
+    torch.save(asd, tmp_path / "agent.bin")
+    H = lcfg["hidden_size"]
+    agent = ContinuousLVLM.from_pretrained(llm, Resampler(4, H, 2, kv_dim=128), Resampler(4, 128, 2, kv_dim=H),
+                                           pretrained_model_path=str(tmp_path / "agent.bin"), add_patch_pos=True)
+    assert agent.patch_pos_embed is not None
+
+    # (4) diffusers unet/ directory: config.json + diffusion_pytorch_model.safetensors (eval_seed_x_detokenizer.py:30-36)
+    ucfg = ru.MINI_UNET
+    udir = tmp_path / "sdxl" / "unet"
+    udir.mkdir(parents=True)
+    boc = ucfg["block_out_channels"]
+    json.dump(dict(in_channels=ucfg["in_channels"], out_channels=ucfg["out_channels"], block_out_channels=list(boc),
+                   layers_per_block=ucfg["layers_per_block"], transformer_layers_per_block=list(ucfg["transformer_layers"]),
+                   attention_head_dim=list(ucfg["heads"]), cross_attention_dim=ucfg["cross_attention_dim"],
+                   addition_time_embed_dim=ucfg["addition_time_embed_dim"],
+                   projection_class_embeddings_input_dim=ucfg["pooled_dim"] + 6 * ucfg["addition_time_embed_dim"],
+                   norm_num_groups=ucfg["norm_groups"], sample_size=16,
+                   down_block_types=["DownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D"],
+                   up_block_types=["CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "UpBlock2D"]), open(udir / "config.json", "w"))
+    save_file({k: v.contiguous() for k, v in ru.unet_sd(ucfg).items()}, str(udir / "diffusion_pytorch_model.safetensors"))
+    unet = UNet2DConditionModel.from_pretrained(str(tmp_path / "sdxl"), subfolder="unet")
+    assert unet.cfg["block_out_channels"] == tuple(boc) and unet.cfg["pooled_dim"] == ucfg["pooled_dim"]
+
+    # (5) scheduler/scheduler_config.json
+    sdir = tmp_path / "sdxl" / "scheduler"
+    sdir.mkdir()
+    json.dump(dict(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
+                   steps_offset=1, timestep_spacing="leading", prediction_type="epsilon"), open(sdir / "scheduler_config.json", "w"))
+    sch = EulerDiscreteScheduler.from_pretrained(str(tmp_path / "sdxl"), subfolder="scheduler")
+    sch.set_timesteps(50)
+    assert float(sch.timesteps[0]) == 981.0 and len(sch.sigmas) == 51
+
+    # (6) vae/ directory (decoder + encoder), .bin fallback
+    vdir = tmp_path / "sdxl" / "vae"
+    vdir.mkdir()
+    mv = rv.MINI_VAE
+    json.dump(dict(in_channels=3, out_channels=3, block_out_channels=list(mv["block_out_channels"]),
+                   layers_per_block=mv["layers_per_block"], latent_channels=4, norm_num_groups=32,
+                   scaling_factor=0.13025, force_upcast=True, act_fn="silu"), open(vdir / "config.json", "w"))
+    torch.save(dict(rv.vae_sd(mv), **rv.vae_encoder_sd(mv)), vdir / "diffusion_pytorch_model.bin")
+    vae = AutoencoderKL.from_pretrained(str(tmp_path / "sdxl"), subfolder="vae")
+    assert vae.has_encoder and vae.config.scaling_factor == 0.13025 and vae.config.force_upcast
+
+    # (7) seed_detokenizer/*/pytorch_model.bin: resampler.* + unet.* (adapter_modules.py:62-65)
+    xcfg = weights.MINI_XLV2
+    ck = dict(weights.xlv2_sd(xcfg))
+    ck.update({"unet." + k: v for k, v in ru.unet_sd(ucfg).items()})
+    torch.save(ck, tmp_path / "detok.bin")
+    ad = SDXLAdapter.from_pretrained(UNet2DConditionModel(**ucfg), ResamplerXLV2(normalize=False, **xcfg),
+                                     pretrained_model_path=str(tmp_path / "detok.bin"))
+    assert ad.unet._sd is not None and ad.resampler is not None
+    ck.pop("unet.conv_in.weight")
+    torch.save(ck, tmp_path / "detok_bad.bin")
+    with pytest.raises(KeyError):
+        SDXLAdapter.from_pretrained(UNet2DConditionModel(**ucfg), ResamplerXLV2(normalize=False, **xcfg),
+                                    pretrained_model_path=str(tmp_path / "detok_bad.bin"))
