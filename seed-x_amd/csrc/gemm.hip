@@ -358,8 +358,8 @@ int launch_cfg(const GemmP& p0, int a_mode, hipStream_t st) {
 // tile menu + cost model. One launch runs ceil(tiles / slots) rounds over the chip (slots = 256 CUs x co-resident blocks) and
 // a round costs a + b*K microseconds (prologue/epilogue + per-k-tile time). The constants are a least-squares fit of the
 // MI355X sweep tools/bench_tile_model.py (profiles/r1_tile_model.jsonl): every tile config forced over the UNet linear and
-// conv shapes at CFG batch 2..16, the ViT-G and the Llama shapes. Picking argmin of the model is within 0.4 % (linear) /
-// 0.0 % (conv) of the per-shape best config on that sweep; the N = k*320 channel counts of the SDXL UNet are why the
+// conv shapes at CFG batch 2..32, the ViT-G and the Llama shapes. Picking argmin of the model is within 0.2 % (linear) /
+// 0.1 % (conv) of the per-shape best config on the re-run of that sweep with the final kernels (worst shape 9 %); the N = k*320 channel counts of the SDXL UNet are why the
 // 256x320 / 256x160 tiles exist (they split N without a ragged last tile and land on whole rounds of 256 tiles).
 struct TileCfg { int bm, bn; bool glu_ok; int slots; float a_lin, b_lin, a_conv, b_conv; };
 static const int kNumTiles = 7;
