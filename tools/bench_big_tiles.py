@@ -1,6 +1,6 @@
 """A/B of the 8-wave GEMM tiles: cfg 4 = 256x256, cfg 5 = 256x320, cfg 6 = 256x160 (N of the SDXL UNet is k*320).
 
-Run on the GPU box: python tools/bench_pp.py
+Run on the GPU box: python tools/bench_big_tiles.py
 """
 import os
 import sys

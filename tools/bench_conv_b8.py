@@ -1,3 +1,4 @@
+"""Conv3x3 tile sweep at CFG batch 16 (batch 8 generations): which 8-wave tile wins per UNet resolution. GPU box only."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
