@@ -261,7 +261,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const GemmP p) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           f32x4_t x = v[i + h];
-          if (p.act != SX_ACT_NONE) {
+          if (p.act == SX_ACT_GELU) {
+            const f32x2_t g0 = gelu_erf2((f32x2_t){x[0], x[1]}), g1 = gelu_erf2((f32x2_t){x[2], x[3]});
+            x = (f32x4_t){g0[0], g0[1], g1[0], g1[1]};
+          } else if (p.act != SX_ACT_NONE) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) x[r] = apply_act(x[r], p.act);
           }
@@ -289,8 +292,16 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const GemmP p) {
       if (p.glu) {
         if (i & 1) continue;
         const f32x4_t g = v[(i + 1) < FN ? (i + 1) : i];
+        if (p.act == SX_ACT_GELU) {   // GEGLU (SDXL feed-forward): packed-fp32 GELU, two gates per VALU issue
+          const f32x2_t g0 = gelu_erf2((f32x2_t){g[0], g[1]}), g1 = gelu_erf2((f32x2_t){g[2], g[3]});
+          v[i][0] *= g0[0]; v[i][1] *= g0[1]; v[i][2] *= g1[0]; v[i][3] *= g1[1];
+        } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[i][r] = v[i][r] * apply_act(g[r], p.act);
+          for (int r = 0; r < 4; ++r) v[i][r] = v[i][r] * apply_act(g[r], p.act);
+        }
+      } else if (p.act == SX_ACT_GELU) {
+        const f32x2_t g0 = gelu_erf2((f32x2_t){v[i][0], v[i][1]}), g1 = gelu_erf2((f32x2_t){v[i][2], v[i][3]});
+        v[i] = (f32x4_t){g0[0], g0[1], g1[0], g1[1]};
       } else if (p.act != SX_ACT_NONE) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[i][r] = apply_act(v[i][r], p.act);

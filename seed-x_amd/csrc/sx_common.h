@@ -150,6 +150,25 @@ __device__ __forceinline__ float gelu_erf(float x) {
   const float h = 0.5f * x;
   return fmaf(copysignf(erf_abs, x), h, h);               // 0.5 x (1 + erf(x/sqrt2))
 }
+// two GELUs at once on <2 x float>: the polynomial / product part becomes v_pk_fma_f32 / v_pk_mul_f32 (2 lanes-worth per
+// issue); only the reciprocal and the exponential stay scalar. Same formula and constants as gelu_erf().
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2_t gelu_erf2(f32x2_t x) {
+  const f32x2_t ax = {fabsf(x[0]), fabsf(x[1])};
+  const f32x2_t z = ax * 0.70710678118654752440f;
+  const f32x2_t d = z * 0.3275911f + 1.0f;
+  const f32x2_t t = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+  f32x2_t pl = t * 1.061405429f + (-1.453152027f);
+  pl = pl * t + 1.421413741f;
+  pl = pl * t + (-0.284496736f);
+  pl = pl * t + 0.254829592f;
+  const f32x2_t a = z * z * (-1.4426950408889634f);
+  const f32x2_t e = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
+  const f32x2_t erf_abs = 1.0f - pl * t * e;
+  const f32x2_t h = x * 0.5f;
+  const f32x2_t sg = {copysignf(erf_abs[0], x[0]), copysignf(erf_abs[1], x[1])};
+  return sg * h + h;
+}
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float apply_act(float x, int act) {
   if (act == SX_ACT_GELU) return gelu_erf(x);
