@@ -183,65 +183,62 @@ __global__ __launch_bounds__(320) void gn_stats_kernel(const float* x, double* s
   for (int i = threadIdx.x; i < 2 * groups; i += T) atomicAdd(&stats[(size_t)b * groups * 2 + i], (double)acc[i]);
 }
 
+// apply: y = (x - mean) * rstd * gamma + beta (+ SiLU), optional 16-bit raw copy. Per-channel scale / shift are built ONCE per
+// block in LDS (fp64 statistics → fp32 pair), then the block streams its rows as one flat run of float4 (a block's rows are
+// contiguous in memory), 4 loads in flight per thread — every one of the 256 threads is busy whatever C is (C = 320 / 640
+// left 31-62 % of the lanes idle when threads were tied to channel quads).
+constexpr int GN_MAX_C = 3072;
 __global__ __launch_bounds__(256) void gn_apply_kernel(const float* x, void* y, void* raw16, int out_dt,
                                                        const float* gamma, const float* beta, const double* stats,
                                                        int HW, int C, int groups, float eps, int silu,
                                                        int rows_per_block) {
+  __shared__ __attribute__((aligned(16))) float s_sc[GN_MAX_C], s_sh[GN_MAX_C];
   const int b = blockIdx.y;
   const int r0 = blockIdx.x * rows_per_block;
   const int r1 = min(HW, r0 + rows_per_block);
   const int n4 = C >> 2, cpg = C / groups;
   const double cnt = (double)HW * cpg;
-  f32x4_t sc[GN_MAX_SLOTS4], sh[GN_MAX_SLOTS4];
-#pragma unroll
-  for (int k = 0; k < GN_MAX_SLOTS4; ++k) {
-    const int qi = threadIdx.x + k * 256;
-    if (qi < n4) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int c = qi * 4 + e;
-        const int g = c / cpg;
-        const double su = stats[((size_t)b * groups + g) * 2], sq = stats[((size_t)b * groups + g) * 2 + 1];
-        const double mean = su / cnt;
-        double var = sq / cnt - mean * mean;
-        if (var < 0) var = 0;
-        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-        const float ga = gamma[c] * rstd;
-        sc[k][e] = ga;
-        sh[k][e] = beta[c] - (float)mean * ga;
-      }
-    }
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const int g = c / cpg;
+    const double su = stats[((size_t)b * groups + g) * 2], sq = stats[((size_t)b * groups + g) * 2 + 1];
+    const double mean = su / cnt;
+    double var = sq / cnt - mean * mean;
+    if (var < 0) var = 0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float ga = gamma[c] * rstd;
+    s_sc[c] = ga;
+    s_sh[c] = beta[c] - (float)mean * ga;
   }
-  const size_t bbase4 = (size_t)b * HW * n4;
-  auto one = [&](int r, int k, const f32x4_t v) {
-    const size_t idx = bbase4 + (size_t)r * n4 + threadIdx.x + k * 256;
-    f32x4_t o = v * sc[k] + sh[k];
+  __syncthreads();
+  const size_t base4 = ((size_t)b * HW + r0) * n4;          // first float4 of this block's rows
+  const int total = (r1 - r0) * n4;
+  const f32x4_t* x4 = (const f32x4_t*)x + base4;
+  auto one = [&](int i, int qi, const f32x4_t v) {
+    f32x4_t o = v * *(const f32x4_t*)(s_sc + 4 * qi) + *(const f32x4_t*)(s_sh + 4 * qi);
     if (silu) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = silu_f(o[e]);
     }
-    store4(y, out_dt, idx, o);
-    if (raw16) store4(raw16, out_dt, idx, v);
+    store4(y, out_dt, base4 + i, o);
+    if (raw16) store4(raw16, out_dt, base4 + i, v);
   };
-  int r = r0;
-  for (; r + 1 < r1; r += 2) {
-#pragma unroll
-    for (int k = 0; k < GN_MAX_SLOTS4; ++k) {
-      const int qi = threadIdx.x + k * 256;
-      if (qi < n4) {
-        const f32x4_t v0 = ((const f32x4_t*)x)[bbase4 + (size_t)r * n4 + qi];
-        const f32x4_t v1 = ((const f32x4_t*)x)[bbase4 + (size_t)(r + 1) * n4 + qi];
-        one(r, k, v0);
-        one(r + 1, k, v1);
-      }
-    }
+  const int step = 256 % n4;                                // channel-quad index advances by 256 mod n4 per stride
+  int qi = threadIdx.x % n4;
+  int i = threadIdx.x;
+  for (; i + 768 < total; i += 1024) {
+    int q1 = qi + step; q1 -= (q1 >= n4) ? n4 : 0;
+    int q2 = q1 + step; q2 -= (q2 >= n4) ? n4 : 0;
+    int q3 = q2 + step; q3 -= (q3 >= n4) ? n4 : 0;
+    const f32x4_t v0 = x4[i], v1 = x4[i + 256], v2 = x4[i + 512], v3 = x4[i + 768];
+    one(i, qi, v0);
+    one(i + 256, q1, v1);
+    one(i + 512, q2, v2);
+    one(i + 768, q3, v3);
+    qi = q3 + step; qi -= (qi >= n4) ? n4 : 0;
   }
-  for (; r < r1; ++r) {
-#pragma unroll
-    for (int k = 0; k < GN_MAX_SLOTS4; ++k) {
-      const int qi = threadIdx.x + k * 256;
-      if (qi < n4) one(r, k, ((const f32x4_t*)x)[bbase4 + (size_t)r * n4 + qi]);
-    }
+  for (; i < total; i += 256) {
+    one(i, qi, x4[i]);
+    qi += step; qi -= (qi >= n4) ? n4 : 0;
   }
 }
 
@@ -336,7 +333,7 @@ extern "C" int sx_groupnorm(const float* x, void* y, void* raw16, int out_dtype,
   SX_CHECK(out_dtype == SX_F16 || out_dtype == SX_BF16, "sx_groupnorm: output must be 16-bit");
   SX_CHECK(groups > 0 && groups <= 64 && C % groups == 0, "sx_groupnorm: C=%d groups=%d", C, groups);
   SX_CHECK(C % 4 == 0 && (C / groups) % 2 == 0, "sx_groupnorm: C %% 4 and (C/groups) %% 2 must be 0 (C=%d)", C);
-  SX_CHECK(C / 2 <= 256 * GN_MAX_SLOTS2, "sx_groupnorm: C=%d too large", C);
+  SX_CHECK(C / 2 <= 256 * GN_MAX_SLOTS2 && C <= GN_MAX_C, "sx_groupnorm: C=%d too large", C);
   hipStream_t st = (hipStream_t)stream;
   if (hipMemsetAsync(stats, 0, sizeof(double) * 2 * B * groups, st) != hipSuccess) {
     sx_set_error("sx_groupnorm: hipMemsetAsync failed");
