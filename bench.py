@@ -374,6 +374,9 @@ def main():
             except Exception as ex:  # the oracle is optional infrastructure; never fail the measurement on it
                 rec["cpu_baseline"] = {"error": repr(ex)}
         print(json.dumps(rec), flush=True)
+    du.barrier(ctx)                 # rank 0 ran the instrumented roofline pass alone: tear the group down together
+    if world > 1:
+        torch.cuda.synchronize()
     du.finalize(ctx)
 
 
