@@ -82,6 +82,8 @@ int sx_gemm(const sx_gemm_args* args, void* stream);
 /* tuning/test hook: force tile config 0..6 (128x128, 128x80, 64x128, 64x64, 256x256, 256x320, 256x160); -1 = automatic
  * (cost model); 100/101 = 2-D XCD partition off/on; 300+g = g tile-rows per in-XCD traversal group (300 = default) */
 int sx_gemm_force_tile(int cfg);
+/* host-only query (no launch): tile config 0..6 the cost model picks for an M x N x K problem (glu / conv3x3 flags) */
+int sx_gemm_pick_tile(int M, int N, int K, int glu, int conv);
 
 /* 1..16-row GEMV for single-token decode of up to 16 lock-step sequences (HBM-bound weight streaming).
  * replaces: the same nn.Linear calls at q_len == 1 (modeling_llama_xformer.py:204-206,239,166-167,707).

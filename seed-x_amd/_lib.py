@@ -54,6 +54,7 @@ SIGNATURES = {
     "sx_version": [],
     "sx_gemm": [C.POINTER(GemmArgs), c_vp],
     "sx_gemm_force_tile": [c_i32],
+    "sx_gemm_pick_tile": [c_i32, c_i32, c_i32, c_i32, c_i32],
     "sx_gemv": [C.POINTER(GemvArgs), c_vp],
     "sx_gemv_force_valu": [c_i32],
     "sx_layernorm": [c_vp, c_i32, c_vp, c_i32, c_vp, c_vp, c_i32, c_i32, c_f32, c_i32, c_vp],

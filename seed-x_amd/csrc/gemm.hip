@@ -399,6 +399,10 @@ inline int pick_tile(int M, int N, int K, bool glu, bool conv, int force) {
 using namespace sxk_gemm;
 
 static int g_force_tile = -1;
+extern "C" int sx_gemm_pick_tile(int M, int N, int K, int glu, int conv) {  // host-only: which tile config sx_gemm would use
+  return sxk_gemm::pick_tile(M, N, K, glu != 0, conv != 0, -1);
+}
+
 extern "C" int sx_gemm_force_tile(int cfg) {  // tuning / test hook: -1 = automatic; 100/101 = 2-D XCD partition off/on
   if (cfg == 100 || cfg == 101) { sxk_gemm::g_xcd_2d = cfg - 100; return SX_OK; }
   if (cfg >= 300 && cfg <= 364) { sxk_gemm::g_gm = cfg - 300; return SX_OK; }

@@ -423,3 +423,28 @@ def test_from_pretrained_reads_reference_checkpoint_layouts(tmp_path):
     with pytest.raises(KeyError):
         SDXLAdapter.from_pretrained(UNet2DConditionModel(**ucfg), ResamplerXLV2(normalize=False, **xcfg),
                                     pretrained_model_path=str(tmp_path / "detok_bad.bin"))
+
+
+def test_gemm_tile_picker_host_logic():
+    """pick_tile() is pure host code (cost model fitted on the MI355X sweep): check the decisions the bench relies on,
+    through the C-ABI query, without launching anything."""
+    from seedx_amd import _lib
+    lib = _lib.load()
+    names = ["128x128", "128x80", "64x128", "64x64", "256x256", "256x320", "256x160"]
+    pick = lambda M, N, K, glu=0, conv=0: names[lib.sx_gemm_pick_tile(M, N, K, glu, conv)]
+    # SDXL channel counts are k*320: whole rounds of 256 tiles beat the ragged 256x256 grid
+    assert pick(16384, 1280, 1280) == "256x320"          # 64 x 4 = 256 tiles = one round
+    assert pick(8192, 1280, 1280) == "256x160"           # 32 x 8 = 256 tiles
+    assert pick(65536, 640, 2560) == "256x320"
+    assert pick(8192, 8192, 8192) == "256x256"
+    # GEGLU projections may only use GLU-capable tiles (32-row [linear|gate] groups inside one wave)
+    assert pick(16384, 10240, 1280, glu=1) in ("256x256", "128x128", "64x128", "64x64")
+    assert pick(16384, 10240, 1280, glu=1) == "256x256"
+    # small problems (batch-1 UNet, LLM prefill) stay on the 4-wave tiles
+    assert pick(2048, 1280, 1280) in ("64x64", "64x128", "128x80")
+    assert pick(165, 15360, 5120) in ("64x128", "64x64")
+    # convs: N = 320 is a single 256x320 column at CFG batch 16+, 256x160 at batch 1
+    assert pick(262144, 320, 2880, conv=1) == "256x320"
+    assert pick(32768, 320, 2880, conv=1) == "256x160"
+    for M, N, K in [(1, 64, 64), (7, 5120, 5120), (1000000, 128, 1152)]:
+        assert 0 <= lib.sx_gemm_pick_tile(M, N, K, 0, 0) <= 6
