@@ -259,6 +259,38 @@ int sx_cfg_euler_step(const float* eps, float* latents, float* scaled_next, cons
                       const int32_t* step_dev, int nb, int64_t n, int C, int ld_scaled, float gs, float igs, int mode,
                       void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Image pre/post-processing: the byte work either side of the dense paths.
+ * ------------------------------------------------------------------------------------------------ */
+/* Pillow `Image.resize` for 8-bit images (ImagingResample, Resample.c [ext Pillow]), bit exact: separable antialiased
+ * convolution in 22-bit fixed point, horizontal pass (→ uint8) then vertical pass (→ uint8).
+ * replaces: `image.resize(...)` (default BICUBIC) at src/inference/any_res.py:104,111,183,187 and torchvision
+ * `transforms.Resize` on PIL input (BILINEAR) at src/processer/transforms.py:8-14.
+ * src: [Hin][Win][C] uint8, row stride src_stride bytes; dst: dense [Hout][Wout][C] uint8. C = 1 | 3.
+ * kk_h / bounds_h (kk_v / bounds_v): Pillow's normalize_coeffs_8bpc(precompute_coeffs(...)) tables built by the host:
+ * kk[out][ksize] int32, bounds[out][2] = {first input index, count}. A NULL kk_* skips that pass (Pillow does the same
+ * when the size along that axis is unchanged). With both passes, `tmp` holds the horizontally resampled rows
+ * [y_first, y_first + y_rows) — the rows the vertical pass touches — as dense [y_rows][Wout][C] uint8. */
+int sx_resample_u8(const void* src, int Hin, int Win, int C, int64_t src_stride, void* dst, int Hout, int Wout,
+                   const int32_t* kk_h, const int32_t* bounds_h, int ksize_h, const int32_t* kk_v,
+                   const int32_t* bounds_v, int ksize_v, int y_first, int y_rows, void* tmp, void* stream);
+/* crop + ToTensor + Normalize in one gather: dst[c][y][x] = lut3x256[c][src[y0+y][x0+x][c]], dst fp32 [3][Hc][Wc].
+ * replaces: `image.crop(box)` (any_res.py:130-134), transforms.ToTensor() and transforms.Normalize(mean, std)
+ * (src/processer/transforms.py:16-19). The host builds lut[c][v] = (float32(v)/255 - mean[c]) / std[c] in float32. */
+int sx_u8_to_chw_lut(const void* src, int H, int W, int64_t src_stride, int x0, int y0, int Hc, int Wc,
+                     const float* lut3x256, float* dst, void* stream);
+/* VaeImageProcessor.postprocess(output_type="pil") [ext diffusers] as called at
+ * pipeline_stable_diffusion_xl_t2i_edit.py:986: src fp32 [3][H][W] → dst uint8 [H][W][3],
+ * u = round_half_even(clamp(x/2 + 0.5, 0, 1) * 255). */
+int sx_chw_to_u8_image(const float* src, int H, int W, void* dst, void* stream);
+/* ids_cmp_mask of eval_img2text_seed_x_i.py:153-160: mask[i] = 1 strictly between the k-th opening marker (boi | bop)
+ * and the k-th closing marker (eoi | eop), pairs formed like zip(boi_indices, eoi_indices). ids: int64 [T]; mask: uint8 [T]. */
+int sx_marker_mask(const int64_t* ids, int T, int64_t boi, int64_t bop, int64_t eoi, int64_t eop, void* mask,
+                   void* stream);
+/* F.normalize(x) with its default dim=1 on x[B][T][D] fp32 (the token axis — ResamplerXLV2(normalize=True),
+ * src/models/detokenizer/resampler.py:271-272): y = x / max(||x[b,:,d]||_2, eps). */
+int sx_l2norm_dim1(const float* x, float* y, int B, int T, int D, float eps, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

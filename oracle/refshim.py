@@ -1,7 +1,7 @@
 """Import the reference's own modules on CPU (build container only: /root/reference does not travel).
 
-torchvision / deepspeed / xformers are absent here, so tiny stand-ins are registered in ``sys.modules``
-before importing ``src.models.*``. ``xformers.ops.memory_efficient_attention`` is restated with SDPA
+torchvision / deepspeed / xformers are absent here, so stand-ins are registered in ``sys.modules`` before importing
+``src.models.*`` (torchvision.transforms: the restated PIL-based transforms of oracle/restated_preproc.py). ``xformers.ops.memory_efficient_attention`` is restated with SDPA
 following the call site modeling_llama_xformer.py:221-238 (layout [B, M, H, K]; causal iff attn_bias is a
 LowerTriangularMask)."""
 import os
@@ -28,27 +28,8 @@ def install():
     import transformers  # noqa: F401  (must be imported before the shims)
     import transformers.activations  # noqa: F401  (pulls transformers.integrations.deepspeed before the fake exists)
 
-    if "torchvision" not in sys.modules:
-        tv = _mod("torchvision")
-        tvt = _mod("torchvision.transforms")
-
-        class _Compose:
-            def __init__(self, ts):
-                self.ts = ts
-
-        class _Any:
-            def __init__(self, *a, **k):
-                pass
-
-        class _IM:
-            BICUBIC = "bicubic"
-            BILINEAR = "bilinear"
-
-        tvt.Compose, tvt.Resize, tvt.ToTensor, tvt.Normalize, tvt.InterpolationMode = _Compose, _Any, _Any, _Any, _IM
-        tvt.CenterCrop = _Any
-        tv.transforms = tvt
-        sys.modules["torchvision"] = tv
-        sys.modules["torchvision.transforms"] = tvt
+    from . import restated_preproc
+    restated_preproc.install_torchvision_shim()     # working Resize / CenterCrop / ToTensor / Normalize on PIL input
     if "deepspeed" not in sys.modules:
         ds = _mod("deepspeed")
         ds.zero = types.SimpleNamespace(GatheredParameters=None, Init=None)

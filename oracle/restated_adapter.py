@@ -41,3 +41,31 @@ def adapter_generate(sd_vit, cfg_vit, sd_x, cfg_x, sd_unet, cfg_unet, latents, s
         return ru.t2i_loop(fn, lat0, pe, pe_neg, pool, pool_neg, tid, steps, guidance_scale)
     il3 = torch.cat([image_latents, image_latents, torch.zeros_like(image_latents)], dim=0)   # :544-546
     return ru.edit_loop(fn, lat0, il3, pe, pe_neg, pool, pool_neg, tid, steps, guidance_scale, image_guidance_scale)
+
+
+def vae_preprocess(image):
+    """VaeImageProcessor.preprocess [ext] as called at pipeline…:823: 4-channel tensors are latents and pass through;
+    RGB in [0,1] is mapped to [-1,1] (already-negative input is left alone); PIL → float/255 first (no resize here:
+    callers hand multiples of 8)."""
+    import numpy as np
+    if not torch.is_tensor(image):
+        image = torch.from_numpy(np.asarray(image.convert("RGB"), dtype=np.float32) / 255.0).permute(2, 0, 1)[None]
+    if image.ndim == 3:
+        image = image[None]
+    if image.shape[1] == 4:
+        return image
+    return 2.0 * image - 1.0 if image.min() >= 0 else image
+
+
+def edit_image_latents(sd_vae_enc, cfg_vae, latent_image):
+    """prepare_image_latents (pipeline…:488-552): latents pass through; RGB is encoded with the fp32 VAE and the
+    distribution's mode() is used UN-scaled (:523, no scaling_factor)."""
+    from . import restated_vae as rv
+    x = vae_preprocess(latent_image)
+    return x if x.shape[1] == 4 else rv.vae_encode_mode(sd_vae_enc, cfg_vae, x)
+
+
+def decode_to_pt(sd_vae_dec, cfg_vae, latents):
+    """pipeline…:965-986 with output_type="pt": decode(latents / scaling_factor) → (x/2+0.5).clamp(0,1)."""
+    from . import restated_vae as rv
+    return (rv.vae_decode(sd_vae_dec, cfg_vae, latents / cfg_vae["scaling_factor"]) / 2 + 0.5).clamp(0, 1)

@@ -26,6 +26,17 @@ MINI_XLV2 = dict(dim=128, depth=2, dim_head=64, heads=2, num_queries=16, embeddi
 FULL_XLV2 = dict(dim=1024, depth=4, dim_head=64, heads=16, num_queries=64, embedding_dim=4096, output1_dim=768,
                  output2_dim=1280, ff_mult=4)  # configs/sdxl_adapter/*.yaml
 
+# mini de-tokenizer stack of tests/golden/{t2i,edit}_mini.npz (oracle/gen_golden.py runs the reference adapters on it)
+DETOK_VIT = dict(image_size=112, patch_size=14, width=256, layers=2, heads=2, mlp_ratio=2.0, n_queries=64, output_dim=256)
+DETOK_XLV2 = dict(MINI_XLV2, embedding_dim=256)
+DETOK_VAE = dict(latent_channels=4, out_channels=3, block_out_channels=(32, 32, 64, 64), layers_per_block=1,
+                 norm_groups=32, scaling_factor=0.13025)
+
+
+def detok_unet_cfg(in_ch):
+    from .restated_unet import MINI_UNET
+    return dict(MINI_UNET, in_channels=in_ch, cross_attention_dim=192, pooled_dim=128)
+
 
 def _g(seed):
     return torch.Generator(device="cpu").manual_seed(seed)

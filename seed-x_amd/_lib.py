@@ -84,6 +84,12 @@ SIGNATURES = {
     "sx_nhwc_to_nchw": [c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp],
     "sx_add_i32": [c_vp, c_i32, c_vp],
     "sx_silu_cast": [c_vp, c_vp, c_i32, c_i64, c_vp],
+    "sx_resample_u8": [c_vp, c_i32, c_i32, c_i32, c_i64, c_vp, c_i32, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32,
+                       c_vp, c_vp],
+    "sx_u8_to_chw_lut": [c_vp, c_i32, c_i32, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp],
+    "sx_chw_to_u8_image": [c_vp, c_i32, c_i32, c_vp, c_vp],
+    "sx_marker_mask": [c_vp, c_i32, c_i64, c_i64, c_i64, c_i64, c_vp, c_vp],
+    "sx_l2norm_dim1": [c_vp, c_vp, c_i32, c_i32, c_i32, c_f32, c_vp],
     "sx_cfg_euler_step": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_i32, c_f32, c_f32, c_i32, c_vp],
 }
 

@@ -1,20 +1,26 @@
 #!/bin/bash
-# Build libseedx_hip.so for gfx950 (cross-compiles without a GPU). Usage: build.sh [outdir]
+# Build libseedx_hip.so for gfx950 (cross-compiles without a GPU). Usage: build.sh [--force] [outdir]
+#   --force: recompile every translation unit (what __graft_entry__.build() does); default: only TUs older than their sources
 set -e
 HERE="$(cd "$(dirname "$0")" && pwd)"
+FORCE=0
+if [ "$1" = "--force" ]; then FORCE=1; shift; fi
 OUT="${1:-$HERE/../lib}"
 mkdir -p "$OUT" "$HERE/.obj"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffast-math -fno-finite-math-only -Wno-unused-result"
+BASE="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result"
+FAST="-ffast-math -fno-finite-math-only"
+if [ "$FORCE" = 1 ]; then rm -f "$HERE"/.obj/*.o; fi
 pids=()
-for f in gemm norm attn elementwise decode; do
+for f in gemm norm attn elementwise decode preproc; do
   src="$HERE/$f.hip"; obj="$HERE/.obj/$f.o"
   if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ "$HERE/sx_common.h" -nt "$obj" ] || [ "$HERE/../../include/seedx_hip.h" -nt "$obj" ]; then
-    extra=""
+    extra="$FAST"
+    if [ "$f" = "preproc" ]; then extra=""; fi   # integer / IEEE-exact float work: no fast-math
     # MFMA accumulators in arch VGPRs: the softmax / rescale VALU code touches every accumulator each KV tile, the
     # default AGPR form costs ~200 v_accvgpr_read/write per tile (attention only; the GEMM touches them once)
-    if [ "$f" = "attn" ] || [ -n "$SX_VGPR_FORM_ALL" ]; then extra="-mllvm -amdgpu-mfma-vgpr-form=1"; fi
-    $HIPCC $FLAGS $extra -c "$src" -o "$obj" &
+    if [ "$f" = "attn" ] || [ -n "$SX_VGPR_FORM_ALL" ]; then extra="$extra -mllvm -amdgpu-mfma-vgpr-form=1"; fi
+    $HIPCC $BASE $extra -c "$src" -o "$obj" &
     pids+=($!)
   fi
 done

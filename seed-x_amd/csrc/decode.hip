@@ -325,7 +325,9 @@ __global__ void rope_kv_append_kernel(unsigned short* qkv, unsigned short* kc, u
     const int h = (int)((i / half) % H);
     const int r = (int)(i / ((int64_t)half * H));     // row of qkv = g*T + t
     const int g = r / T, t = r - g * T;
-    const int pos = pos0_dev[g] + t;
+    int pos = pos0_dev[g] + t;
+    const bool pos_ok = pos >= 0 && pos < Tmax;
+    if (!pos_ok) pos = 0;                   // keep the table reads in range; the cache write below is skipped
     // tables are rounded to the activation dtype before use (modeling_llama_xformer.py:128-131)
     const float c = TT::to_f32(TT::from_f32(cos_t[(size_t)pos * half + j]));
     const float s = TT::to_f32(TT::from_f32(sin_t[(size_t)pos * half + j]));
@@ -337,6 +339,7 @@ __global__ void rope_kv_append_kernel(unsigned short* qkv, unsigned short* kc, u
     qh[j] = TT::from_f32(q1 * c - q2 * s);
     qh[j + half] = TT::from_f32(q2 * c + q1 * s);
     const float k1 = TT::to_f32(kh[j]), k2 = TT::to_f32(kh[j + half]);
+    if (!pos_ok) continue;                  // device-resident position past the cache: never write outside it
     unsigned short* kd = kc + (size_t)g * seq_stride + ((size_t)h * Tmax + pos) * D;
     unsigned short* vd = vc + (size_t)g * seq_stride + ((size_t)h * Tmax + pos) * D;
     kd[j] = TT::from_f32(k1 * c - k2 * s);
@@ -368,7 +371,9 @@ __global__ void scatter_rows_step_kernel(const float* src, const int* step, floa
   const int64_t total = (int64_t)G * dim;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int g = (int)(i / dim), d = (int)(i % dim);
-    dst[((size_t)g * seq_rows + step[g]) * dim + d] = src[i];
+    const int st = step[g];
+    if (st < 0 || st >= seq_rows) continue;  // device-resident step past the log: drop the row instead of corrupting HBM
+    dst[((size_t)g * seq_rows + st) * dim + d] = src[i];
   }
 }
 
@@ -420,7 +425,10 @@ __global__ __launch_bounds__(1024) void greedy_next_kernel(float* logits, int vo
   }
   if (threadIdx.x == 0) {
     *next_id = result;
-    if (out_ids) out_ids[*step_dev] = result;
+    if (out_ids) {
+      const int st = *step_dev;
+      if (st >= 0 && (ld_out <= 0 || st < ld_out)) out_ids[st] = result;   // ld_out doubles as the row capacity
+    }
   }
 }
 

@@ -355,11 +355,13 @@ int launch_cfg(const GemmP& p0, int a_mode, hipStream_t st) {
   const size_t lds = (size_t)NSTAGE * (BM + (BN + 8 * NW - 1) / (8 * NW) * (8 * NW)) * 128;
   if (a_mode == SX_A_LINEAR) {
     auto k = gemm_kernel<TT, BM, BN, WM, WN, NSTAGE, SX_A_LINEAR>;
-    if (lds > 65536) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static const hipError_t attr = lds > 65536 ? hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) : hipSuccess;
+    SX_CHECK(attr == hipSuccess, "sx_gemm: cannot reserve %zu B of LDS for the %dx%d tile: %s", lds, BM, BN, hipGetErrorString(attr));
     hipLaunchKernelGGL(k, dim3(grid), dim3(NW * 64), lds, st, p);
   } else {
     auto k = gemm_kernel<TT, BM, BN, WM, WN, NSTAGE, SX_A_CONV3X3>;
-    if (lds > 65536) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static const hipError_t attr = lds > 65536 ? hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) : hipSuccess;
+    SX_CHECK(attr == hipSuccess, "sx_gemm: cannot reserve %zu B of LDS for the %dx%d tile: %s", lds, BM, BN, hipGetErrorString(attr));
     hipLaunchKernelGGL(k, dim3(grid), dim3(NW * 64), lds, st, p);
   }
   SX_HIP_LAUNCH_CHECK();

@@ -8,8 +8,10 @@ Reference interfaces mirrored (same names, argument meaning, defaults):
   * t2i loop ``StableDiffusionXLPipeline.__call__`` [ext diffusers 0.25.0] as driven by adapter_modules.py:156-167
   * edit loop ``StableDiffusionXLText2ImageAndEditPipeline.__call__``  pipeline_stable_diffusion_xl_t2i_edit.py:900-963
   * ``EulerDiscreteScheduler`` [ext] with the SDXL scheduler config (eval_seed_x_detokenizer.py:30)
-The VAE (AutoencoderKL decode/encode) is a "next" row: ``generate`` returns latents unless a VAE
-object exposing ``decode`` is supplied through ``init_pipe``.
+``generate`` returns what the reference returns — a list of PIL images (``sdxl_pipe(...).images``,
+adapter_modules.py:156-169 / :273-287) — whenever a VAE was given to ``init_pipe``; without a VAE (the reference would
+fail there) it returns the final latents. ``output_type`` ("pil" | "np" | "pt" | "latent" | "raw") overrides, exactly like
+the ``**kwargs`` the reference forwards to the diffusers pipeline.
 
 One denoise step = {time embeddings → UNet (CFG batch 2 or 3) → fused CFG + Euler update + next scaled input}, all
 device-resident (step counter, sigma table and timestep table live in HBM) and captured once into a HIP graph that is
@@ -27,8 +29,7 @@ from . import ops
 class ResamplerXLV2:
     def __init__(self, dim=1024, depth=8, dim_head=64, heads=16, num_queries=8, embedding_dim=768, output1_dim=768,
                  output2_dim=1280, ff_mult=4, normalize=True):
-        if normalize:
-            raise NotImplementedError("normalize=True is not used by the shipped configs (…_no_normalize.yaml)")
+        self.normalize = normalize                       # F.normalize(x) over the TOKEN axis (resampler.py:271-272)
         self.dim, self.depth, self.dim_head, self.heads = dim, depth, dim_head, heads
         self.num_queries, self.embedding_dim = num_queries, embedding_dim
         self.o1, self.o2, self.ff_mult = output1_dim, output2_dim, ff_mult
@@ -93,6 +94,9 @@ class ResamplerXLV2:
         B, n, _ = x.shape
         nq, inner = self.num_queries, self.heads * self.dim_head
         x16 = x.to(self.device)
+        if self.normalize:
+            from .image_ops import l2norm_dim1
+            x16 = l2norm_dim1(x16)
         x16 = x16.contiguous() if x16.dtype == dt else ops.cast(x16.float().contiguous(), dt)
         xs = ops.gemm(x16.view(B * n, -1), P["pin"][0], bias=P["pin"][1], out_dtype=torch.float32)       # proj_in
         lat = P["latents"].unsqueeze(0).expand(B, nq, dim).contiguous().view(B * nq, dim)
@@ -202,7 +206,8 @@ class _DenoiseLoop:
         scheduler.set_timesteps(num_steps)
         ts_dev = scheduler.timesteps.to(dev)
         sig_dev = scheduler.sigmas.to(dev)
-        key = (mode, G, H, W, num_steps, float(guidance_scale), float(image_guidance_scale))
+        key = (mode, G, H, W, num_steps, float(guidance_scale), float(image_guidance_scale), tuple(prompt_embeds.shape),
+               tuple(pooled.shape), tuple(time_ids.shape), unet.dtype, str(dev))
         if self._state is None or self._graph_key != key:
             self._state = dict(lat=torch.empty((G, HW, Cl), dtype=torch.float32, device=dev),
                                scaled=torch.zeros((NB, HW, cin), dtype=torch.float32, device=dev),
@@ -272,6 +277,37 @@ class _DenoiseLoop:
 
 
 # ---------------------------------------------------------------------------------------------------------------
+def vae_image_preprocess(image, vae_scale_factor=8):
+    """``VaeImageProcessor.preprocess`` [ext diffusers 0.25.0] as the edit pipeline calls it (pipeline…:823, no explicit
+    height/width): PIL / ndarray / tensor (or lists of them) → float tensor [B,C,H,W]; PIL images are resized (lanczos) down
+    to a multiple of ``vae_scale_factor``; RGB in [0,1] is mapped to [-1,1] (input that is already negative is left alone);
+    a 4-channel tensor is taken to be latents and returned untouched."""
+    from PIL import Image
+    if isinstance(image, (Image.Image, np.ndarray)) or (torch.is_tensor(image) and image.ndim == 3):
+        image = [image]
+    if isinstance(image, (list, tuple)):
+        if isinstance(image[0], Image.Image):
+            arrs = []
+            for im in image:
+                w, h = im.size
+                w, h = w - w % vae_scale_factor, h - h % vae_scale_factor
+                if (w, h) != im.size:
+                    im = im.resize((w, h), resample=Image.LANCZOS)
+                arrs.append(np.asarray(im.convert("RGB"), dtype=np.float32) / 255.0)
+            image = torch.from_numpy(np.stack(arrs, 0)).permute(0, 3, 1, 2)
+        elif isinstance(image[0], np.ndarray):
+            arrs = [a if a.ndim == 4 else a[None] for a in image]
+            image = torch.from_numpy(np.concatenate(arrs, 0)).permute(0, 3, 1, 2).float()
+        else:
+            image = torch.cat([t if t.ndim == 4 else t[None] for t in image], dim=0)
+    if not torch.is_tensor(image) or image.ndim != 4:
+        raise ValueError(f"`image` has to be a PIL image, ndarray, tensor or a list of them but is {type(image)}")
+    if image.shape[1] == 4:
+        return image
+    image = image.float()
+    return 2.0 * image - 1.0 if float(image.min()) >= 0 else image
+
+
 class SDXLAdapter:
     def __init__(self, unet, resampler, full_ft=False, vit_down=False):
         self.unet, self.resampler = unet, resampler
@@ -291,10 +327,12 @@ class SDXLAdapter:
         return model
 
     def load_state_dict(self, sd, strict=True):
-        """Checkpoint keys: resampler.* and unet.* (second stage: 8-channel unet.conv_in)."""
+        """Checkpoint keys: resampler.* and unet.* (second stage: 8-channel unet.conv_in). The unet.* entries OVERLAY the
+        weights the UNet already holds, like the reference's `load_state_dict(ckpt, strict=False)` over the SDXL-base
+        UNet (adapter_modules.py:62-65): a first-stage checkpoint may carry only the trained to_k / to_v tensors."""
         self.resampler.load_state_dict(sd, prefix="resampler.", strict=strict)
         if any(k.startswith("unet.") for k in sd):
-            self.unet.load_state_dict(sd, prefix="unet.", strict=strict)
+            self.unet.load_state_dict(sd, prefix="unet.", strict=strict, merge=True)
         return [], []
 
     def to(self, device=None, dtype=None):
@@ -304,6 +342,9 @@ class SDXLAdapter:
             self.dtype = dtype
         self.unet.to(self.device, self.dtype)
         self.resampler.to(self.device, self.dtype)
+        self._neg_cache = {}
+        if self._loop is not None:
+            self._loop._graph = self._loop._state = self._loop._ctx_static = None
         return self
 
     def eval(self):
@@ -320,6 +361,7 @@ class SDXLAdapter:
         self.discrete_model = discrete_model
         self.image_transform = image_transform
         self.to(self.device, self.dtype)
+        self._neg_cache = {}                                                        # new encoder / dtype → new negatives
         self._loop = _DenoiseLoop(self.unet, self.use_graph, comm=getattr(self, "comm", None))
 
     def _negative_embeds(self, image_size, pooled):
@@ -373,6 +415,8 @@ class SDXLAdapter:
     def _finish(self, latents, output_type):
         """pipeline…:965-986: "latent" → latents; otherwise VAE-decode (latents / scaling_factor) and post-process like
         VaeImageProcessor.postprocess [ext]: "pt" → [B,3,H,W] in [0,1]; "np" → [B,H,W,3]; "pil" → list of PIL images."""
+        if output_type is None:                                                      # the reference's default is "pil"
+            output_type = "pil" if self.vae is not None else "latent"
         if output_type == "latent":
             return latents
         if self.vae is None:
@@ -381,18 +425,22 @@ class SDXLAdapter:
         img = self.vae.decode(latents / scaling, return_dict=False)[0]
         if output_type == "raw":                                                     # decoder output, no post-processing
             return img
+        if output_type == "pil":                                                     # fused denormalise → uint8 HWC kernel
+            from .image_ops import images_to_pil
+            return images_to_pil(img.float())
         img = (img / 2 + 0.5).clamp(0, 1)
         if output_type == "pt":
             return img
-        arr = img.permute(0, 2, 3, 1).float().cpu().numpy()
         if output_type == "np":
-            return arr
-        from PIL import Image
-        return [Image.fromarray((a * 255).round().astype("uint8")) for a in arr]
+            return img.permute(0, 2, 3, 1).float().cpu().numpy()
+        raise ValueError(f"unknown output_type {output_type!r}")
 
     def generate(self, image_pil=None, image_tensor=None, image_embeds=None, seed=None, height=1024, width=1024,
-                 guidance_scale=7.5, num_inference_steps=30, input_image_size=448, output_type="latent", latents=None,
+                 guidance_scale=7.5, num_inference_steps=30, input_image_size=448, output_type=None, latents=None,
                  **kwargs):
+        if image_pil is not None:
+            from PIL import Image
+            assert isinstance(image_pil, Image.Image)                                # adapter_modules.py:143-144
         pe, pe_neg, pool, pool_neg = self.get_image_embeds(image_pil=image_pil, image_tensor=image_tensor,
                                                            image_embeds=image_embeds, return_negative=True,
                                                            image_size=input_image_size)
@@ -411,9 +459,36 @@ class SDXLAdapter:
 class SDXLAdapterWithLatentImage(SDXLAdapter):
     """Edit variant (adapter_modules.py:172-287): 8-channel UNet input, 3-way guidance."""
 
+    def __init__(self, unet, resampler, full_ft=False, set_trainable_late=False, vit_down=False):
+        super().__init__(unet, resampler, full_ft=full_ft, vit_down=vit_down)
+        if not set_trainable_late:
+            self.set_trainable()
+
+    def set_trainable(self):
+        """The inference-relevant part of adapter_modules.py:186-198: conv_in grows to 8 input channels, the new ones
+        zero-initialised, the first four copied — so a checkpoint without unet.conv_in still yields a valid edit UNet."""
+        self.unet.expand_conv_in(8)
+
+    @classmethod
+    def from_pretrained(cls, unet, resampler, pretrained_model_path=None, set_trainable_late=False, **kwargs):
+        model = cls(unet=unet, resampler=resampler, set_trainable_late=set_trainable_late, **kwargs)
+        if pretrained_model_path is not None:
+            ckpt = torch.load(pretrained_model_path, map_location="cpu")          # adapter_modules.py:215-218
+            model.load_state_dict(ckpt)
+        if set_trainable_late:
+            model.set_trainable()
+        return model
+
+    def init_pipe(self, vae, scheduler, visual_encoder, image_transform, dtype=torch.float16, device='cuda', **kw):
+        return super().init_pipe(vae, scheduler, visual_encoder, image_transform, discrete_model=None, dtype=dtype,
+                                 device=device)
+
     def generate(self, image_pil=None, image_tensor=None, image_embeds=None, latent_image=None, seed=42, height=1024,
                  width=1024, guidance_scale=7.5, num_inference_steps=30, input_image_size=448,
-                 image_guidance_scale=1.5, output_type="latent", latents=None, image_latents=None, **kwargs):
+                 image_guidance_scale=1.5, output_type=None, latents=None, image_latents=None, **kwargs):
+        if image_pil is not None:
+            from PIL import Image
+            assert isinstance(image_pil, Image.Image)                                # adapter_modules.py:261-262
         pe, pe_neg, pool, pool_neg = self.get_image_embeds(image_pil=image_pil, image_tensor=image_tensor,
                                                            image_embeds=image_embeds, return_negative=True,
                                                            image_size=input_image_size)
@@ -426,10 +501,18 @@ class SDXLAdapterWithLatentImage(SDXLAdapter):
             if latent_image is None:
                 image_latents = torch.zeros(G, 4, height // 8, width // 8)          # pipeline…:909-910 (no source image)
             else:
-                if self.vae is None:
-                    raise RuntimeError("`latent_image` needs a VAE with encoder weights (init_pipe(vae=...)); or pass "
-                                       "`image_latents` = vae.encode(img).latent_dist.mode() (NOT scaled, :523)")
-                image_latents = self.vae.encode(latent_image).latent_dist.mode()
+                src = vae_image_preprocess(latent_image)                            # pipeline…:823
+                if src.shape[1] == 4:                                               # already latents (:500-505)
+                    image_latents = src
+                else:
+                    if self.vae is None:
+                        raise RuntimeError("an RGB `latent_image` needs a VAE with encoder weights (init_pipe(vae=...)); "
+                                           "or pass 4-channel latents = vae.encode(img).latent_dist.mode() (NOT scaled, :523)")
+                    image_latents = self.vae.encode(src).latent_dist.mode()
+                if image_latents.shape[0] != G:                                     # :529-541 duplicate per prompt
+                    if G % image_latents.shape[0] != 0:
+                        raise ValueError(f"Cannot duplicate `image` of batch size {image_latents.shape[0]} to {G} prompts.")
+                    image_latents = torch.cat([image_latents] * (G // image_latents.shape[0]), dim=0)
         il = image_latents.to(self.device, torch.float32)
         il3 = torch.cat([il, il, torch.zeros_like(il)], dim=0)                       # [img, img, 0]  (:544-546)
         ehs = torch.cat([pe, pe_neg, pe_neg], dim=0)                                 # order [text, image, uncond] (:884)

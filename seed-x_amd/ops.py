@@ -306,8 +306,9 @@ def scatter_rows(src, rows_i32, dst):
 def greedy_next(logits, vocab, img_ids_dev, prev_id_dev, next_id_dev, out_ids=None, step_dev=None):
     lib = _lib.load()
     assert logits.dtype == torch.float32
-    check(lib.sx_greedy_next(_p(logits), vocab, _p(img_ids_dev), img_ids_dev.numel(), _p(prev_id_dev),
-                             _p(next_id_dev), _p(out_ids), _p(step_dev), _stream()), "sx_greedy_next")
+    cap = out_ids.numel() if out_ids is not None else 0          # capacity: the kernel drops writes at step >= cap
+    check(lib.sx_greedy_next_b(_p(logits), 0, vocab, _p(img_ids_dev), img_ids_dev.numel(), _p(prev_id_dev),
+                               _p(next_id_dev), _p(out_ids), cap, _p(step_dev), 1, _stream()), "sx_greedy_next")
 
 
 # ---------------------------------------------------------------------------------------------------------

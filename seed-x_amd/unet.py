@@ -71,9 +71,28 @@ class UNet2DConditionModel:
         return m
 
     # ---- state dict ------------------------------------------------------------------------------------------
-    def load_state_dict(self, sd, strict=True, prefix=""):
+    def expand_conv_in(self, in_channels):
+        """conv_in [Co, 4, 3, 3] → [Co, in_channels, 3, 3], new input channels zero (adapter_modules.py:187-198)."""
+        if self.cfg["in_channels"] == in_channels:
+            return
+        if self._sd is None and self._P is not None:
+            raise RuntimeError("UNet2DConditionModel: weights already packed; expand conv_in before the first forward")
+        if self._sd is not None:
+            w = self._sd["conv_in.weight"]
+            new = torch.zeros((w.shape[0], in_channels, w.shape[2], w.shape[3]), dtype=w.dtype)
+            new[:, :w.shape[1]] = w
+            self._sd = dict(self._sd)
+            self._sd["conv_in.weight"] = new
+        self.cfg["in_channels"] = self.config.in_channels = in_channels
+        self._P = None
+
+    def load_state_dict(self, sd, strict=True, prefix="", merge=False):
         if prefix:
             sd = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+        if merge and self._sd is not None:                      # overlay on the weights already held
+            full = dict(self._sd)
+            full.update(sd)
+            sd = full
         need = ["conv_in.weight", "conv_out.weight", "time_embedding.linear_1.weight", "add_embedding.linear_2.bias",
                 "mid_block.resnets.1.conv2.weight", "conv_norm_out.weight"]
         missing = [k for k in need if k not in sd]

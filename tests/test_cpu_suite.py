@@ -67,6 +67,60 @@ def test_oracle_resamplers_match_golden():
     assert _rel(pe, g["prompt"]) < 2e-5 and _rel(pooled, g["pooled"]) < 2e-5
 
 
+def test_oracle_detok_matches_reference_executed_golden():
+    """tests/golden/{t2i,edit}_mini.npz were produced by EXECUTING the reference's adapter_modules.py and
+    pipeline_stable_diffusion_xl_t2i_edit.py (oracle/diffusers_shim.py supplies the third-party base classes); the
+    restated adapter / CFG loops used as the oracle of every GPU test must reproduce them."""
+    from oracle import restated_adapter as ra, restated_unet as ru, restated_vae as rv
+    t2i, edit = _gold("t2i_mini.npz"), _gold("edit_mini.npz")
+    V, X = weights.DETOK_VIT, weights.DETOK_XLV2
+    sd_vit, sd_x = weights.vit_sd(V), weights.xlv2_sd(X)
+    out = ra.get_image_embeds(sd_vit, V, sd_x, X, image_tensor=t2i["image_tensor"])
+    for o, k in zip(out, ("tensor_prompt", "tensor_prompt_neg", "tensor_pooled", "tensor_pooled_neg")):
+        assert _rel(o, t2i[k]) < 2e-5, k
+    u4, u8 = weights.detok_unet_cfg(4), weights.detok_unet_cfg(8)
+    kw = dict(height=128, width=128)
+    lat = ra.adapter_generate(sd_vit, V, sd_x, X, ru.unet_sd(u4), u4, t2i["noise"], 5, image_embeds=t2i["feats"], **kw)
+    assert _rel(lat, t2i["latents"]) < 5e-5
+    sd8 = ru.unet_sd(u8)
+    lat = ra.adapter_generate(sd_vit, V, sd_x, X, sd8, u8, edit["noise"], 5, image_embeds=edit["feats"],
+                              image_latents=edit["image_latents"], **kw)
+    assert _rel(lat, edit["latents"]) < 5e-5
+    il = ra.edit_image_latents(rv.vae_encoder_sd(weights.DETOK_VAE), weights.DETOK_VAE, edit["src_image"])
+    lat = ra.adapter_generate(sd_vit, V, sd_x, X, sd8, u8, edit["noise"], 2, image_embeds=edit["feats"],
+                              image_latents=il, **kw)
+    assert _rel(lat, edit["latents_from_rgb"]) < 5e-5
+
+
+def test_pillow_coefficient_tables_and_anyres_oracle():
+    """Host logic of the GPU preprocessing: image_ops.pil_coeffs (Pillow's precompute_coeffs / normalize_coeffs_8bpc
+    restated) fed to a numpy emulation of the two integer kernel passes reproduces Pillow's resize bit for bit; the
+    Pillow-based any-res oracle reproduces the fixtures the reference's own process_anyres_image produced; the grid
+    selection of the product equals the oracle's."""
+    import numpy as np
+    from PIL import Image
+    from oracle import restated_preproc as rp
+    from seedx_amd import image_ops as io
+    rng = np.random.default_rng(0)
+    for (H, W), (ow, oh), rs in [((300, 400), (224, 224), "bicubic"), ((100, 120), (448, 448), "bicubic"),
+                                 ((333, 517), (448, 448), "bilinear"), ((448, 700), (448, 448), "bilinear"),
+                                 ((900, 450), (448, 1344), "bicubic"), ((1, 5), (7, 3), "bicubic")]:
+        img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        ref = np.asarray(Image.fromarray(img).resize((ow, oh), {"bicubic": Image.BICUBIC, "bilinear": Image.BILINEAR}[rs]))
+        kw, bw, _ = io.pil_coeffs(W, ow, rs)
+        kh, bh, _ = io.pil_coeffs(H, oh, rs)
+        assert np.array_equal(rp.resample_u8_fixed_point(img, (ow, oh), kw, bw, kh, bh), ref), ((H, W), (ow, oh), rs)
+    g = np.load(os.path.join(GOLD, "anyres_mini.npz"))
+    S = 64
+    pins = [[int(s.split('x')[0]) * S, int(s.split('x')[1]) * S] for s in ['1x1', '1x2', '1x3', '2x1', '3x1', '1x4', '4x1', '2x2']]
+    for i in range(5):
+        o, p = rp.process_anyres_image(Image.fromarray(g[f"img{i}"]), rp.clip_transform(S), pins, S)
+        assert np.array_equal(o.numpy(), g[f"out{i}"]) and np.array_equal(p.numpy(), g[f"pos{i}"])
+        H, W, _ = g[f"img{i}"].shape
+        gx, gy = io.get_anyres_image_grid_shape((W, H), pins, S)
+        assert gx * gy + 1 == o.shape[0]
+
+
 def test_unet_inventory_matches_sdxl_param_count():
     """The only structural pin available for the diffusers UNet: exact parameter counts."""
     assert ru.unet_param_count(ru.FULL_UNET) == 2_567_463_684

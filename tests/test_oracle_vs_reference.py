@@ -93,3 +93,48 @@ def test_resampler_and_xlv2_match_reference():
         pe, pooled = m(x)
     pe2, pooled2 = restated.resampler_xlv2_forward(sdx, cfg, x, pre="")
     assert _rel(pe2, pe) < 2e-5 and _rel(pooled2, pooled) < 2e-5
+
+
+# ---- path C: the reference's OWN adapters + edit pipeline (executed over oracle/diffusers_shim.py) -------------------
+def test_detok_goldens_are_reproducible_and_pin_the_restated_adapter():
+    """(1) re-running the reference adapters reproduces the committed tests/golden/{t2i,edit}_mini.npz bit for bit;
+    (2) oracle/restated_adapter.py + restated_unet.{t2i,edit}_loop (the restatements every GPU parity test uses) agree
+    with what the reference code computed: get_image_embeds branches, 5-step trajectories, VAE-encoded source."""
+    import os
+    import numpy as np
+    from oracle import gen_golden as gg, restated_adapter as ra, restated_unet as ru, restated_vae as rv
+    live = gg.run_reference_detok()
+    gold_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    for name, arrs in live.items():
+        gold = np.load(os.path.join(gold_dir, name))
+        for k, v in arrs.items():
+            assert np.array_equal(gold[k], v.numpy()), f"{name}:{k} differs from the committed fixture"
+    t2i, edit = live["t2i_mini.npz"], live["edit_mini.npz"]
+    sd_vit, sd_x = weights.vit_sd(gg.DETOK_VIT), weights.xlv2_sd(gg.DETOK_XLV2)
+    out = ra.get_image_embeds(sd_vit, gg.DETOK_VIT, sd_x, gg.DETOK_XLV2, image_tensor=t2i["image_tensor"])
+    for o, k in zip(out, ("tensor_prompt", "tensor_prompt_neg", "tensor_pooled", "tensor_pooled_neg")):
+        assert _rel(o, t2i[k]) < 2e-5, k
+    out = ra.get_image_embeds(sd_vit, gg.DETOK_VIT, sd_x, gg.DETOK_XLV2, image_embeds=t2i["feats"], vit_down=True)
+    for o, k in zip(out, ("embeds_prompt", "embeds_prompt_neg", "embeds_pooled", "embeds_pooled_neg")):
+        assert _rel(o, t2i[k]) < 2e-5, k
+    u4, u8 = gg.detok_unet_cfg(4), gg.detok_unet_cfg(8)
+    sd4, sd8 = ru.unet_sd(u4), ru.unet_sd(u8)
+    kw = dict(height=128, width=128)
+    lat = ra.adapter_generate(sd_vit, gg.DETOK_VIT, sd_x, gg.DETOK_XLV2, sd4, u4, t2i["noise"], 5,
+                              image_embeds=t2i["feats"], **kw)
+    assert _rel(lat, t2i["latents"]) < 5e-5
+    assert torch.equal(t2i["latents_traj"][-1], t2i["latents"])
+    lat = ra.adapter_generate(sd_vit, gg.DETOK_VIT, sd_x, gg.DETOK_XLV2, sd8, u8, edit["noise"], 5,
+                              image_embeds=edit["feats"], image_latents=edit["image_latents"], **kw)
+    assert _rel(lat, edit["latents"]) < 5e-5
+    lat = ra.adapter_generate(sd_vit, gg.DETOK_VIT, sd_x, gg.DETOK_XLV2, sd8, u8, edit["noise"], 3,
+                              image_embeds=edit["feats"], image_latents=torch.zeros(1, 4, 16, 16), **kw)
+    assert _rel(lat, edit["latents_no_image"]) < 5e-5
+    il = ra.edit_image_latents(rv.vae_encoder_sd(gg.DETOK_VAE), gg.DETOK_VAE, edit["src_image"])
+    lat = ra.adapter_generate(sd_vit, gg.DETOK_VIT, sd_x, gg.DETOK_XLV2, sd8, u8, edit["noise"], 2,
+                              image_embeds=edit["feats"], image_latents=il, **kw)
+    assert _rel(lat, edit["latents_from_rgb"]) < 5e-5
+    lat2 = ra.adapter_generate(sd_vit, gg.DETOK_VIT, sd_x, gg.DETOK_XLV2, sd8, u8, edit["noise"], 2,
+                               image_embeds=edit["feats"], image_latents=edit["image_latents"], **kw)
+    img = ra.decode_to_pt(rv.vae_sd(gg.DETOK_VAE), gg.DETOK_VAE, lat2)
+    assert (img - edit["image_pt"]).abs().max() < 1e-4
