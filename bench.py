@@ -1,22 +1,30 @@
 #!/usr/bin/env python
-"""bench.py — end-to-end SEED-X-I generations/sec on MI355X (BASELINE.json metric).
+"""bench.py — end-to-end SEED-X generations/sec on MI355X (BASELINE.json metric).
 
-One "step" = ONE full generation on one GPU, with every input already resident in HBM:
-    1x448px image (any-res → 2 crops) → ViT-G/448 → input resampler → Llama-13B-dim prefill (165 tokens) →
-    greedy decode of 128 new tokens (61 text tokens with lm_head + logits rule, then <img> + 64 forced image tokens
-    + </img>; EOS disabled so the length is fixed) → output resampler → ResamplerXLV2 (CFG batch 2; the all-zero-image
-    negative ViT features are a per-model constant and cached) → 50-step SDXL UNet CFG(7.5)+Euler at 128x128 latents
-    (= 1024x1024 px) → SDXL VAE decoder → [3, 1024, 1024] image in [0, 1] (`--no-vae` stops at the latents).
+Default workload (`--config 0`, the headline metric: image in → text + 1024 px image out, BASELINE configs 2 + 3
+composed). One "step" = `--batch` independent generations processed together on one GPU, every input already resident
+in HBM as the RAW uint8 image and the prompt token ids:
+    448x448x3 uint8 image → any-res tiling + resize + CLIP normalise ON THE GPU (2 crops) → ViT-G/448 → input resampler
+    → Llama-13B-dim prefill (165 tokens, all requests as one M = batch·165 pass) → greedy decode of 128 new tokens
+    (61 text tokens with lm_head + logits rule, then <img> + 64 forced image tokens + </img>; EOS disabled so the
+    length is fixed) → output resampler → ResamplerXLV2 (CFG batch 2; the all-zero-image negative ViT features are a
+    per-model constant and cached) → 50-step SDXL UNet CFG(7.5)+Euler at 128x128 latents (= 1024x1024 px) → SDXL VAE
+    decoder → uint8 [1024, 1024, 3] image (`--no-vae` stops at the latents).
+`--config 1..5` run BASELINE.json's five configs (see CONFIGS below); they are parity / coverage workloads, the driver's
+bench line is config 0.
+
 Synthetic data: seeded random image / prompt ids, random-init weights of the real architecture (no checkpoints exist
-here). N > 1 GPUs: one process per GPU (torchrun), independent generations per rank (no data-path collective; weak
-scaling); value = total generations of all ranks / max-over-ranks wall time.
+here). N > 1 GPUs: one process per GPU, independent generations per rank (no data-path collective; weak scaling);
+value = total generations of all ranks / max-over-ranks wall time. `python bench.py --gpus N` starts the N ranks itself
+(re-exec under torch.distributed.run); under an external launcher (WORLD_SIZE set) it joins that job.
 
-Usage: python bench.py --gpus N --steps K --warmup W   (prints ONE JSON line on rank 0)
+Usage: python bench.py --gpus N --steps K --warmup W [--config C]   (prints ONE JSON line on rank 0)
 """
 import argparse
 import json
-import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,7 +32,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
 
 PEAK_TFLOPS_16BIT = 2500.0   # dense bf16/fp16 MFMA peak, MI355X_MICROARCH.md
 # algorithmic FLOPs
@@ -33,11 +40,22 @@ FLOP_LLM_TOKEN = 25.71e9
 FLOP_UNET_SAMPLE = 6.747e12
 FLOP_VAE_DECODE = 10.47e12   # SDXL VAE decoder at 128x128 latents (conv/linear/attention MACs x 2)
 
+CONFIGS = {
+    0: "headline: 1x448px image in -> text + one 1024px image out (BASELINE configs 2+3 composed)",
+    1: "de-tokenizer only: 1x448px ViT features (B=2 incl. zero image) -> ResamplerXLV2 -> ONE SDXL-UNet CFG-2 Euler step",
+    2: "comprehension: 1x448px in (2 crops), 165-token prefill, 128-token greedy decode (text only)",
+    3: "text->image: 64-token prompt -> 8 text tokens + <img>64</img> -> 50-step SDXL de-tokenize at 1024x1024",
+    4: "edit: 1x448px in + 16-token instruction -> image block -> 50-step edit loop, UNet Bc=3 x 8-ch, gs 7.5 / igs 1.5",
+    5: "any-res multi-image multi-turn: 4x896px (ViT B=20), ~1.5k-token prefill, 3 turns x 64 text tokens, last turn "
+       "emits an image -> 50-step t2i de-tokenize",
+}
+
 
 class BenchTokenizer:
     """Stand-in for the LLaMA sentencepiece tokenizer (clm_llama_tokenizer_224loc_anyres): only the special-token ids
-    matter for the hot path. <img>=32000, <img_00000..63>=32001..32064, </img>=32065 (ids of the added tokens)."""
+    matter for the hot path. <img>=32000, <img_00000..63>=32001..32064, </img>=32065, <patch>=32066, </patch>=32067."""
     eos_token_id = 2
+    BOI, EOI, BOP, EOP = 32000, 32065, 32066, 32067
 
     def encode(self, s, add_special_tokens=False):
         import re
@@ -51,76 +69,108 @@ class BenchTokenizer:
 
 
 USE_VAE = True   # set from --no-vae
+BATCH = 16       # generations processed together per step on one GPU (set from --batch)
+GRID_PINPOINTS = [[a * 448, b * 448] for a, b in ((1, 1), (1, 2), (1, 3), (2, 1), (3, 1), (1, 4), (4, 1), (2, 2))]
 
 
-def build_models(dev, dtype, llm_comm=None, cfg_comm=None):
+def build_models(dev, dtype, llm_comm=None, cfg_comm=None, need=("vit", "llm", "adapter"), edit=False, max_cache_len=1024):
     """llm_comm / cfg_comm: tensor-parallel Llama and CFG-parallel UNet communicators (tools/bench_tp_latency.py only;
-    the throughput bench leaves them None = one full replica per GPU)."""
+    the throughput bench leaves them None = one full replica per GPU). Returns (vit, agent, adapter); parts not in `need`
+    are None."""
     from seedx_amd import synthetic as syn
-    from seedx_amd.detokenizer import EulerDiscreteScheduler, ResamplerXLV2, SDXLAdapter
+    from seedx_amd.detokenizer import EulerDiscreteScheduler, ResamplerXLV2, SDXLAdapter, SDXLAdapterWithLatentImage
     from seedx_amd.llama import LlamaForCausalLM
     from seedx_amd.seed_x import ContinuousLVLM
     from seedx_amd.unet import SDXL_BASE_CONFIG, UNet2DConditionModel
     from seedx_amd.visual_encoder import Resampler, VisionTransformerWithAttnPool
-    vit = VisionTransformerWithAttnPool(**syn.FULL_VIT)
-    vit.load_state_dict(syn.vit_state_dict(syn.FULL_VIT, dev, dtype))
-    vit.eval().to(dev, dtype=dtype)
-    vit._pack()
-    llm = LlamaForCausalLM(dict(syn.FULL_LLM), max_cache_len=1024, max_batch=BATCH, comm=llm_comm)
-    llm.load_state_dict(syn.llama_state_dict(syn.FULL_LLM, dev, dtype))
-    llm.to(dev, dtype)
-    llm._pack()
-    torch.cuda.empty_cache()
-    H = syn.FULL_LLM["hidden_size"]
-    agent = ContinuousLVLM(llm, Resampler(8, H, 32, kv_dim=4096), Resampler(8, 4096, 32, kv_dim=H), add_patch_pos=True,
-                           vit_down=True)                                    # agent_seed_x_i.yaml
-    agent.load_state_dict(syn.agent_state_dict(H, 4096, dev, dtype))
-    agent.eval().to(dev, dtype)
-    unet = UNet2DConditionModel(**SDXL_BASE_CONFIG)
-    unet.load_state_dict(syn.unet_state_dict(unet.cfg, dev, dtype))
-    res = ResamplerXLV2(normalize=False, **syn.FULL_XLV2)
-    res.load_state_dict(syn.xlv2_state_dict(syn.FULL_XLV2, dev, dtype), prefix="resampler.")
-    adapter = SDXLAdapter(unet, res, vit_down=True)
-    adapter.comm = cfg_comm
-    vae = None
-    if USE_VAE:
-        from seedx_amd.vae import AutoencoderKL
-        vae = AutoencoderKL()                                                    # SDXL vae/config.json defaults
-        vae.load_state_dict(syn.vae_state_dict(vae, dev, dtype))
-        vae.to(dev, dtype)
-        vae._pack()
-    adapter.init_pipe(vae=vae, scheduler=EulerDiscreteScheduler(), visual_encoder=vit, image_transform=None,
-                      discrete_model=None, dtype=dtype, device=dev)
-    unet._pack()
-    torch.cuda.empty_cache()
+    vit = agent = adapter = None
+    if "vit" in need or "adapter" in need:                                      # the adapter needs the ViT for its negatives
+        vit = VisionTransformerWithAttnPool(**syn.FULL_VIT)
+        vit.load_state_dict(syn.vit_state_dict(syn.FULL_VIT, dev, dtype))
+        vit.eval().to(dev, dtype=dtype)
+        vit._pack()
+    if "llm" in need:
+        llm = LlamaForCausalLM(dict(syn.FULL_LLM), max_cache_len=max_cache_len, max_batch=BATCH, comm=llm_comm)
+        llm.load_state_dict(syn.llama_state_dict(syn.FULL_LLM, dev, dtype))
+        llm.to(dev, dtype)
+        llm._pack()
+        torch.cuda.empty_cache()
+        H = syn.FULL_LLM["hidden_size"]
+        agent = ContinuousLVLM(llm, Resampler(8, H, 32, kv_dim=4096), Resampler(8, 4096, 32, kv_dim=H), add_patch_pos=True,
+                               vit_down=True)                                    # agent_seed_x_i.yaml
+        agent.load_state_dict(syn.agent_state_dict(H, 4096, dev, dtype))
+        agent.eval().to(dev, dtype)
+    if "adapter" in need:
+        ucfg = dict(SDXL_BASE_CONFIG, in_channels=8) if edit else dict(SDXL_BASE_CONFIG)
+        unet = UNet2DConditionModel(**ucfg)
+        unet.load_state_dict(syn.unet_state_dict(unet.cfg, dev, dtype))
+        res = ResamplerXLV2(normalize=False, **syn.FULL_XLV2)
+        res.load_state_dict(syn.xlv2_state_dict(syn.FULL_XLV2, dev, dtype), prefix="resampler.")
+        adapter = (SDXLAdapterWithLatentImage if edit else SDXLAdapter)(unet, res, vit_down=True)
+        adapter.comm = cfg_comm
+        vae = None
+        if USE_VAE:
+            from seedx_amd.vae import AutoencoderKL
+            vae = AutoencoderKL()                                                    # SDXL vae/config.json defaults
+            vae.load_state_dict(syn.vae_state_dict(vae, dev, dtype))
+            vae.to(dev, dtype)
+            vae._pack()
+        adapter.init_pipe(vae=vae, scheduler=EulerDiscreteScheduler(), visual_encoder=vit, image_transform=None,
+                          dtype=dtype, device=dev)
+        unet._pack()
+        torch.cuda.empty_cache()
     return vit, agent, adapter
 
 
-def make_inputs(dev, seed=0):
+def make_inputs(dev, seed=0, size=448, n_images=1, extra_text=0):
+    """(uint8 images resident in HBM, prompt ids, marker ids). Prompt layout of eval_img2text_seed_x_i.py:131-150:
+    BOS [INST] {<patch>64</patch>}·(crops-1) <img>64</img> ~question tokens [/INST]\\n."""
     g = torch.Generator(device="cpu").manual_seed(seed)
-    image = torch.randn(2, 3, 448, 448, generator=g).to(dev)                   # 1 tile + global crop (any_res.py:185-189)
-    patch_pos = torch.tensor([[0.5, 0.5], [0.5, 0.5]])
-    # prompt: BOS [INST] <patch>64</patch> <img>64</img> ~20 question tokens [/INST]\n  → 165 tokens (SURVEY §8d cfg 2)
-    text = torch.randint(3, 32000, (165,), generator=g).tolist()
-    ids = [1] + text[:7] + [32066] + [0] * 64 + [32067] + [32000] + [0] * 64 + [32065] + text[7:7 + 26]
-    ids = ids[:165]
-    mask = torch.zeros(1, len(ids), dtype=torch.bool)
-    mask[0, 9:73] = True
-    mask[0, 75:139] = True
-    return image, patch_pos, ids, mask
+    images = [torch.randint(0, 256, (size, size, 3), generator=g, dtype=torch.uint8).to(dev) for _ in range(n_images)]
+    crops = (size // 448) ** 2 + 1
+    text = torch.randint(3, 32000, (400,), generator=g).tolist()
+    T = BenchTokenizer
+    ids = [1] + text[:7]
+    for _ in range(n_images):
+        for c in range(crops):
+            last = c == crops - 1
+            ids += [T.BOI if last else T.BOP] + [0] * 64 + [T.EOI if last else T.EOP]
+    ids += text[7:7 + 25 + extra_text]
+    return images, ids
 
 
-BATCH = 16  # generations processed together per step on one GPU (set from --batch)
+def preprocess(images, dev):
+    """any_res.py:158-201 + transforms.py:5-20 on the GPU: uint8 images → ([n_crops, 3, 448, 448] fp32, patch_pos)."""
+    from seedx_amd import image_ops
+    tf = image_ops.get_transform(type='clip', image_size=448, keep_ratio=False, device=dev)
+    tens, pos = [], []
+    for im in images:
+        t, p = image_ops.process_anyres_image(im, tf, GRID_PINPOINTS, 448)
+        tens.append(t)
+        pos.append(p)
+    return torch.cat(tens, dim=0), torch.cat(pos, dim=0)
 
 
-def front_half(vit, agent, tok, inp, n_text):
-    """Paths A + B for BATCH requests: ViT on all 2·BATCH crops at once, then the BATCH greedy decodes in lock step.
-    Returns the image-generation features [BATCH, 64, 4096]."""
-    image, patch_pos, ids, mask = inp
+def requests_for(vit, inp, dev):
+    """Path A for BATCH requests (preprocessing + ViT on all BATCH·n_crops crops at once) → generate_batch requests."""
+    from seedx_amd import image_ops
+    images, ids = inp
     G = BATCH
-    emb = vit(image if G == 1 else image.repeat(G, 1, 1, 1))                    # path A, [2G, 256, 4096]
-    reqs = [dict(input_ids=[ids], image_embeds=emb[2 * g:2 * g + 2], embeds_cmp_mask=torch.tensor([True, True]),
-                 ids_cmp_mask=mask, patch_positions=patch_pos) for g in range(G)]
+    T = BenchTokenizer
+    crops, ppos = preprocess(images, dev)                                      # identical image per request: preprocess once
+    n = crops.shape[0]                                                         # per request … but run the ViT on every crop
+    emb = vit(crops if G == 1 else crops.repeat(G, 1, 1, 1))                   # [G·n, 256, 4096]
+    ids_dev = torch.tensor(ids, dtype=torch.long, device=dev)
+    mask = image_ops.marker_mask(ids_dev, T.BOI, T.EOI, T.BOP, T.EOP).view(1, -1)   # eval_img2text_seed_x_i.py:153-160
+    return [dict(input_ids=[ids], image_embeds=emb[n * g:n * (g + 1)], embeds_cmp_mask=torch.tensor([True] * n),
+                 ids_cmp_mask=mask, patch_positions=ppos) for g in range(G)]
+
+
+def front_half(vit, agent, tok, inp, n_text, dev=None):
+    """Paths A + B for BATCH requests: GPU preprocessing, ViT on all crops at once, then the BATCH greedy decodes in lock
+    step. Returns the image-generation features [BATCH, 64, 4096]."""
+    dev = dev or agent.llm.device
+    reqs = requests_for(vit, inp, dev)
     outs = agent.generate_batch(tok, reqs, max_new_tokens=n_text + 66 + 1, eos_token_id=None,
                                 force_image_at=n_text)                          # path B, G sequences in lock step
     for out in outs:
@@ -128,40 +178,191 @@ def front_half(vit, agent, tok, inp, n_text):
     return torch.cat([o["img_gen_feat"] for o in outs], dim=0)
 
 
-def back_half(adapter, feats, steps_unet, seed):
-    """Path C for BATCH requests as one UNet batch of 2·BATCH CFG samples (enqueue-only: no host sync inside)."""
+def back_half(adapter, feats, steps_unet, seed, **kw):
+    """Path C for BATCH requests as one UNet batch of 2·BATCH (edit: 3·BATCH) CFG samples (enqueue-only: no host sync)."""
     G = feats.shape[0]
     out = adapter.generate(image_embeds=feats, num_inference_steps=steps_unet, seed=[seed * G + g for g in range(G)],
-                           output_type="pt" if USE_VAE else "latent")
-    assert out.shape == ((G, 3, 1024, 1024) if USE_VAE else (G, 4, 128, 128))
+                           output_type="u8" if USE_VAE else "latent", **kw)
+    assert out.shape == ((G, 1024, 1024, 3) if USE_VAE else (G, 4, 128, 128))
     return out
 
 
-def one_generation(vit, agent, adapter, tok, inp, steps_unet, n_text, seed):
-    """One bench step, strictly sequential on the current stream."""
-    feats = front_half(vit, agent, tok, inp, n_text)
-    return feats, back_half(adapter, feats, steps_unet, seed)
+# ---------------------------------------------------------------------------------------------------------------------
+# workloads (one per BASELINE config)
+# ---------------------------------------------------------------------------------------------------------------------
+class Workload:
+    def __init__(self, a, dev, dtype):
+        self.a, self.dev, self.dtype, self.tok = a, dev, dtype, BenchTokenizer()
+        self.setup()
+
+    def flops(self):
+        raise NotImplementedError
+
+    def describe(self):
+        return CONFIGS[self.a.config]
 
 
+class Headline(Workload):
+    def setup(self):
+        self.vit, self.agent, self.adapter = build_models(self.dev, self.dtype)
+        self.inp = make_inputs(self.dev)
+        assert len(self.inp[1]) == 165
+
+    def step(self, seed):
+        feats = front_half(self.vit, self.agent, self.tok, self.inp, self.a.text_tokens, self.dev)
+        return back_half(self.adapter, feats, self.a.unet_steps, seed)
+
+    def flops(self):
+        return 2 * FLOP_VIT_CROP + (165 + 128) * FLOP_LLM_TOKEN + 2 * self.a.unet_steps * FLOP_UNET_SAMPLE \
+            + (FLOP_VAE_DECODE if USE_VAE else 0.0)
+
+    def describe(self):
+        return ("SEED-X-I: 448x448 uint8 image -> GPU any-res/resize/normalise (2 crops) -> ViT-G -> 165-token prefill -> "
+                "128 greedy tokens (%d text + <img> + 64 forced + </img>) -> %d-step SDXL-UNet CFG-2 de-tokenize @1024x1024 "
+                "-> %s" % (self.a.text_tokens, self.a.unet_steps,
+                           "SDXL VAE decode to a uint8 [1024,1024,3] image" if USE_VAE else "latents (VAE decode skipped)"))
+
+
+class DetokOneStep(Workload):                                                   # config 1
+    def setup(self):
+        self.vit, _, self.adapter = build_models(self.dev, self.dtype, need=("vit", "adapter"))
+        self.images, _ = make_inputs(self.dev)
+
+    def step(self, seed):
+        crops, _ = preprocess(self.images, self.dev)
+        x = crops[-1:].repeat(BATCH, 1, 1, 1)                                   # the 448² global view of each request
+        out = self.adapter.generate(image_tensor=x, num_inference_steps=1, seed=[seed * BATCH + g for g in range(BATCH)],
+                                    output_type="latent")
+        assert out.shape == (BATCH, 4, 128, 128)
+        return out
+
+    def flops(self):
+        return 2 * FLOP_VIT_CROP + 2 * FLOP_UNET_SAMPLE
+
+
+class Comprehension(Workload):                                                  # config 2
+    def setup(self):
+        self.vit, self.agent, _ = build_models(self.dev, self.dtype, need=("vit", "llm"))
+        self.inp = make_inputs(self.dev)
+
+    def step(self, seed):
+        reqs = requests_for(self.vit, self.inp, self.dev)
+        outs = self.agent.generate_batch(self.tok, reqs, max_new_tokens=128, eos_token_id=None)
+        assert all(len(o["generate_ids"]) == 128 for o in outs)
+        return outs
+
+    def flops(self):
+        return 2 * FLOP_VIT_CROP + (165 + 128) * FLOP_LLM_TOKEN
+
+
+class TextToImage(Workload):                                                    # config 3
+    def setup(self):
+        _, self.agent, self.adapter = build_models(self.dev, self.dtype, need=("llm", "adapter"))
+        g = torch.Generator().manual_seed(3)
+        self.ids = [1] + torch.randint(3, 32000, (63,), generator=g).tolist()
+
+    def step(self, seed):
+        reqs = [dict(input_ids=[self.ids]) for _ in range(BATCH)]
+        outs = self.agent.generate_batch(self.tok, reqs, max_new_tokens=8 + 66 + 1, eos_token_id=None, force_image_at=8)
+        feats = torch.cat([o["img_gen_feat"] for o in outs], dim=0)
+        return back_half(self.adapter, feats, self.a.unet_steps, seed)
+
+    def flops(self):
+        return (64 + 75) * FLOP_LLM_TOKEN + 2 * self.a.unet_steps * FLOP_UNET_SAMPLE + (FLOP_VAE_DECODE if USE_VAE else 0.0)
+
+
+class Edit(Workload):                                                           # config 4
+    def setup(self):
+        self.vit, self.agent, self.adapter = build_models(self.dev, self.dtype, edit=True)
+        self.inp = make_inputs(self.dev, extra_text=16)
+        self.src = torch.randn(1, 4, 128, 128, generator=torch.Generator().manual_seed(7))   # VAE-encoded source stand-in
+
+    def step(self, seed):
+        feats = front_half(self.vit, self.agent, self.tok, self.inp, 8, self.dev)
+        return back_half(self.adapter, feats, self.a.unet_steps, seed, image_latents=self.src.repeat(BATCH, 1, 1, 1))
+
+    def flops(self):
+        return 2 * FLOP_VIT_CROP + (181 + 75) * FLOP_LLM_TOKEN + 3 * self.a.unet_steps * FLOP_UNET_SAMPLE \
+            + (FLOP_VAE_DECODE if USE_VAE else 0.0)
+
+
+class MultiTurn(Workload):                                                      # config 5
+    def setup(self):
+        self.vit, self.agent, self.adapter = build_models(self.dev, self.dtype, max_cache_len=2304)
+        self.inp = make_inputs(self.dev, size=896, n_images=4)
+        g = torch.Generator().manual_seed(5)
+        self.turn_text = [torch.randint(3, 32000, (20,), generator=g).tolist() for _ in range(2)]
+        self.prefilled = None
+
+    def step(self, seed):
+        from seedx_amd import image_ops
+        T = BenchTokenizer
+        reqs = requests_for(self.vit, self.inp, self.dev)                       # ViT B = 20 per request
+        ids = list(self.inp[1])
+        pre = []
+        for turn in range(3):
+            last = turn == 2
+            for r in reqs:
+                r["input_ids"] = [ids]
+                r["ids_cmp_mask"] = image_ops.marker_mask(torch.tensor(ids, dtype=torch.long, device=self.dev), T.BOI,
+                                                          T.EOI, T.BOP, T.EOP).view(1, -1)
+            outs = self.agent.generate_batch(self.tok, reqs, max_new_tokens=(8 + 67) if last else 64, eos_token_id=None,
+                                             force_image_at=8 if last else None, reuse_cache=bool(self.a.kv_reuse))
+            pre.append(self.agent.last_prefill_tokens[0])
+            if not last:
+                ids = ids + outs[0]["generate_ids"].tolist() + self.turn_text[turn]   # every request shares the transcript
+        self.prefilled = pre
+        feats = torch.cat([o["img_gen_feat"] for o in outs], dim=0)
+        return back_half(self.adapter, feats, self.a.unet_steps, seed)
+
+    def flops(self):
+        T0 = len(self.inp[1])
+        toks = (T0 + 64) + (20 + 64) + (20 + 75) if self.a.kv_reuse else (T0 + 64) + (T0 + 84 + 64) + (T0 + 168 + 75)
+        return 20 * FLOP_VIT_CROP + toks * FLOP_LLM_TOKEN + 2 * self.a.unet_steps * FLOP_UNET_SAMPLE \
+            + (FLOP_VAE_DECODE if USE_VAE else 0.0)
+
+    def describe(self):
+        return CONFIGS[5] + "; cross-turn KV reuse %s (prefilled tokens per turn: %s; the reference re-prefills everything)" \
+            % ("ON" if self.a.kv_reuse else "OFF", self.prefilled)
+
+
+class StubWorkload(Workload):
+    """CPU stand-in used by the launch-path test (tests/test_cpu_suite.py): exercises argument parsing, rank start-up,
+    the barrier / max-over-ranks timing and the JSON line without a GPU or a model."""
+
+    def setup(self):
+        pass
+
+    def step(self, seed):
+        time.sleep(0.01)
+
+    def flops(self):
+        return 0.0
+
+
+WORKLOADS = {0: Headline, 1: DetokOneStep, 2: Comprehension, 3: TextToImage, 4: Edit, 5: MultiTurn}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 class Pipeline:
-    """Request-level software pipeline on two HIP streams: while the MFMA-bound de-tokenizer of request i runs on the
-    `back` stream, the HBM-bound LLM decode (and ViT) of request i+1 runs on the `front` stream. Every request still
-    executes all of its work; only the phases of CONSECUTIVE requests overlap."""
+    """Request-level software pipeline on two HIP streams (config 0 only): while the MFMA-bound de-tokenizer of request i
+    runs on the `back` stream, the HBM-bound LLM decode (and ViT) of request i+1 runs on the `front` stream. Every request
+    still executes all of its work; only the phases of CONSECUTIVE requests overlap."""
 
-    def __init__(self, vit, agent, adapter, tok, inp, steps_unet, n_text):
-        self.args = (vit, agent, adapter, tok, inp, steps_unet, n_text)
+    def __init__(self, w):
+        self.w = w
         self.s_front, self.s_back = torch.cuda.Stream(), torch.cuda.Stream()
         self.keep = []
 
     def submit(self, seed):
-        vit, agent, adapter, tok, inp, steps_unet, n_text = self.args
+        w = self.w
         with torch.cuda.stream(self.s_front):
-            feats = front_half(vit, agent, tok, inp, n_text)
+            feats = front_half(w.vit, w.agent, w.tok, w.inp, w.a.text_tokens, w.dev)
             ev = torch.cuda.Event()
             ev.record(self.s_front)
         with torch.cuda.stream(self.s_back):
             self.s_back.wait_event(ev)
-            lat = back_half(adapter, feats, steps_unet, seed)
+            lat = back_half(w.adapter, feats, w.a.unet_steps, seed)
         self.keep.append((feats, lat))          # keep tensors alive until both streams are drained
 
     def drain(self):
@@ -172,11 +373,11 @@ class Pipeline:
         return out
 
 
-def gemm_roofline(vit, agent, adapter, tok, inp, steps_unet, n_text):
-    """Instrumented (eager, un-graphed) generation with HIP events around EVERY sx_gemm launch on the launch stream:
-    per-launch algorithmic FLOPs (2·M·N·K, conv: 2·M·N·9·Cin) and duration. The GEMM/implicit-conv kernel is the
-    dominant kernel (≈85 % of algorithmic FLOPs)."""
-    from seedx_amd import _lib, ops
+def gemm_roofline(w):
+    """Instrumented (eager, un-graphed) step with HIP events around EVERY sx_gemm launch on the launch stream: per-launch
+    algorithmic FLOPs (2·M·N·K, conv: 2·M·N·9·Cin) and duration. The GEMM/implicit-conv kernel family is the dominant
+    kernel (≈85 % of algorithmic FLOPs)."""
+    from seedx_amd import _lib
     lib = _lib.load()
     real = lib.sx_gemm
     rec = []
@@ -196,14 +397,17 @@ def gemm_roofline(vit, agent, adapter, tok, inp, steps_unet, n_text):
             rec.append((2.0 * a.M * a.N * a.K, s, e, byt))
             return r
 
-    agent.use_graph, adapter._loop.use_graph = False, False
+    graphs = [m for m in (getattr(w, "agent", None), getattr(getattr(w, "adapter", None), "_loop", None)) if m is not None]
+    for m in graphs:
+        m.use_graph = False
     lib.sx_gemm = Hook()
     try:
-        one_generation(vit, agent, adapter, tok, inp, steps_unet, n_text, seed=1)
+        w.step(1)
         torch.cuda.synchronize()
     finally:
         lib.sx_gemm = real
-        agent.use_graph, adapter._loop.use_graph = True, True
+        for m in graphs:
+            m.use_graph = True
     ms = [s.elapsed_time(e) for _, s, e, _ in rec]
     fl = sum(r_[0] for r_ in rec)
     alg_bytes = sum(r_[3] for r_ in rec)
@@ -211,14 +415,17 @@ def gemm_roofline(vit, agent, adapter, tok, inp, steps_unet, n_text):
     n = len(rec)
     # traffic: bytes per launch from the rocprofv3 --pmc passes of THIS command (tools/bench_pmc_traffic.py; graph replay
     # crashes the counter collection on this pool, so the passes run the same step with eager launches). Only quoted
-    # when the stored profile was taken at the batch size being run.
-    traffic, tnote = None, "no PMC profile for this batch size"
-    try:
-        prof = json.load(open(os.path.join(ROOT, "profiles", "r1_bench_pmc_traffic.json")))
-        if prof.get("batch_per_gpu") == BATCH:
-            traffic, tnote = prof["traffic_bytes_per_launch"], prof["method"]
-    except (OSError, ValueError, KeyError):
-        pass
+    # when the stored profile was taken at the batch size / config being run.
+    traffic, tnote = None, "no PMC profile for this batch size / config"
+    for name in ("r2_bench_pmc_traffic.json", "r1_bench_pmc_traffic.json"):
+        try:
+            prof = json.load(open(os.path.join(ROOT, "profiles", name)))
+            if prof.get("batch_per_gpu") == BATCH and w.a.config == 0 and prof.get("kernels", "r1") == \
+                    ("r2" if name.startswith("r2") else "r1"):
+                traffic, tnote = prof["traffic_bytes_per_launch"], prof["method"]
+                break
+        except (OSError, ValueError, KeyError):
+            pass
     return {"bound": "mfma", "achieved": fl / tot_s / 1e12, "peak": PEAK_TFLOPS_16BIT, "unit": "TFLOP/s",
             "frac": fl / tot_s / 1e12 / PEAK_TFLOPS_16BIT, "traffic": traffic, "traffic_unit": "bytes/launch",
             "traffic_source": tnote, "algorithmic_bytes_per_launch": alg_bytes / n,
@@ -228,30 +435,33 @@ def gemm_roofline(vit, agent, adapter, tok, inp, steps_unet, n_text):
 
 
 def cpu_baseline():
-    """Bounded sample of the CPU oracle ("port": oracle/restated*.py, fp32 torch on the host cores), extrapolated by
-    layer count / algorithmic FLOPs to one full generation."""
+    """Bounded sample of the CPU oracle ("port": the functions of oracle/restated*.py, fp32 torch on the host's PHYSICAL
+    cores), extrapolated by layer count / algorithmic FLOPs to one config-0 generation."""
     from oracle import restated, restated_unet as ru, weights
-    torch.set_num_threads(os.cpu_count())
+    try:
+        import psutil
+        cores = psutil.cpu_count(logical=False) or os.cpu_count()
+    except Exception:
+        cores = os.cpu_count()
+    torch.set_num_threads(max(1, cores))
     cores = torch.get_num_threads()
     g = torch.Generator().manual_seed(0)
     t_total = 0.0
-    # (1) one of 48 ViT blocks at full width, B = 2 crops
-    W, heads, L = 1664, 16, 1024
-    import torch.nn.functional as F
-    x = torch.randn(2, L, W, generator=g)
-    wq, wo = torch.randn(3 * W, W, generator=g) * 0.02, torch.randn(W, W, generator=g) * 0.02
-    w1, w2 = torch.randn(8192, W, generator=g) * 0.02, torch.randn(W, 8192, generator=g) * 0.02
-
-    def vit_block(x):
-        h = F.layer_norm(x, (W,))
-        q, k, v = F.linear(h, wq).view(2, L, heads, 3 * 104).split(104, dim=-1)
-        a = torch.softmax((q.permute(0, 2, 1, 3) / math.sqrt(104)) @ k.permute(0, 2, 3, 1), -1) @ v.permute(0, 2, 1, 3)
-        x = x + F.linear(a.permute(0, 2, 1, 3).reshape(2, L, W), wo)
-        return x + F.linear(F.gelu(F.linear(F.layer_norm(x, (W,)), w1)), w2)
-    vit_block(x)
-    t0 = time.time(); vit_block(x); t_vit_layer = time.time() - t0
-    t_total += t_vit_layer * 48 * (FLOP_VIT_CROP * 2 / (2 * 2 * 42.8e9 * 48))   # + attn_pool/proj share by FLOPs
-    # (2) one of 40 Llama layers: prefill T=165 and 4 cached decode steps
+    # (1) oracle ViT (restated.vit_forward) at full width with 1 and 2 of the 48 blocks, B = 2 crops: the difference is one
+    #     block, the 1-block run carries patchify + attn_pool + proj
+    x = torch.randn(2, 3, 448, 448, generator=g)
+    t_vit = []
+    for layers in (1, 2):
+        cfg = dict(weights.FULL_VIT, layers=layers)
+        sd = weights.vit_sd(cfg)
+        restated.vit_forward(sd, cfg, x[:1])                                    # warm-up (allocator, threads)
+        t0 = time.time()
+        restated.vit_forward(sd, cfg, x)
+        t_vit.append(time.time() - t0)
+        del sd
+    t_block = max(t_vit[1] - t_vit[0], 1e-3)
+    t_total += t_vit[0] + 47 * t_block
+    # (2) oracle Llama (restated.llama_forward), one of 40 layers: prefill T=165 and 4 cached decode steps
     cfg = dict(weights.FULL_LLM, num_hidden_layers=1, vocab_size=512)
     sd = weights.llama_sd(cfg)
     xe = torch.randn(1, 165, 5120, generator=g)
@@ -262,7 +472,8 @@ def cpu_baseline():
     t_dec = (time.time() - t0) / 4
     n_new = 128
     t_total += 40 * (t_pre + n_new * t_dec)
-    # (3) SDXL UNet: mid-block resnet + one of its 10 transformer layers at 32x32, CFG batch 2 → scale by FLOPs
+    # (3) oracle SDXL UNet pieces (restated_unet._resnet / _transformer): mid-block resnet + one of its 10 transformer
+    #     layers at 32x32, CFG batch 2 → scaled by algorithmic FLOPs to the whole UNet
     ucfg = ru.FULL_UNET
     shapes = ru.unet_param_shapes(ucfg)
     usd = {}
@@ -283,99 +494,118 @@ def cpu_baseline():
                      + 4 * HW * HW * C + 4 * HW * 64 * C + 2 * 2 * 64 * 2048 * C)
     t_total += 50 * t_u * (2 * FLOP_UNET_SAMPLE / fl_sample)
     return {"value": 1.0 / t_total, "unit": "gens/s", "cores": cores, "kind": "port",
-            "sample": "oracle fp32 torch on host cores: 1 of 48 ViT-G blocks (B=2) %.2fs, 1 of 40 Llama-13B-dim layers "
-                      "(prefill T=165 %.2fs, cached decode %.3fs/token), SDXL mid-block resnet + 1 transformer layer @32x32 "
-                      "CFG-2 %.2fs; extrapolated by layer count / algorithmic FLOPs to one generation (%.0f s)"
-                      % (t_vit_layer, t_pre, t_dec, t_u, t_total)}
+            "sample": "oracle/restated*.py fp32 torch on %d host threads (physical cores): ViT-G with 1 and 2 of 48 blocks "
+                      "(B=2) %.2fs / %.2fs, 1 of 40 Llama-13B-dim layers (prefill T=165 %.2fs, cached decode %.3fs/token), "
+                      "SDXL mid-block resnet + 1 transformer layer @32x32 CFG-2 %.2fs; extrapolated by layer count / "
+                      "algorithmic FLOPs to one config-0 generation (%.0f s)"
+                      % (cores, t_vit[0], t_vit[1], t_pre, t_dec, t_u, t_total)}
 
 
-def main():
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", type=int, default=0, choices=sorted(CONFIGS), help="; ".join(f"{k}: {v}" for k, v in CONFIGS.items()))
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
     ap.add_argument("--unet-steps", type=int, default=50)
     ap.add_argument("--text-tokens", type=int, default=61)
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay (profiling aid)")
     ap.add_argument("--overlap", type=int, default=0,
                     help="1: pipeline consecutive requests on two streams (LLM decode of request i+1 under the UNet of request i)")
-    ap.add_argument("--batch", type=int, default=16,
-                    help="independent generations processed together per GPU per step (1 = single-request latency mode)")
+    ap.add_argument("--batch", type=int, default=None,
+                    help="independent generations processed together per GPU per step (default 16; config 5: 4; 1 = latency mode)")
+    ap.add_argument("--kv-reuse", type=int, default=1, help="config 5: keep the KV cache across turns (0 = re-prefill like the reference)")
     ap.add_argument("--no-vae", action="store_true", help="stop at the denoised latents (no VAE decode)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    a = ap.parse_args()
-    global BATCH
-    BATCH = a.batch
-    global USE_VAE
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: CPU launch-path test only (with --stub)")
+    ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)
+    return ap.parse_args(argv)
+
+
+def main(argv=None):
+    a = parse_args(argv)
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no external launcher: start the N ranks ourselves (one process per GPU over RCCL) and hand over
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr",
+               "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(sys.argv[1:] if argv is None else argv)
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        raise SystemExit(subprocess.run(cmd, env=env).returncode)
+    global BATCH, USE_VAE
+    BATCH = a.batch if a.batch is not None else (4 if a.config == 5 else 16)
+    a.batch = BATCH
     USE_VAE = not a.no_vae
     from seedx_amd import dist_utils as du
-    ctx = du.init("nccl")                       # RCCL over xGMI; only barrier + max-reduce of the wall time
+    ctx = du.init(a.backend)                    # RCCL over xGMI; only barrier + max-reduce of the wall time
     rank, world, local = ctx.rank, ctx.world, ctx.local
-    assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but {world} rank(s) came up (WORLD_SIZE={os.environ.get('WORLD_SIZE')})")
+    gpu = not a.stub
+    if gpu:
+        torch.cuda.set_device(local)
+    dev = torch.device("cuda", local) if gpu else torch.device("cpu")
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float16
-    tok = BenchTokenizer()
+    sync = torch.cuda.synchronize if gpu else (lambda: None)
     with torch.no_grad():
-        vit, agent, adapter = build_models(dev, dtype)
-        inp = make_inputs(dev)
-        if a.no_graph:
-            agent.use_graph = False
-            adapter._loop.use_graph = False
+        w = (StubWorkload if a.stub else WORKLOADS[a.config])(a, dev, dtype)
+        if a.no_graph and gpu:
+            for m in (getattr(w, "agent", None), getattr(getattr(w, "adapter", None), "_loop", None)):
+                if m is not None:
+                    m.use_graph = False
         seeds = du.shard_seeds(ctx, a.steps)      # independent requests, round-robin over ranks
-        pipe = Pipeline(vit, agent, adapter, tok, inp, a.unet_steps, a.text_tokens) if a.overlap else None
+        pipe = Pipeline(w) if (a.overlap and a.config == 0 and gpu) else None
 
         def run(seed_list):
             if pipe is None:
                 for sd_ in seed_list:
-                    one_generation(vit, agent, adapter, tok, inp, a.unet_steps, a.text_tokens, seed=sd_)
+                    w.step(sd_)
             else:
                 for sd_ in seed_list:
                     pipe.submit(sd_)
                 pipe.drain()
         run([100 + i for i in range(a.warmup)])
-        torch.cuda.synchronize()
+        sync()
         du.barrier(ctx)
-        torch.cuda.synchronize()
+        sync()
         t0 = time.perf_counter()
         run(seeds)
-        torch.cuda.synchronize()
+        sync()
         du.barrier(ctx)
-        torch.cuda.synchronize()
+        sync()
         dt = du.max_over_ranks(ctx, time.perf_counter() - t0)
         roof = None
-        if rank == 0 and not a.no_roofline:
-            roof = gemm_roofline(vit, agent, adapter, tok, inp, a.unet_steps, a.text_tokens)
+        if rank == 0 and gpu and not a.no_roofline:
+            roof = gemm_roofline(w)
     if rank == 0:
         total = du.total_units(ctx, a.steps) * a.batch
-        rec = {"metric": "end-to-end generations/sec (img-in -> txt + 1024px-img-out)", "value": total / dt,
+        rec = {"metric": "end-to-end generations/sec (img-in -> txt + 1024px-img-out)" if a.config == 0 else
+               "generations/sec of BASELINE config %d" % a.config, "value": total / dt,
                "unit": "gens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": a.dtype, "data": "synthetic (seeded random image/prompt, random-init weights of the real dims)",
-               "config": {"workload": "SEED-X-I: 1x448px image (2 crops ViT-G) -> 165-token prefill -> 128 greedy tokens "
-                                      "(%d text + <img> + 64 forced + </img>) -> %d-step SDXL-UNet CFG-2 de-tokenize "
-                                      "@1024x1024 -> %s" % (a.text_tokens, a.unet_steps,
-                                                            "SDXL VAE decode to a [3,1024,1024] image" if USE_VAE
-                                                            else "latents (VAE decode skipped)"),
+               "dtype": a.dtype if gpu else "none",
+               "data": "synthetic (seeded random uint8 image / prompt ids, random-init weights of the real dims)",
+               "config": {"workload": w.describe() if gpu else "stub (launch-path test)", "baseline_config": a.config,
                           "parallelism": "replica x%d (independent generations, no data-path collective)" % world,
-                          "batch_per_gpu": a.batch,
-                          "request_pipelining": bool(a.overlap)},
-               "flops_per_generation": 2 * FLOP_VIT_CROP + (165 + 128) * FLOP_LLM_TOKEN + 2 * a.unet_steps * FLOP_UNET_SAMPLE
-               + (FLOP_VAE_DECODE if USE_VAE else 0.0),
-               "generations_per_step": a.batch}
+                          "batch_per_gpu": a.batch, "request_pipelining": bool(a.overlap)},
+               "flops_per_generation": w.flops(), "generations_per_step": a.batch}
         rec["model_tflops"] = rec["flops_per_generation"] * rec["value"] / world / 1e12
         if roof is not None:
             rec["roofline"] = roof
-        if not a.no_cpu_baseline and world == 1:
+        if gpu and not a.no_cpu_baseline and world == 1:
             try:
                 rec["cpu_baseline"] = cpu_baseline()
             except Exception as ex:  # the oracle is optional infrastructure; never fail the measurement on it
                 rec["cpu_baseline"] = {"error": repr(ex)}
         print(json.dumps(rec), flush=True)
     du.barrier(ctx)                 # rank 0 ran the instrumented roofline pass alone: tear the group down together
-    if world > 1:
+    if world > 1 and gpu:
         torch.cuda.synchronize()
     du.finalize(ctx)
 

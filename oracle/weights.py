@@ -29,7 +29,7 @@ FULL_XLV2 = dict(dim=1024, depth=4, dim_head=64, heads=16, num_queries=64, embed
 # mini de-tokenizer stack of tests/golden/{t2i,edit}_mini.npz (oracle/gen_golden.py runs the reference adapters on it)
 DETOK_VIT = dict(image_size=112, patch_size=14, width=256, layers=2, heads=2, mlp_ratio=2.0, n_queries=64, output_dim=256)
 DETOK_XLV2 = dict(MINI_XLV2, embedding_dim=256)
-DETOK_VAE = dict(latent_channels=4, out_channels=3, block_out_channels=(32, 32, 64, 64), layers_per_block=1,
+DETOK_VAE = dict(latent_channels=4, out_channels=3, block_out_channels=(64, 64, 128, 128), layers_per_block=1,
                  norm_groups=32, scaling_factor=0.13025)
 
 

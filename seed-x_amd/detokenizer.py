@@ -10,7 +10,7 @@ Reference interfaces mirrored (same names, argument meaning, defaults):
   * ``EulerDiscreteScheduler`` [ext] with the SDXL scheduler config (eval_seed_x_detokenizer.py:30)
 ``generate`` returns what the reference returns — a list of PIL images (``sdxl_pipe(...).images``,
 adapter_modules.py:156-169 / :273-287) — whenever a VAE was given to ``init_pipe``; without a VAE (the reference would
-fail there) it returns the final latents. ``output_type`` ("pil" | "np" | "pt" | "latent" | "raw") overrides, exactly like
+fail there) it returns the final latents. ``output_type`` ("pil" | "np" | "pt" | "latent" | "raw" | "u8" = device uint8 [B,H,W,3]) overrides, exactly like
 the ``**kwargs`` the reference forwards to the diffusers pipeline.
 
 One denoise step = {time embeddings → UNet (CFG batch 2 or 3) → fused CFG + Euler update + next scaled input}, all
@@ -425,9 +425,9 @@ class SDXLAdapter:
         img = self.vae.decode(latents / scaling, return_dict=False)[0]
         if output_type == "raw":                                                     # decoder output, no post-processing
             return img
-        if output_type == "pil":                                                     # fused denormalise → uint8 HWC kernel
-            from .image_ops import images_to_pil
-            return images_to_pil(img.float())
+        if output_type in ("pil", "u8"):                                             # fused denormalise → uint8 HWC kernel
+            from .image_ops import images_to_pil, images_to_u8
+            return images_to_pil(img.float()) if output_type == "pil" else images_to_u8(img.float())   # u8: stays in HBM
         img = (img / 2 + 0.5).clamp(0, 1)
         if output_type == "pt":
             return img

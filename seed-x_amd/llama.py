@@ -179,32 +179,60 @@ class LlamaForCausalLM:
         P["step"][s] = 0
         P["ctx"][s] = 1                 # invariant: ctx == pos + 1 (keys visible to the token at `pos`)
 
-    def _layers_multi(self, x, T, seq):
-        """T tokens of sequence `seq` at positions pos..pos+T-1 (prefill or a forced-token chunk): MFMA GEMMs + causal
-        flash attention over that sequence's cache. x: fp32 [T, H] residual stream. Returns the final residual stream."""
+    def _layers_multi(self, x, Ts, seqs):
+        """Ts[i] tokens appended to sequence seqs[i] at its cache position (prefill of several prompts, or the forced
+        image-token chunk of several sequences, as ONE pass): every GEMM runs on all sum(Ts) rows at once — the weights
+        stream once per pass instead of once per sequence — while RoPE / KV append / causal flash attention stay per
+        sequence (batched into single launches when all sequences share T and position). x: fp32 [sum(Ts), H] residual
+        stream, rows ordered like seqs. Returns the final residual stream."""
         P, dt, H, nh, hd = self._P, self.dtype, self.H_l, self.nh_l, self.hd     # local heads under tensor parallelism
         comm, lead = self.comm, self.comm.rank == 0
-        pos_v, ctx_v = P["pos"][seq:seq + 1], P["ctx"][seq:seq + 1]
-        pos0 = int(pos_v.item())
-        Tk = pos0 + T
-        assert Tk <= self.Tmax, f"sequence {Tk} exceeds the KV cache ({self.Tmax})"
+        n = len(seqs)
+        pos_all = P["pos"].tolist()                                              # one host read per pass
+        pos0 = [pos_all[g] for g in seqs]
+        for T, p0 in zip(Ts, pos0):
+            assert p0 + T <= self.Tmax, f"sequence {p0 + T} exceeds the KV cache ({self.Tmax})"
+        uniform = n > 1 and len(set(Ts)) == 1 and len(set(pos0)) == 1 and list(seqs) == list(range(seqs[0], seqs[0] + n))
+        offs = [0]
+        for T in Ts:
+            offs.append(offs[-1] + T)
+        M = offs[-1]
         eps = self.config.rms_norm_eps
         scale = 1.0 / math.sqrt(hd)
+        g0 = seqs[0]
         for li, lw in enumerate(P["layers"]):
-            kc, vc = P["kc"][li][seq], P["vc"][li][seq]
+            kc_l, vc_l = P["kc"][li], P["vc"][li]
             h = ops.rmsnorm(x, lw["ln1"], eps, dt)
-            qkv = ops.gemm(h, lw["wqkv"])                                             # [T, 3H]
-            ops.rope_kv_append(qkv, kc, vc, P["cos"], P["sin"], pos_v, nh, hd)
-            q4 = qkv.view(1, T, 3, nh, hd)[:, :, 0]
-            k4 = kc[:, :Tk].permute(1, 0, 2).unsqueeze(0)                              # [1, Tk, nh, hd] view of the cache
-            v4 = vc[:, :Tk].permute(1, 0, 2).unsqueeze(0)
-            att = ops.attention(q4, k4, v4, scale, causal=True)                       # [1, T, H]
-            x = comm.all_reduce(ops.gemm(att.view(T, H), lw["wo"], residual=x if lead else None, out_dtype=torch.float32))
+            qkv = ops.gemm(h, lw["wqkv"])                                             # [M, 3H]
+            if uniform:
+                T, Tk = Ts[0], pos0[0] + Ts[0]
+                ops.rope_kv_append_b(qkv, kc_l[g0:g0 + n], vc_l[g0:g0 + n], P["cos"], P["sin"], P["pos"][g0:g0 + n], n, T,
+                                     nh, hd)
+                q4 = qkv.view(n, T, 3, nh, hd)[:, :, 0]
+                k4 = kc_l[g0:g0 + n, :, :Tk].permute(0, 2, 1, 3)                      # [n, Tk, nh, hd] views of the caches
+                v4 = vc_l[g0:g0 + n, :, :Tk].permute(0, 2, 1, 3)
+                att = ops.attention(q4, k4, v4, scale, causal=True).view(M, H)
+            else:
+                att = torch.empty((M, H), dtype=dt, device=x.device)
+                for i, g in enumerate(seqs):
+                    T, Tk = Ts[i], pos0[i] + Ts[i]
+                    rows = qkv[offs[i]:offs[i + 1]]
+                    ops.rope_kv_append(rows, kc_l[g], vc_l[g], P["cos"], P["sin"], P["pos"][g:g + 1], nh, hd)
+                    q4 = rows.view(1, T, 3, nh, hd)[:, :, 0]
+                    k4 = kc_l[g][:, :Tk].permute(1, 0, 2).unsqueeze(0)                # [1, Tk, nh, hd] view of the cache
+                    v4 = vc_l[g][:, :Tk].permute(1, 0, 2).unsqueeze(0)
+                    ops.attention(q4, k4, v4, scale, causal=True, out=att[offs[i]:offs[i + 1]].view(1, T, H))
+            x = comm.all_reduce(ops.gemm(att, lw["wo"], residual=x if lead else None, out_dtype=torch.float32))
             h = ops.rmsnorm(x, lw["ln2"], eps, dt)
-            g = ops.gemm(h, lw["wgu"], act="silu", glu=True)                          # silu(gate) * up, [T, I/tp]
-            x = comm.all_reduce(ops.gemm(g, lw["wd"], residual=x if lead else None, out_dtype=torch.float32))
-        ops.add_i32(pos_v, T)
-        ops.add_i32(ctx_v, T)
+            g_ = ops.gemm(h, lw["wgu"], act="silu", glu=True)                         # silu(gate) * up, [M, I/tp]
+            x = comm.all_reduce(ops.gemm(g_, lw["wd"], residual=x if lead else None, out_dtype=torch.float32))
+        if uniform:
+            ops.add_i32(P["pos"][g0:g0 + n], Ts[0])
+            ops.add_i32(P["ctx"][g0:g0 + n], Ts[0])
+        else:
+            for i, g in enumerate(seqs):
+                ops.add_i32(P["pos"][g:g + 1], Ts[i])
+                ops.add_i32(P["ctx"][g:g + 1], Ts[i])
         return x
 
     def _layers_single(self, x):
@@ -237,7 +265,7 @@ class LlamaForCausalLM:
         if T == 1 and self.G == 1:
             x = self._layers_single(x)
         else:
-            x = self._layers_multi(x, T, seq)
+            x = self._layers_multi(x, [T], [seq])
         hn = ops.rmsnorm(x, P["norm"], self.config.rms_norm_eps, torch.float32)      # :595
         logits = None
         if need_logits:
@@ -245,6 +273,30 @@ class LlamaForCausalLM:
             if self.tp > 1:
                 logits = self.comm.all_gather(logits).reshape(-1)                     # [tp, V/tp] → [Vpad], vocab order
         return logits, hn
+
+    def forward_embeds_batch(self, xs, seqs, need_logits=True):
+        """xs[i]: fp32 [T_i, H] appended to sequence seqs[i]; all sequences in one pass (see _layers_multi).
+        Returns (logits fp32 [n, Vpad] of each sequence's LAST position or None, list of final-norm states [T_i, H])."""
+        P = self._pack()
+        Ts = [int(x.shape[0]) for x in xs]
+        x = torch.cat([x.to(device=self.device, dtype=torch.float32) for x in xs], dim=0).contiguous()   # plumbing
+        x = self._layers_multi(x, Ts, list(seqs))
+        hn = ops.rmsnorm(x, P["norm"], self.config.rms_norm_eps, torch.float32)
+        ends = torch.tensor([sum(Ts[:i + 1]) - 1 for i in range(len(Ts))], device=self.device)
+        logits = None
+        if need_logits:
+            last = ops.cast(hn[ends].contiguous(), self.dtype)                         # [n, H]
+            logits = ops.linear(last, P["lm_head"], out_dtype=torch.float32)
+            if self.tp > 1:
+                logits = self.comm.all_gather(logits).permute(1, 0, 2).reshape(len(Ts), self.Vpad).contiguous()
+        return logits, list(torch.split(hn, Ts, dim=0))
+
+    def set_position(self, seq, pos):
+        """Truncate / rewind sequence `seq`'s KV cache to `pos` tokens (cross-turn prefix reuse)."""
+        P = self._pack()
+        assert 0 <= pos <= self.Tmax
+        P["pos"][seq] = pos
+        P["ctx"][seq] = pos + 1
 
     # reference-style entry (prefill + cached steps through inputs_embeds / input_ids), batch 1
     def forward(self, input_ids=None, inputs_embeds=None, past_key_values=None, use_cache=True,

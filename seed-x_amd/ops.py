@@ -149,8 +149,8 @@ def gemv(x, w, residual=None, act=None, glu=False, out_dtype=None):
 
 
 def linear(x, w, **kw):
-    """Dispatch M <= 8 rows to the weight-streaming GEMV (when the epilogue allows), else the MFMA GEMM."""
-    if x.shape[0] <= 8 and kw.get("bias") is None and kw.get("bias2d") is None and not kw.get("res_mod") \
+    """Dispatch M <= 16 rows to the weight-streaming GEMV / skinny GEMM (when the epilogue allows), else the MFMA GEMM."""
+    if x.shape[0] <= 16 and kw.get("bias") is None and kw.get("bias2d") is None and not kw.get("res_mod") \
             and kw.get("out") is None and not kw.get("n_valid"):
         res = kw.get("residual")
         if res is None or res.is_contiguous():

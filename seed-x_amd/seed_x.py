@@ -29,6 +29,8 @@ class ContinuousLVLM:
         self.device, self.dtype = None, torch.float16
         self.use_graph = True
         self.chunk_forced_image_tokens = True
+        self._conv = {}                  # sequence → (token ids, row fingerprints) currently held by its KV cache
+        self.last_prefill_tokens = []
 
     @classmethod
     def from_pretrained(cls, llm, input_resampler, output_resampler, pretrained_model_path=None, **kwargs):
@@ -96,11 +98,48 @@ class ContinuousLVLM:
         return input_ids, x
 
     @torch.no_grad()
+    def _row_sig(self, x):
+        """Per-row fingerprint of prompt embeddings (fp32 [T, H]) used to validate a cached prefix bit for bit."""
+        return x.view(torch.int32).sum(dim=1, dtype=torch.int64)
+
+    def _reuse_prefix(self, prompts):
+        """Cross-turn KV reuse (no reference counterpart: seed_x.py:184-189 re-prefills the whole conversation every turn).
+        For sequence g the cache still holds the previous call's prompt + the generated tokens that were fed back. The new
+        prompt's longest prefix whose token ids AND embedding rows (image features included) are identical to what produced
+        those cache entries is kept; only the rest is prefilled. Returns the prefix length per sequence."""
+        starts = []
+        for g, (ids, x) in enumerate(prompts):
+            prev = self._conv.get(g)
+            p = 0
+            if prev is not None:
+                old_ids, old_sig = prev
+                m = min(len(old_ids), len(ids) - 1)                                   # >= 1 token must be forwarded
+                while p < m and old_ids[p] == ids[p]:
+                    p += 1
+                if p:
+                    same = (self._row_sig(x[:p]) == old_sig[:p]).to(torch.int32)
+                    p = int(torch.cumprod(same, 0).sum().item())
+            starts.append(p)
+        return starts
+
+    def _remember(self, g, prompt, gen_ids_fed):
+        """Records what sequence g's KV cache now holds: the prompt rows and the generated tokens that were fed back."""
+        ids, x = prompt
+        sig = self._row_sig(x)
+        if len(gen_ids_fed):
+            P = self.llm._P
+            e = ops.embedding(torch.tensor(gen_ids_fed, dtype=torch.int32, device=x.device), P["embed"])
+            sig = torch.cat([sig, self._row_sig(e)])
+        self._conv[g] = (list(ids) + list(gen_ids_fed), sig)
+
+    @torch.no_grad()
     def generate_batch(self, tokenizer, requests, num_img_gen_tokens=64, max_new_tokens=120, eos_token_id="auto",
-                       force_image_at=None):
+                       force_image_at=None, reuse_cache=False):
         """G = len(requests) = llm.G independent requests decoded in lock step. Each request is a dict with the
         ``generate`` keyword arguments (input_ids | prompt, image_embeds, embeds_cmp_mask, ids_cmp_mask,
-        patch_positions). Returns one reference-style result dict per request."""
+        patch_positions). Returns one reference-style result dict per request.
+        ``reuse_cache``: keep each sequence's KV cache across calls and prefill only the part of the new prompt that is not
+        already in it (multi-turn conversations; results are identical to a full re-prefill)."""
         llm = self.llm
         dev, H, G = llm.device, llm.H, len(requests)
         P = llm._pack()
@@ -116,16 +155,23 @@ class ContinuousLVLM:
         out_ids = torch.full((G, rows), -1, dtype=torch.int32, device=dev)
         hid = torch.zeros((G, rows, H), dtype=torch.float32, device=dev)                    # row k = state at input new[k-1]
 
-        # ---- prefill every request, first token -----------------------------------------------------------------
-        llm.reset()
-        logits = torch.empty((G, llm.Vpad), dtype=torch.float32, device=dev)
-        last_ids = []
-        for g, req in enumerate(requests):
-            input_ids, x = self._prompt_embeds(tokenizer, req)
+        # ---- prefill every request (ONE batched pass: M = sum of the prompt lengths), first token --------------------
+        prompts = [self._prompt_embeds(tokenizer, req) for req in requests]
+        starts = self._reuse_prefix(prompts) if reuse_cache else [0] * G
+        if not reuse_cache:
+            llm.reset()
+            self._conv = {}
+        xs, last_ids = [], []
+        for g, (input_ids, x) in enumerate(prompts):
             assert len(input_ids) + rows <= llm.Tmax, "KV cache too small for prompt + max_new_tokens"
-            lg, _ = llm.forward_embeds(x, seq=g)
-            logits[g] = lg
+            if reuse_cache:
+                llm.set_position(g, starts[g])
+            xs.append(x[starts[g]:])
             last_ids.append(input_ids[-1])
+        P["step"].zero_()
+        logits, _ = llm.forward_embeds_batch(xs, list(range(G)))
+        logits = logits.contiguous()
+        self.last_prefill_tokens = [int(x.shape[0]) for x in xs]
         P["cur"].copy_(torch.tensor(last_ids, dtype=torch.int32))
         ops.greedy_next_b(logits, llm.V, img_ids_dev, P["cur"], out_ids, P["step"])
         ops.add_i32(P["step"], 1)
@@ -149,14 +195,18 @@ class ContinuousLVLM:
         final_n = [n_new[g] if done[g] else None for g in range(G)]
         # ---- token loop ---------------------------------------------------------------------------------------------
         while not all(done):
-            for g in range(G):
-                if not done[g] and self.chunk_forced_image_tokens and cur[g] == boi_id and n_new[g] + nchunk <= max_new_tokens:
-                    # inputs [<img>, <img_0> … <img_63>] as one causal chunk; outputs are forced (generation.py:23-26)
-                    chunk = torch.tensor([boi_id] + img_ids[1:-1], dtype=torch.int32, device=dev)
-                    xe = ops.embedding(chunk, P["embed"])
-                    _, hn = llm.forward_embeds(xe, need_logits=False, seq=g)
+            hit = [g for g in range(G) if not done[g] and self.chunk_forced_image_tokens and cur[g] == boi_id
+                   and n_new[g] + nchunk <= max_new_tokens]
+            if hit:
+                # inputs [<img>, <img_0> … <img_63>] as one causal chunk per sequence, all such sequences in ONE pass;
+                # the outputs are forced (generation.py:23-26)
+                chunk = torch.tensor([boi_id] + img_ids[1:-1], dtype=torch.int32, device=dev)
+                xe = ops.embedding(chunk, P["embed"])
+                _, hns = llm.forward_embeds_batch([xe] * len(hit), hit, need_logits=False)
+                forced = torch.tensor(img_ids[1:], dtype=torch.int32, device=dev)
+                for g, hn in zip(hit, hns):
                     hid[g, n_new[g]:n_new[g] + nchunk] = hn                                  # plumbing copy
-                    out_ids[g, n_new[g]:n_new[g] + nchunk] = torch.tensor(img_ids[1:], dtype=torch.int32, device=dev)
+                    out_ids[g, n_new[g]:n_new[g] + nchunk] = forced
                     n_new[g] += nchunk
                     P["step"][g] = n_new[g]
                     P["cur"][g] = eoi_id
@@ -179,6 +229,8 @@ class ContinuousLVLM:
         for g in range(G):
             n = final_n[g]
             generate_ids = out_ids[g, :n].cpu().long()
+            if reuse_cache:
+                self._remember(g, prompts[g], generate_ids[:n - 1].tolist())          # the last new token was never fed
             last_hidden = hid[g, 1:n]                                                        # seed_x.py:196-197
             eoi_indices = torch.where(generate_ids == eoi_id)[0].tolist()                    # :199
             text_mask = torch.ones_like(generate_ids, dtype=torch.bool)
@@ -201,7 +253,7 @@ class ContinuousLVLM:
     def generate(self, tokenizer, prompt=None, input_ids=None, image_embeds=None, embeds_cmp_mask=None,
                  ids_cmp_mask=None, logits_processor=None, num_img_gen_tokens=64, temperature=0.7, num_beams=1,
                  max_new_tokens=120, top_p=0.5, dtype=torch.float16, device='cuda', patch_positions=None,
-                 eos_token_id="auto", force_image_at=None):
+                 eos_token_id="auto", force_image_at=None, reuse_cache=False):
         """Reference signature (seed_x.py:130-145). Greedy (do_sample=False, num_beams=1 — temperature/top_p are inert in
         the reference too, :175-189). ``eos_token_id``: "auto" → tokenizer.eos_token_id; None disables the EOS stop."""
         assert logits_processor is None, "the AutoImageTokenGenerationProcessor rule is fused on the device"
@@ -209,4 +261,5 @@ class ContinuousLVLM:
         assert self.llm.G == 1, "this LLM was built for lock-step batches: use generate_batch()"
         req = dict(prompt=prompt, input_ids=input_ids, image_embeds=image_embeds, embeds_cmp_mask=embeds_cmp_mask,
                    ids_cmp_mask=ids_cmp_mask, patch_positions=patch_positions)
-        return self.generate_batch(tokenizer, [req], num_img_gen_tokens, max_new_tokens, eos_token_id, force_image_at)[0]
+        return self.generate_batch(tokenizer, [req], num_img_gen_tokens, max_new_tokens, eos_token_id, force_image_at,
+                                   reuse_cache)[0]

@@ -53,3 +53,65 @@ def test_generate_batch_equals_single_runs(dev):
                                  reqs[1]["embeds_cmp_mask"], reqs[1]["ids_cmp_mask"], reqs[1]["patch_positions"],
                                  list(range(400, 466)), 400, 465, 28, 16, None, None, batch[1]["generate_ids"].tolist(), trace)
     assert relerr(batch[1]["last_hidden_states"], ref["last_hidden"]) < 4e-3
+
+
+def test_uniform_batched_prefill_and_chunk_equal_single_runs(dev):
+    """All requests share prompt length and position → the batched RoPE / flash-attention launches (one per layer for the
+    whole batch) are taken; the results must still equal separate single-request runs."""
+    dtype, cfg, vit_dim = torch.float16, weights.MINI_LLM, 128
+    sd_llm = weights.llama_sd(cfg)
+    sd_agent = weights.agent_sd(cfg, vit_dim, in_grid=4, out_grid=4)
+    g = torch.Generator().manual_seed(33)
+    reqs = []
+    for r in range(4):
+        ids = [1, 10 + r] + [0] * 16 + [20 + r + i for i in range(6)]
+        mask = torch.zeros(1, len(ids), dtype=torch.bool)
+        mask[0, 2:18] = True
+        reqs.append(dict(input_ids=[ids], image_embeds=torch.randn(1, 36, vit_dim, generator=g).to(dev),
+                         embeds_cmp_mask=torch.tensor([True]), ids_cmp_mask=mask, patch_positions=torch.tensor([[0.5, 0.5]])))
+    tok = StubTokenizer()
+    kw = dict(num_img_gen_tokens=16, max_new_tokens=26, eos_token_id=None, force_image_at=3)
+    batch = _agent(dev, dtype, sd_llm, sd_agent, cfg, vit_dim, 4).generate_batch(tok, reqs, **kw)
+    single = _agent(dev, dtype, sd_llm, sd_agent, cfg, vit_dim, 1)
+    for r in range(4):
+        one = single.generate_batch(tok, [reqs[r]], **kw)[0]
+        assert batch[r]["generate_ids"].tolist() == one["generate_ids"].tolist()
+        assert relerr(batch[r]["last_hidden_states"], one["last_hidden_states"]) < 2e-3
+        assert relerr(batch[r]["img_gen_feat"], one["img_gen_feat"]) < 2e-3
+
+
+def test_cross_turn_kv_reuse_equals_full_reprefill(dev):
+    """Three-turn conversation (layout of src/data/sft_clm.py:229-276). With reuse_cache the second and third turns
+    prefill only their new tokens, and the generated ids / hidden states are identical to re-prefilling the whole
+    transcript like the reference does (seed_x.py:184-189). A changed image invalidates the cached prefix."""
+    dtype, cfg, vit_dim = torch.float16, weights.MINI_LLM, 128
+    sd_llm = weights.llama_sd(cfg)
+    sd_agent = weights.agent_sd(cfg, vit_dim, in_grid=4, out_grid=4)
+    g = torch.Generator().manual_seed(44)
+    img = torch.randn(1, 36, vit_dim, generator=g).to(dev)
+    tok = StubTokenizer()
+    kw = dict(num_img_gen_tokens=16, max_new_tokens=10, eos_token_id=None)
+    reuse = _agent(dev, dtype, sd_llm, sd_agent, cfg, vit_dim, 1)
+    full = _agent(dev, dtype, sd_llm, sd_agent, cfg, vit_dim, 1)
+
+    def req(ids):
+        mask = torch.zeros(1, len(ids), dtype=torch.bool)
+        mask[0, 2:18] = True
+        return dict(input_ids=[ids], image_embeds=img, embeds_cmp_mask=torch.tensor([True]), ids_cmp_mask=mask,
+                    patch_positions=torch.tensor([[0.5, 0.5]]))
+    ids = [1, 30] + [0] * 16 + [31, 32, 33, 34]
+    prefilled = []
+    for turn in range(3):
+        a = reuse.generate_batch(tok, [req(ids)], reuse_cache=True, **kw)[0]
+        prefilled.append(reuse.last_prefill_tokens[0])
+        b = full.generate_batch(tok, [req(ids)], **kw)[0]
+        assert a["generate_ids"].tolist() == b["generate_ids"].tolist(), turn
+        assert relerr(a["last_hidden_states"], b["last_hidden_states"]) < 1e-3
+        ids = ids + a["generate_ids"].tolist() + [50 + turn, 51, 52]            # answer + the next user turn
+    assert prefilled[0] == 22 and prefilled[1] == 1 + 3 and prefilled[2] == 1 + 3, prefilled   # last answer token + new turn
+    # same ids, different image → the fingerprint mismatch at the first image row cuts the reusable prefix to 2 tokens
+    img = torch.randn(1, 36, vit_dim, generator=g).to(dev)
+    a = reuse.generate_batch(tok, [req(ids)], reuse_cache=True, **kw)[0]
+    assert reuse.last_prefill_tokens[0] == len(ids) - 2
+    b = full.generate_batch(tok, [req(ids)], **kw)[0]
+    assert a["generate_ids"].tolist() == b["generate_ids"].tolist()

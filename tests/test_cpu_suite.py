@@ -280,6 +280,22 @@ def test_two_rank_gloo_aggregation(tmp_path):
     assert rec["t"] == 2.0 and rec["total"] == 6 and rec["seeds"] == [0, 2, 4]
 
 
+def test_bench_gpus2_launches_two_ranks_itself():
+    """`python bench.py --gpus 2` with no external launcher must start two ranks (re-exec under torch.distributed.run) and
+    report n_gpus 2; a rank count that does not match --gpus is an error. gloo + the stub workload: no GPU, no model."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                          "--backend", "gloo", "--stub", "--batch", "4"], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["scaling"] == "weak" and rec["generations_per_step"] == 4
+    assert abs(rec["value"] - 2 * 3 * 4 / (rec["ms_per_step"] * 3 / 1e3)) < 1e-6 * rec["value"]
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--stub"],
+                         capture_output=True, text=True, timeout=120, env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
+    assert bad.returncode != 0 and "rank(s) came up" in (bad.stderr + bad.stdout)
+
+
 # ---- tensor-parallel host logic (parallel.py) ------------------------------------------------------------------------
 def test_llama_tp_shard_reconstructs_full_layer():
     """Megatron slices of one decoder layer: column-parallel outputs concatenate, row-parallel partial products sum, to

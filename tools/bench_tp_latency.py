@@ -46,7 +46,7 @@ def main():
         inp = bench.make_inputs(dev)
 
         def one(seed):
-            feats = bench.front_half(vit, agent, tok, inp, a.text_tokens)
+            feats = bench.front_half(vit, agent, tok, inp, a.text_tokens, dev)
             if ctx.world < 2 or ctx.rank < 2:
                 bench.back_half(adapter, feats, a.unet_steps, seed)
         for i in range(a.warmup):

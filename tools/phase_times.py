@@ -1,4 +1,6 @@
-"""Wall time of each phase of one bench generation (synchronised between phases; run on the GPU box)."""
+"""Wall time of each phase of one config-0 bench step at a given batch (synchronised between phases; GPU box).
+    python tools/phase_times.py [--batch 16] [--unet-steps 50]"""
+import argparse
 import os
 import sys
 import time
@@ -11,18 +13,17 @@ import bench
 
 
 def main():
-    dev = torch.device("cuda:0")
-    dtype = torch.bfloat16
-    tok = bench.BenchTokenizer()
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--unet-steps", type=int, default=50)
+    a = ap.parse_args()
+    bench.BATCH = a.batch
+    dev, dtype, tok = torch.device("cuda:0"), torch.bfloat16, bench.BenchTokenizer()
     with torch.no_grad():
         vit, agent, adapter = bench.build_models(dev, dtype)
         inp = bench.make_inputs(dev)
-        for _ in range(2):
-            bench.one_generation(vit, agent, adapter, tok, inp, 50, 61, seed=1)
-        torch.cuda.synchronize()
-        image, patch_pos, ids, mask = inp
 
-        def timed(fn, n=3):
+        def timed(fn, n=2):
             ts = []
             for _ in range(n):
                 torch.cuda.synchronize()
@@ -31,26 +32,29 @@ def main():
                 torch.cuda.synchronize()
                 ts.append(time.perf_counter() - t0)
             return min(ts), r
-        t_vit, emb = timed(lambda: vit(image))
-        kw = dict(input_ids=[ids], image_embeds=emb, embeds_cmp_mask=torch.tensor([True, True]), ids_cmp_mask=mask,
-                  patch_positions=patch_pos, eos_token_id=None)
-        t_pre, _ = timed(lambda: agent.generate(tok, max_new_tokens=1, **kw))
-        t_62, _ = timed(lambda: agent.generate(tok, max_new_tokens=62, **kw))
-        t_full, out = timed(lambda: agent.generate(tok, max_new_tokens=128, force_image_at=61, **kw))
-        agent.chunk_forced_image_tokens = False
-        t_nochunk, _ = timed(lambda: agent.generate(tok, max_new_tokens=128, force_image_at=61, **kw), n=1)
-        agent.chunk_forced_image_tokens = True
-        feats = out["img_gen_feat"]
+        feats = bench.front_half(vit, agent, tok, inp, 61, dev)                   # warm-up incl. graph capture
+        bench.back_half(adapter, feats, 2, 1)
+        t_pre, _ = timed(lambda: bench.preprocess(inp[0], dev))
+        t_a, reqs = timed(lambda: bench.requests_for(vit, inp, dev))
+        t_p1, _ = timed(lambda: agent.generate_batch(tok, reqs, max_new_tokens=1, eos_token_id=None))
+        t_62, _ = timed(lambda: agent.generate_batch(tok, reqs, max_new_tokens=62, eos_token_id=None))
+        t_full, outs = timed(lambda: agent.generate_batch(tok, reqs, max_new_tokens=128, eos_token_id=None, force_image_at=61))
+        feats = torch.cat([o["img_gen_feat"] for o in outs], dim=0)
         t_emb, _ = timed(lambda: adapter.get_image_embeds(image_embeds=feats, image_size=448))
-        t_unet, _ = timed(lambda: adapter.generate(image_embeds=feats, num_inference_steps=50, seed=3), n=2)
-        print("ViT (2 crops)                       %8.1f ms" % (t_vit * 1e3))
-        print("LLM input resampler + prefill(165)  %8.1f ms" % (t_pre * 1e3))
-        print("LLM 61 decoded tokens               %8.1f ms  (%.2f ms/token)" % ((t_62 - t_pre) * 1e3, (t_62 - t_pre) / 61 * 1e3))
-        print("LLM image block (65-token chunk) + 2 tokens + output resampler %8.1f ms" % ((t_full - t_62) * 1e3))
-        print("   same without chunking (66 single-token steps)             %8.1f ms" % ((t_nochunk - t_62) * 1e3))
-        print("adapter.get_image_embeds (XLV2, cached negative)             %8.1f ms" % (t_emb * 1e3))
-        print("adapter.generate 50 UNet steps      %8.1f ms  (%.2f ms/step)" % (t_unet * 1e3, (t_unet - t_emb) / 50 * 1e3))
-        print("sum                                 %8.1f ms" % ((t_vit + t_full + t_unet) * 1e3))
+        t_lat, lat = timed(lambda: adapter.generate(image_embeds=feats, num_inference_steps=a.unet_steps, seed=3,
+                                                    output_type="latent"))
+        t_img, _ = timed(lambda: adapter._finish(lat, "u8"))
+        G = a.batch
+        print("batch %d per step" % G)
+        print("GPU preprocessing (any-res, normalise)              %9.1f ms" % (t_pre * 1e3))
+        print("preprocessing + ViT (%d crops) + marker mask         %9.1f ms" % (2 * G, t_a * 1e3))
+        print("input resampler + batched prefill (M=%d) + 1 token %9.1f ms" % (165 * G, t_p1 * 1e3))
+        print("61 decoded tokens                                    %9.1f ms  (%.2f ms/token)" % ((t_62 - t_p1) * 1e3, (t_62 - t_p1) / 61 * 1e3))
+        print("image block (65-token chunk x%d) + 2 tokens + out-resampler %9.1f ms" % (G, (t_full - t_62) * 1e3))
+        print("adapter.get_image_embeds (XLV2, cached negative)     %9.1f ms" % (t_emb * 1e3))
+        print("%d UNet CFG steps (batch %d)                          %9.1f ms  (%.2f ms/step)" % (a.unet_steps, 2 * G, (t_lat - t_emb) * 1e3, (t_lat - t_emb) / a.unet_steps * 1e3))
+        print("VAE decode + uint8 (%d images)                       %9.1f ms" % (G, t_img * 1e3))
+        print("sum                                                  %9.1f ms" % ((t_a + t_full + t_lat + t_img) * 1e3))
 
 
 if __name__ == "__main__":
