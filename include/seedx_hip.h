@@ -124,6 +124,11 @@ int sx_softmax_rows(const float* x, int64_t ldx, void* y, int64_t ldy, int rows,
  * raw16: optional 16-bit un-normalised copy of x (feeds the 1x1 shortcut conv), may be NULL. */
 int sx_groupnorm(const float* x, void* y, void* raw16, int out_dtype, const float* gamma, const float* beta,
                  double* stats, int B, int HW, int C, int groups, float eps, int silu, void* stream);
+/* same with the input given as the channel concatenation [x | x2] of two NHWC tensors (x: [B][HW][C1], x2: [B][HW][C-C1]):
+ * GroupNorm over torch.cat([hidden_states, res_hidden_states], dim=1) of the UNet up blocks (diffusers
+ * CrossAttnUpBlock2D / UpBlock2D [ext]) without materialising the concatenation. x2 == NULL: plain sx_groupnorm. */
+int sx_groupnorm2(const float* x, const float* x2, int C1, void* y, void* raw16, int out_dtype, const float* gamma,
+                  const float* beta, double* stats, int B, int HW, int C, int groups, float eps, int silu, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Attention

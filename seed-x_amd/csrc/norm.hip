@@ -131,8 +131,11 @@ constexpr int GN_MAX_SLOTS4 = 3;  // C/4 quads per row / 256 threads
 
 // blockDim.x = T (320 / 160 / 256, chosen so the C/2 channel pairs tile the block evenly); each thread owns fixed
 // channel pairs and walks the block's rows four at a time (4 independent 8-B loads in flight per slot).
-__global__ __launch_bounds__(320) void gn_stats_kernel(const float* x, double* stats, int HW, int C, int groups,
-                                                       int rows_per_block) {
+// TWO: the logical [HW][C] input is the channel concatenation of x[HW][C1] and x2[HW][C - C1] (UNet up blocks:
+// torch.cat([hidden, skip], dim=1) — never materialised)
+template <bool TWO>
+__global__ __launch_bounds__(320) void gn_stats_kernel(const float* x, const float* x2, int C1, double* stats, int HW, int C,
+                                                       int groups, int rows_per_block) {
   __shared__ float acc[2 * 64];  // [groups][2], groups <= 64
   const int T = blockDim.x;
   const int b = blockIdx.y;
@@ -144,15 +147,27 @@ __global__ __launch_bounds__(320) void gn_stats_kernel(const float* x, double* s
   float s[GN_MAX_SLOTS2], q[GN_MAX_SLOTS2];
 #pragma unroll
   for (int k = 0; k < GN_MAX_SLOTS2; ++k) { s[k] = 0.f; q[k] = 0.f; }
-  const float2* xb = (const float2*)(x + (size_t)b * HW * C);
+  const float2* xb = (const float2*)(x + (size_t)b * HW * (TWO ? C1 : C));
+  const float2* xb2 = TWO ? (const float2*)(x2 + (size_t)b * HW * (C - C1)) : nullptr;
+  const int np1 = TWO ? (C1 >> 1) : np, np2 = np - np1;
+  // per-slot source: base pointer of the thread's channel pair in row 0 and the row stride (float2 units)
+  const float2* src[GN_MAX_SLOTS2];
+  int ld[GN_MAX_SLOTS2];
+#pragma unroll
+  for (int k = 0; k < GN_MAX_SLOTS2; ++k) {
+    const int pidx = threadIdx.x + k * T;
+    const bool second = TWO && pidx >= np1;
+    src[k] = second ? xb2 + (pidx - np1) : xb + pidx;
+    ld[k] = second ? np2 : np1;
+  }
   int r = r0;
   for (; r + 3 < r1; r += 4) {
 #pragma unroll
     for (int k = 0; k < GN_MAX_SLOTS2; ++k) {
       const int pidx = threadIdx.x + k * T;
       if (pidx < np) {
-        const float2 v0 = xb[(size_t)r * np + pidx], v1 = xb[(size_t)(r + 1) * np + pidx];
-        const float2 v2 = xb[(size_t)(r + 2) * np + pidx], v3 = xb[(size_t)(r + 3) * np + pidx];
+        const float2 v0 = src[k][(size_t)r * ld[k]], v1 = src[k][(size_t)(r + 1) * ld[k]];
+        const float2 v2 = src[k][(size_t)(r + 2) * ld[k]], v3 = src[k][(size_t)(r + 3) * ld[k]];
         s[k] += ((v0.x + v0.y) + (v1.x + v1.y)) + ((v2.x + v2.y) + (v3.x + v3.y));
         q[k] += ((v0.x * v0.x + v0.y * v0.y) + (v1.x * v1.x + v1.y * v1.y)) +
                 ((v2.x * v2.x + v2.y * v2.y) + (v3.x * v3.x + v3.y * v3.y));
@@ -164,7 +179,7 @@ __global__ __launch_bounds__(320) void gn_stats_kernel(const float* x, double* s
     for (int k = 0; k < GN_MAX_SLOTS2; ++k) {
       const int pidx = threadIdx.x + k * T;
       if (pidx < np) {
-        const float2 v = xb[(size_t)r * np + pidx];
+        const float2 v = src[k][(size_t)r * ld[k]];
         s[k] += v.x + v.y;
         q[k] += v.x * v.x + v.y * v.y;
       }
@@ -188,7 +203,8 @@ __global__ __launch_bounds__(320) void gn_stats_kernel(const float* x, double* s
 // contiguous in memory), 4 loads in flight per thread — every one of the 256 threads is busy whatever C is (C = 320 / 640
 // left 31-62 % of the lanes idle when threads were tied to channel quads).
 constexpr int GN_MAX_C = 3072;
-__global__ __launch_bounds__(256) void gn_apply_kernel(const float* x, void* y, void* raw16, int out_dt,
+template <bool TWO>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float* x, const float* x2, int C1, void* y, void* raw16, int out_dt,
                                                        const float* gamma, const float* beta, const double* stats,
                                                        int HW, int C, int groups, float eps, int silu,
                                                        int rows_per_block) {
@@ -212,7 +228,15 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* x, void* y, 
   __syncthreads();
   const size_t base4 = ((size_t)b * HW + r0) * n4;          // first float4 of this block's rows
   const int total = (r1 - r0) * n4;
-  const f32x4_t* x4 = (const f32x4_t*)x + base4;
+  const f32x4_t* x4 = (const f32x4_t*)x + (TWO ? 0 : base4);
+  const f32x4_t* x4b = (const f32x4_t*)x2;
+  const int n4a = C1 >> 2, n4b = n4 - n4a;
+  const size_t row_base = (size_t)b * HW + r0;
+  // TWO: quad (row, q) of the logical concatenation lives in x (q < n4a) or x2; (row, q) are tracked incrementally
+  auto fetch = [&](int i, int row, int q) -> f32x4_t {
+    if (!TWO) return x4[i];
+    return q < n4a ? x4[(row_base + row) * n4a + q] : x4b[(row_base + row) * n4b + (q - n4a)];
+  };
   auto one = [&](int i, int qi, const f32x4_t v) {
     f32x4_t o = v * *(const f32x4_t*)(s_sc + 4 * qi) + *(const f32x4_t*)(s_sh + 4 * qi);
     if (silu) {
@@ -222,23 +246,24 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* x, void* y, 
     store4(y, out_dt, base4 + i, o);
     if (raw16) store4(raw16, out_dt, base4 + i, v);
   };
-  const int step = 256 % n4;                                // channel-quad index advances by 256 mod n4 per stride
-  int qi = threadIdx.x % n4;
+  const int step = 256 % n4, dstep = 256 / n4;              // (row, quad) advance by (256 / n4, 256 mod n4) per stride
+  int qi = threadIdx.x % n4, ri = threadIdx.x / n4;
   int i = threadIdx.x;
+  auto adv = [&](int& r_, int& q_) { q_ += step; r_ += dstep; if (q_ >= n4) { q_ -= n4; ++r_; } };
   for (; i + 768 < total; i += 1024) {
-    int q1 = qi + step; q1 -= (q1 >= n4) ? n4 : 0;
-    int q2 = q1 + step; q2 -= (q2 >= n4) ? n4 : 0;
-    int q3 = q2 + step; q3 -= (q3 >= n4) ? n4 : 0;
-    const f32x4_t v0 = x4[i], v1 = x4[i + 256], v2 = x4[i + 512], v3 = x4[i + 768];
+    int q1 = qi, r1_ = ri; adv(r1_, q1);
+    int q2 = q1, r2_ = r1_; adv(r2_, q2);
+    int q3 = q2, r3_ = r2_; adv(r3_, q3);
+    const f32x4_t v0 = fetch(i, ri, qi), v1 = fetch(i + 256, r1_, q1), v2 = fetch(i + 512, r2_, q2), v3 = fetch(i + 768, r3_, q3);
     one(i, qi, v0);
     one(i + 256, q1, v1);
     one(i + 512, q2, v2);
     one(i + 768, q3, v3);
-    qi = q3 + step; qi -= (qi >= n4) ? n4 : 0;
+    qi = q3; ri = r3_; adv(ri, qi);
   }
   for (; i < total; i += 256) {
-    one(i, qi, x4[i]);
-    qi += step; qi -= (qi >= n4) ? n4 : 0;
+    one(i, qi, fetch(i, ri, qi));
+    adv(ri, qi);
   }
 }
 
@@ -326,10 +351,11 @@ extern "C" int sx_layernorm(const void* x, int in_dtype, void* y, int out_dtype,
   return SX_OK;
 }
 
-extern "C" int sx_groupnorm(const float* x, void* y, void* raw16, int out_dtype, const float* gamma,
-                            const float* beta, double* stats, int B, int HW, int C, int groups, float eps, int silu,
-                            void* stream) {
+extern "C" int sx_groupnorm2(const float* x, const float* x2, int C1, void* y, void* raw16, int out_dtype, const float* gamma,
+                             const float* beta, double* stats, int B, int HW, int C, int groups, float eps, int silu,
+                             void* stream) {
   SX_CHECK(x && y && gamma && beta && stats, "sx_groupnorm: null pointer");
+  SX_CHECK(!x2 || (C1 > 0 && C1 < C && C1 % 4 == 0 && (C - C1) % 4 == 0), "sx_groupnorm2: C1=%d of C=%d", C1, C);
   SX_CHECK(out_dtype == SX_F16 || out_dtype == SX_BF16, "sx_groupnorm: output must be 16-bit");
   SX_CHECK(groups > 0 && groups <= 64 && C % groups == 0, "sx_groupnorm: C=%d groups=%d", C, groups);
   SX_CHECK(C % 4 == 0 && (C / groups) % 2 == 0, "sx_groupnorm: C %% 4 and (C/groups) %% 2 must be 0 (C=%d)", C);
@@ -351,12 +377,25 @@ extern "C" int sx_groupnorm(const float* x, void* y, void* raw16, int out_dtype,
   int rows_stats = (HW * B + 511) / 512;
   if (rows_stats < 8) rows_stats = 8;
   const dim3 grid_s((HW + rows_stats - 1) / rows_stats, B);
-  hipLaunchKernelGGL(gn_stats_kernel, grid_s, dim3(T), 0, st, x, stats, HW, C, groups, rows_stats);
-  SX_HIP_LAUNCH_CHECK();
-  hipLaunchKernelGGL(gn_apply_kernel, grid, block, 0, st, x, y, raw16, out_dtype, gamma, beta, stats, HW, C, groups,
-                     eps, silu, rows_per_block);
+  if (x2) {
+    hipLaunchKernelGGL(gn_stats_kernel<true>, grid_s, dim3(T), 0, st, x, x2, C1, stats, HW, C, groups, rows_stats);
+    SX_HIP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gn_apply_kernel<true>, grid, block, 0, st, x, x2, C1, y, raw16, out_dtype, gamma, beta, stats, HW, C,
+                       groups, eps, silu, rows_per_block);
+  } else {
+    hipLaunchKernelGGL(gn_stats_kernel<false>, grid_s, dim3(T), 0, st, x, x2, C, stats, HW, C, groups, rows_stats);
+    SX_HIP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gn_apply_kernel<false>, grid, block, 0, st, x, x2, C, y, raw16, out_dtype, gamma, beta, stats, HW, C,
+                       groups, eps, silu, rows_per_block);
+  }
   SX_HIP_LAUNCH_CHECK();
   return SX_OK;
+}
+
+extern "C" int sx_groupnorm(const float* x, void* y, void* raw16, int out_dtype, const float* gamma,
+                            const float* beta, double* stats, int B, int HW, int C, int groups, float eps, int silu,
+                            void* stream) {
+  return sx_groupnorm2(x, nullptr, 0, y, raw16, out_dtype, gamma, beta, stats, B, HW, C, groups, eps, silu, stream);
 }
 
 extern "C" int sx_softmax_rows(const float* x, int64_t ldx, void* y, int64_t ldy, int rows, int cols, float scale,

@@ -357,6 +357,8 @@ class SDXLAdapter:
                   device='cuda'):
         self.device, self.dtype = torch.device(device), dtype
         self.vae, self.scheduler = vae, scheduler
+        if vae is not None and getattr(vae, "device", self.device) is None and hasattr(vae, "to"):
+            vae.to(self.device, self.dtype)          # the edit pipeline moves its modules itself (adapter_modules.py:243)
         self.visual_encoder = visual_encoder.to(self.device, dtype=self.dtype)
         self.discrete_model = discrete_model
         self.image_transform = image_transform

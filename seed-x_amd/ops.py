@@ -176,16 +176,21 @@ def rmsnorm(x, gamma, eps, out_dtype):
     return layernorm(x, gamma, None, eps, out_dtype, rms=True)
 
 
-def groupnorm(x, gamma, beta, groups, eps, silu, out_dtype, want_raw=False):
-    """x: fp32 [B, HW, C] (NHWC). Returns y (16-bit) and optionally a 16-bit raw copy of x."""
+def groupnorm(x, gamma, beta, groups, eps, silu, out_dtype, want_raw=False, x2=None):
+    """x: fp32 [B, HW, C] (NHWC). Returns y (16-bit) and optionally a 16-bit raw copy of x.
+    x2: optional second fp32 [B, HW, C2] tensor — the op then runs over the channel concatenation [x | x2] (never built)."""
     lib = _lib.load()
     assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 3
-    B, HW, Cc = x.shape
-    y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
-    raw = torch.empty(x.shape, dtype=out_dtype, device=x.device) if want_raw else None
+    B, HW, C1 = x.shape
+    Cc = C1
+    if x2 is not None:
+        assert x2.dtype == torch.float32 and x2.is_contiguous() and x2.shape[:2] == (B, HW)
+        Cc = C1 + x2.shape[2]
+    y = torch.empty((B, HW, Cc), dtype=out_dtype, device=x.device)
+    raw = torch.empty((B, HW, Cc), dtype=out_dtype, device=x.device) if want_raw else None
     stats = torch.empty((B, groups, 2), dtype=torch.float64, device=x.device)
-    check(lib.sx_groupnorm(_p(x), _p(y), _p(raw), _DT[out_dtype], _p(_f32c(gamma)), _p(_f32c(beta)), _p(stats), B, HW,
-                           Cc, groups, float(eps), 1 if silu else 0, _stream()), "sx_groupnorm")
+    check(lib.sx_groupnorm2(_p(x), _p(x2), C1, _p(y), _p(raw), _DT[out_dtype], _p(_f32c(gamma)), _p(_f32c(beta)), _p(stats), B,
+                            HW, Cc, groups, float(eps), 1 if silu else 0, _stream()), "sx_groupnorm")
     return (y, raw) if want_raw else y
 
 

@@ -240,13 +240,16 @@ class UNet2DConditionModel:
         return P
 
     # ---- building blocks ---------------------------------------------------------------------------------------------
-    def _resnet(self, r, x, B, Hc, Wc, temb_all):
-        """x: fp32 [B, HW, Ci] → fp32 [B, HW, Co]  (diffusers ResnetBlock2D [ext])."""
+    def _resnet(self, r, x, B, Hc, Wc, temb_all, skip=None):
+        """x: fp32 [B, HW, Ci] → fp32 [B, HW, Co]  (diffusers ResnetBlock2D [ext]).
+        skip: fp32 [B, HW, Cs] — the block input is torch.cat([x, skip], dim=1) (up blocks); the concatenation is never
+        built: norm1 reads both tensors and emits the 16-bit operands of conv1 and of the 1x1 shortcut."""
         G, dt = self.cfg["norm_groups"], self.dtype
-        Ci = x.shape[-1]
+        Ci = x.shape[-1] + (skip.shape[-1] if skip is not None else 0)
         if "ws" in r:
-            h, raw = ops.groupnorm(x, r["n1"][0], r["n1"][1], G, 1e-5, True, dt, want_raw=True)
+            h, raw = ops.groupnorm(x, r["n1"][0], r["n1"][1], G, 1e-5, True, dt, want_raw=True, x2=skip)
         else:
+            assert skip is None
             h = ops.groupnorm(x, r["n1"][0], r["n1"][1], G, 1e-5, True, dt)
         off, Co = self._P["temb_off"][r["name"]]
         h = ops.conv3x3(h.view(B, Hc, Wc, Ci), r["w1"], bias=r["b1"], bias2d=temb_all[:, off:off + Co],
@@ -353,11 +356,7 @@ class UNet2DConditionModel:
         for blk in P["up"]:
             for j, r in enumerate(blk["res"]):
                 s, _, _ = skips.pop()
-                C1, C2 = x.shape[-1], s.shape[-1]
-                cat = torch.empty((B * Hc * Wc, C1 + C2), dtype=torch.float32, device=self.device)
-                ops.copy2d(x.view(-1, C1), cat, 0)                                  # torch.cat([x, skip], dim=1)
-                ops.copy2d(s.view(-1, C2), cat, C1)
-                x = self._resnet(r, cat.view(B, Hc * Wc, C1 + C2), B, Hc, Wc, temb_all)
+                x = self._resnet(r, x.contiguous(), B, Hc, Wc, temb_all, skip=s)   # torch.cat([x, skip], dim=1), fused
                 if blk["attn"]:
                     x = self._transformer(blk["attn"][j], x, B, ctx[ti])
                     ti += 1

@@ -197,6 +197,24 @@ def test_groupnorm(dev, B, HW, C, silu):
     assert relerr(raw, x) < TOL[torch.float16]
 
 
+@pytest.mark.parametrize("B,HW,C1,C2", [(2, 1024, 1280, 1280), (2, 4096, 640, 320), (3, 256, 1280, 640), (1, 4096, 320, 320)])
+def test_groupnorm_two_sources_equals_concat(dev, B, HW, C1, C2):
+    """sx_groupnorm2 over [x | skip] (UNet up blocks) == GroupNorm of the materialised concatenation, bit for bit the same
+    kernel arithmetic (only the addressing differs), and within tolerance of torch's group_norm."""
+    from seedx_amd import ops
+    x = rnd((B, HW, C1), torch.float32, dev, 1.5, seed=31) + 0.3
+    s2 = rnd((B, HW, C2), torch.float32, dev, 0.7, seed=32) - 0.2
+    C = C1 + C2
+    g, b = rnd((C,), torch.float32, dev, seed=33), rnd((C,), torch.float32, dev, seed=34)
+    cat = torch.cat([x, s2], dim=-1).contiguous()
+    y1, raw1 = ops.groupnorm(cat, g, b, 32, 1e-5, True, torch.bfloat16, want_raw=True)
+    y2, raw2 = ops.groupnorm(x, g, b, 32, 1e-5, True, torch.bfloat16, want_raw=True, x2=s2)
+    ref = F.silu(F.group_norm(cat.permute(0, 2, 1), 32, g, b, 1e-5).permute(0, 2, 1))
+    assert relerr(y2, ref) < TOL[torch.bfloat16]
+    assert torch.equal(raw1, raw2)
+    assert relerr(y2, y1) < 1e-3          # identical up to the order of the fp32 partial sums / fp64 atomics
+
+
 def _attn_ref(q, k, v, scale, causal):
     # q [B,Sq,H,D], k/v [B,Skv,H,D]
     qf, kf, vf = (t.float().permute(0, 2, 1, 3) for t in (q, k, v))
