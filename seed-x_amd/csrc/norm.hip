@@ -131,6 +131,11 @@ constexpr int GN_MAX_SLOTS4 = 3;  // C/4 quads per row / 256 threads
 
 // blockDim.x = T (320 / 160 / 256, chosen so the C/2 channel pairs tile the block evenly); each thread owns fixed
 // channel pairs and walks the block's rows four at a time (4 independent 8-B loads in flight per slot).
+__global__ void gn_zero_kernel(double* p, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 0.0;
+}
+
 // TWO: the logical [HW][C] input is the channel concatenation of x[HW][C1] and x2[HW][C - C1] (UNet up blocks:
 // torch.cat([hidden, skip], dim=1) — never materialised)
 template <bool TWO>
@@ -361,10 +366,10 @@ extern "C" int sx_groupnorm2(const float* x, const float* x2, int C1, void* y, v
   SX_CHECK(C % 4 == 0 && (C / groups) % 2 == 0, "sx_groupnorm: C %% 4 and (C/groups) %% 2 must be 0 (C=%d)", C);
   SX_CHECK(C / 2 <= 256 * GN_MAX_SLOTS2 && C <= GN_MAX_C, "sx_groupnorm: C=%d too large", C);
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(stats, 0, sizeof(double) * 2 * B * groups, st) != hipSuccess) {
-    sx_set_error("sx_groupnorm: hipMemsetAsync failed");
-    return SX_ERR_HIP;
-  }
+  // zero the fp64 accumulators with a KERNEL node, not hipMemsetAsync: under hipGraph replay a memset node was observed to
+  // race with the neighbouring kernel nodes (NaN statistics whenever the replay started on an idle GPU)
+  hipLaunchKernelGGL(gn_zero_kernel, dim3((2 * B * groups + 255) / 256), dim3(256), 0, st, stats, 2 * B * groups);
+  SX_HIP_LAUNCH_CHECK();
   // ~2048 blocks over the chip
   int rows_per_block = (HW * B + 2047) / 2048;
   if (rows_per_block < 4) rows_per_block = 4;

@@ -109,3 +109,33 @@ def test_config4_edit_with_latent_image(dev):
     out0 = ad.generate(image_embeds=feats.to(dev), latents=noise.clone(), num_inference_steps=2, height=128, width=128,
                        input_image_size=112)
     assert relerr(out0, ref0) < 5e-3
+
+
+def test_graph_replay_is_robust_to_idle_gaps_and_allocator_resets(dev):
+    """Regression: GroupNorm used to zero its fp64 accumulators with hipMemsetAsync; as a memset NODE of the captured
+    denoise step it raced with the neighbouring kernel nodes whenever a replay started on an idle GPU (host sync between
+    replays, or the first call after torch.cuda.empty_cache()) → NaN latents. The accumulators are now zeroed by a kernel.
+    Graph replays with host syncs in between, across allocator resets, must equal the eager loop bit for bit."""
+    from seedx_amd.detokenizer import SDXLAdapter
+    ad, _ = _build(dev, torch.float16, 4, SDXLAdapter)
+    g = torch.Generator().manual_seed(2)
+    feats = torch.randn(1, 16, 256, generator=g).to(dev)
+    noise = torch.randn(1, 4, 16, 16, generator=g)
+    kw = dict(image_embeds=feats, num_inference_steps=4, height=128, width=128, input_image_size=112, output_type="latent")
+    ad._loop.use_graph = False
+    ref = ad.generate(latents=noise.clone(), **kw)
+    ad._loop.use_graph = True
+    first = ad.generate(latents=noise.clone(), **kw)                 # capture + replay
+    assert torch.equal(first, ref)
+    real = ad._loop._graph
+
+    class SyncEach:
+        def replay(self):
+            real.replay()
+            torch.cuda.synchronize()
+    for trial in range(4):
+        if trial % 2 == 0:
+            torch.cuda.empty_cache()
+        ad._loop._graph = SyncEach() if trial >= 2 else real
+        out = ad.generate(latents=noise.clone(), **kw)
+        assert not torch.isnan(out).any() and torch.equal(out, ref), trial
