@@ -188,11 +188,12 @@ class _DenoiseLoop:
         self._ctx_static = None
 
     def run(self, mode, latents_nchw, prompt_embeds, pooled, time_ids, scheduler, num_steps, guidance_scale,
-            image_guidance_scale=1.5, image_latents_nchw=None):
+            image_guidance_scale=1.5, image_latents_nchw=None, trace=None):
         """mode 0 (t2i): prompt_embeds ordered [uncond, text]; mode 1 (edit): [text, image, uncond].
         latents_nchw: [G,4,H,W] already multiplied by init_noise_sigma, G >= 1 independent generations denoised as one
         UNet batch of nb·G samples ordered [branch][generation] (prompt_embeds / pooled / time_ids / image latents all
-        follow that order). Returns fp32 [G,4,H,W]."""
+        follow that order). Returns fp32 [G,4,H,W]. ``trace``: optional dict {step index (1-based): None}; filled with a
+        copy of the latents after that many steps (drift measurements; the pipeline's `callback` equivalent)."""
         unet = self.unet
         unet._pack()
         dev = unet.device
@@ -253,9 +254,14 @@ class _DenoiseLoop:
                                image_guidance_scale, mode)
             ops.add_i32(S["step"], 1)
 
+        def snap_trace(done):
+            if trace is not None and done in trace:
+                trace[done] = ops.nhwc_to_nchw(S["lat"], Cl, H, W).clone()
+
         if not self.use_graph or not comm.graph_safe:
-            for _ in range(num_steps):
+            for i in range(num_steps):
                 step_body()
+                snap_trace(i + 1)
         else:
             if self._graph is None:
                 snap = {k: S[k].clone() for k in ("lat", "scaled", "step")}
@@ -271,8 +277,9 @@ class _DenoiseLoop:
                 for k, v in snap.items():
                     S[k].copy_(v)
                 self._graph = g
-            for _ in range(num_steps):
+            for i in range(num_steps):
                 self._graph.replay()
+                snap_trace(i + 1)
         return ops.nhwc_to_nchw(S["lat"], Cl, H, W)
 
 

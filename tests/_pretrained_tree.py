@@ -20,17 +20,22 @@ class StubTokenizer:
     bos_token_id, eos_token_id, pad_token_id = 1, 2, 0
 
     def encode(self, s, add_special_tokens=False):
-        if s == "<img>":
-            return [IMG_IDS[0]]
-        if s == "</img>":
-            return [IMG_IDS[-1]]
-        if s == "<patch>":
-            return [398]
-        if s == "</patch>":
-            return [399]
-        if s.startswith("<img") and "<img_" in s and s.count("<") > 1:      # the marker string of generation.py:15-17
-            return IMG_IDS
-        return [3 + (ord(c) % 300) for c in s][:24]
+        import re
+        out = []
+        for tok in re.findall(r"<img_\d{5}>|<img>|</img>|<patch>|</patch>|[^<]+|<", s):
+            if tok == "<img>":
+                out.append(IMG_IDS[0])
+            elif tok == "</img>":
+                out.append(IMG_IDS[-1])
+            elif tok == "<patch>":
+                out.append(398)
+            elif tok == "</patch>":
+                out.append(399)
+            elif tok.startswith("<img_"):
+                out.append(IMG_IDS[1] + int(tok[5:10]))
+            else:
+                out.extend(3 + (ord(c) % 300) for c in tok[:24])
+        return out
 
     def batch_decode(self, ids, skip_special_tokens=False):
         return [" ".join(str(int(i)) for i in row) for row in ids]
