@@ -212,13 +212,13 @@ template <bool TWO>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const float* x, const float* x2, int C1, void* y, void* raw16, int out_dt,
                                                        const float* gamma, const float* beta, const double* stats,
                                                        int HW, int C, int groups, float eps, int silu,
-                                                       int rows_per_block) {
+                                                       int rows_per_block, int hw_total) {
   __shared__ __attribute__((aligned(16))) float s_sc[GN_MAX_C], s_sh[GN_MAX_C];
   const int b = blockIdx.y;
   const int r0 = blockIdx.x * rows_per_block;
   const int r1 = min(HW, r0 + rows_per_block);
   const int n4 = C >> 2, cpg = C / groups;
-  const double cnt = (double)HW * cpg;
+  const double cnt = (double)hw_total * cpg;                // hw_total > HW: the statistics cover rows held by other ranks too
   for (int c = threadIdx.x; c < C; c += 256) {
     const int g = c / cpg;
     const double su = stats[((size_t)b * groups + g) * 2], sq = stats[((size_t)b * groups + g) * 2 + 1];
@@ -356,20 +356,20 @@ extern "C" int sx_layernorm(const void* x, int in_dtype, void* y, int out_dtype,
   return SX_OK;
 }
 
-extern "C" int sx_groupnorm2(const float* x, const float* x2, int C1, void* y, void* raw16, int out_dtype, const float* gamma,
-                             const float* beta, double* stats, int B, int HW, int C, int groups, float eps, int silu,
-                             void* stream) {
-  SX_CHECK(x && y && gamma && beta && stats, "sx_groupnorm: null pointer");
+// phase 0: statistics + apply; 1: zero + statistics of the local rows only (caller all-reduces `stats` across ranks);
+// 2: apply only, `stats` holding the sums over hw_total rows per sample.
+static int groupnorm_impl(const float* x, const float* x2, int C1, void* y, void* raw16, int out_dtype, const float* gamma,
+                          const float* beta, double* stats, int B, int HW, int hw_total, int C, int groups, float eps,
+                          int silu, int phase, void* stream) {
+  SX_CHECK(x && stats, "sx_groupnorm: null pointer");
+  SX_CHECK(phase == 1 || (y && gamma && beta), "sx_groupnorm: null pointer");
   SX_CHECK(!x2 || (C1 > 0 && C1 < C && C1 % 4 == 0 && (C - C1) % 4 == 0), "sx_groupnorm2: C1=%d of C=%d", C1, C);
-  SX_CHECK(out_dtype == SX_F16 || out_dtype == SX_BF16, "sx_groupnorm: output must be 16-bit");
+  SX_CHECK(phase == 1 || out_dtype == SX_F16 || out_dtype == SX_BF16, "sx_groupnorm: output must be 16-bit");
   SX_CHECK(groups > 0 && groups <= 64 && C % groups == 0, "sx_groupnorm: C=%d groups=%d", C, groups);
   SX_CHECK(C % 4 == 0 && (C / groups) % 2 == 0, "sx_groupnorm: C %% 4 and (C/groups) %% 2 must be 0 (C=%d)", C);
   SX_CHECK(C / 2 <= 256 * GN_MAX_SLOTS2 && C <= GN_MAX_C, "sx_groupnorm: C=%d too large", C);
+  SX_CHECK(hw_total >= HW && HW > 0, "sx_groupnorm: hw_total=%d < HW=%d", hw_total, HW);
   hipStream_t st = (hipStream_t)stream;
-  // zero the fp64 accumulators with a KERNEL node, not hipMemsetAsync: under hipGraph replay a memset node was observed to
-  // race with the neighbouring kernel nodes (NaN statistics whenever the replay started on an idle GPU)
-  hipLaunchKernelGGL(gn_zero_kernel, dim3((2 * B * groups + 255) / 256), dim3(256), 0, st, stats, 2 * B * groups);
-  SX_HIP_LAUNCH_CHECK();
   // ~2048 blocks over the chip
   int rows_per_block = (HW * B + 2047) / 2048;
   if (rows_per_block < 4) rows_per_block = 4;
@@ -377,24 +377,45 @@ extern "C" int sx_groupnorm2(const float* x, const float* x2, int C1, void* y, v
   const int np = C / 2;
   const int T = (np % 320 == 0) ? 320 : ((np % 160 == 0) ? 160 : 256);
   SX_CHECK((np + T - 1) / T <= GN_MAX_SLOTS2, "sx_groupnorm: C=%d too large", C);
-  // stats: ~512 blocks in total — every block ends with 2*groups fp64 atomics on the same B*groups*2 words, so the
-  // block count (not the byte count) bounds this kernel once the atomics serialise in L2
-  int rows_stats = (HW * B + 511) / 512;
-  if (rows_stats < 8) rows_stats = 8;
-  const dim3 grid_s((HW + rows_stats - 1) / rows_stats, B);
-  if (x2) {
-    hipLaunchKernelGGL(gn_stats_kernel<true>, grid_s, dim3(T), 0, st, x, x2, C1, stats, HW, C, groups, rows_stats);
+  if (phase != 2) {
+    // zero the fp64 accumulators with a KERNEL node, not hipMemsetAsync: under hipGraph replay a memset node was observed
+    // to race with the neighbouring kernel nodes (NaN statistics whenever the replay started on an idle GPU)
+    hipLaunchKernelGGL(gn_zero_kernel, dim3((2 * B * groups + 255) / 256), dim3(256), 0, st, stats, 2 * B * groups);
     SX_HIP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(gn_apply_kernel<true>, grid, block, 0, st, x, x2, C1, y, raw16, out_dtype, gamma, beta, stats, HW, C,
-                       groups, eps, silu, rows_per_block);
-  } else {
-    hipLaunchKernelGGL(gn_stats_kernel<false>, grid_s, dim3(T), 0, st, x, x2, C, stats, HW, C, groups, rows_stats);
+    // stats: ~512 blocks in total — every block ends with 2*groups fp64 atomics on the same B*groups*2 words, so the
+    // block count (not the byte count) bounds this kernel once the atomics serialise in L2
+    int rows_stats = (HW * B + 511) / 512;
+    if (rows_stats < 8) rows_stats = 8;
+    const dim3 grid_s((HW + rows_stats - 1) / rows_stats, B);
+    if (x2)
+      hipLaunchKernelGGL(gn_stats_kernel<true>, grid_s, dim3(T), 0, st, x, x2, C1, stats, HW, C, groups, rows_stats);
+    else
+      hipLaunchKernelGGL(gn_stats_kernel<false>, grid_s, dim3(T), 0, st, x, x2, C, stats, HW, C, groups, rows_stats);
     SX_HIP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(gn_apply_kernel<false>, grid, block, 0, st, x, x2, C, y, raw16, out_dtype, gamma, beta, stats, HW, C,
-                       groups, eps, silu, rows_per_block);
   }
-  SX_HIP_LAUNCH_CHECK();
+  if (phase != 1) {
+    if (x2)
+      hipLaunchKernelGGL(gn_apply_kernel<true>, grid, block, 0, st, x, x2, C1, y, raw16, out_dtype, gamma, beta, stats, HW, C,
+                         groups, eps, silu, rows_per_block, hw_total);
+    else
+      hipLaunchKernelGGL(gn_apply_kernel<false>, grid, block, 0, st, x, x2, C, y, raw16, out_dtype, gamma, beta, stats, HW, C,
+                         groups, eps, silu, rows_per_block, hw_total);
+    SX_HIP_LAUNCH_CHECK();
+  }
   return SX_OK;
+}
+
+extern "C" int sx_groupnorm2(const float* x, const float* x2, int C1, void* y, void* raw16, int out_dtype, const float* gamma,
+                             const float* beta, double* stats, int B, int HW, int C, int groups, float eps, int silu,
+                             void* stream) {
+  return groupnorm_impl(x, x2, C1, y, raw16, out_dtype, gamma, beta, stats, B, HW, HW, C, groups, eps, silu, 0, stream);
+}
+
+extern "C" int sx_groupnorm_sp(const float* x, const float* x2, int C1, void* y, void* raw16, int out_dtype, const float* gamma,
+                               const float* beta, double* stats, int B, int HW, int hw_total, int C, int groups, float eps,
+                               int silu, int phase, void* stream) {
+  SX_CHECK(phase == 1 || phase == 2, "sx_groupnorm_sp: phase must be 1 (statistics) or 2 (apply)");
+  return groupnorm_impl(x, x2, C1, y, raw16, out_dtype, gamma, beta, stats, B, HW, hw_total, C, groups, eps, silu, phase, stream);
 }
 
 extern "C" int sx_groupnorm(const float* x, void* y, void* raw16, int out_dtype, const float* gamma,

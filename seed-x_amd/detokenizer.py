@@ -258,7 +258,7 @@ class _DenoiseLoop:
             if trace is not None and done in trace:
                 trace[done] = ops.nhwc_to_nchw(S["lat"], Cl, H, W).clone()
 
-        if not self.use_graph or not comm.graph_safe:
+        if not self.use_graph or not comm.graph_safe or not getattr(unet, "comm", comm).graph_safe:
             for i in range(num_steps):
                 step_body()
                 snap_trace(i + 1)

@@ -34,7 +34,12 @@ class UNetOutput:
 
 
 class UNet2DConditionModel:
-    def __init__(self, **cfg):
+    def __init__(self, comm=None, **cfg):
+        """comm (seedx_amd.parallel.Comm) with world > 1: ONE forward is sharded by pixel rows over the ranks of that
+        communicator (seqpar.py — weights replicated, K|V all-gather per self-attention, conv halos, GroupNorm statistics
+        all-reduce); every rank passes the same full inputs and receives the same full output."""
+        from .parallel import Comm
+        self.comm = comm or Comm()
         c = dict(SDXL_BASE_CONFIG)
         c.update(cfg)
         self.cfg = c
@@ -240,41 +245,87 @@ class UNet2DConditionModel:
         return P
 
     # ---- building blocks ---------------------------------------------------------------------------------------------
+    # ---- pixel-row sharding helpers (identity for a single rank) -----------------------------------------------------
+    def _gn(self, x, gb, eps, silu, Hc, Wc, want_raw=False, x2=None):
+        """GroupNorm of this rank's rows with statistics over the whole image (Hc x Wc global size)."""
+        G, dt = self.cfg["norm_groups"], self.dtype
+        return ops.groupnorm(x, gb[0], gb[1], G, eps, silu, dt, want_raw=want_raw, x2=x2, comm=self.comm, hw_total=Hc * Wc)
+
+    def _conv(self, h16, B, Hc, Wc, w, bias=None, bias2d=None, residual=None, stride=1, upsample=False, n_valid=0):
+        """3x3 conv on this rank's slab. h16: 16-bit [B, Hl*Wc, Cin] (Hl = Hc / tp rows). Returns fp32 [B, Hl'*Wc', Cout].
+        With tp > 1 the slab is extended by the neighbours' boundary rows (seqpar.with_halo) so that no output pixel sees a
+        wrong zero padding; rows computed from the artificial padding of the halo itself are dropped."""
+        tp = self.comm.world
+        Cin = h16.shape[-1]
+        if tp == 1:
+            return ops.conv3x3(h16.view(B, Hc, Wc, Cin), w, bias=bias, bias2d=bias2d, residual=residual, stride=stride,
+                               upsample=upsample, out_dtype=torch.float32, n_valid=n_valid)
+        from . import seqpar
+        Hl = Hc // tp
+        Co = n_valid or w.shape[0]
+        if stride == 2:
+            # output row y reads input rows 2y-1 .. 2y+1: only the row ABOVE the slab is foreign. The slab gets that row on
+            # top and a zero column on the left, and the kernel pads bottom/right only (pad_mode 1): tap (ky, kx) of output
+            # (j, x) then lands on padded index (2j + ky, 2x + kx) = image pixel (2y - 1 + ky, 2x - 1 + kx). No waste.
+            xin = seqpar.with_halo(h16, self.comm, Hl, Wc, left_col=True, bottom=False)
+            out = ops.conv3x3(xin, w, bias=bias, bias2d=bias2d, stride=2, pad_mode=1, out_dtype=torch.float32)
+            assert residual is None
+            return out.view(B, (Hl // 2) * (Wc // 2), Co)
+        xin = seqpar.with_halo(h16, self.comm, Hl, Wc)                          # [B, Hl + 2, Wc, Cin]
+        out = ops.conv3x3(xin, w, bias=bias, bias2d=bias2d, upsample=upsample, out_dtype=torch.float32, n_valid=n_valid)
+        f = 2 if upsample else 1
+        out = out.view(B, f * (Hl + 2), f * Wc, Co)[:, f:f * (Hl + 1)].reshape(B, f * Hl * f * Wc, Co).contiguous()
+        if residual is not None:
+            out = ops.add(out, residual.reshape(out.shape).contiguous())
+        return out
+
+    # ---- building blocks ---------------------------------------------------------------------------------------------
     def _resnet(self, r, x, B, Hc, Wc, temb_all, skip=None):
         """x: fp32 [B, HW, Ci] → fp32 [B, HW, Co]  (diffusers ResnetBlock2D [ext]).
         skip: fp32 [B, HW, Cs] — the block input is torch.cat([x, skip], dim=1) (up blocks); the concatenation is never
-        built: norm1 reads both tensors and emits the 16-bit operands of conv1 and of the 1x1 shortcut."""
-        G, dt = self.cfg["norm_groups"], self.dtype
+        built: norm1 reads both tensors and emits the 16-bit operands of conv1 and of the 1x1 shortcut.
+        (HW = this rank's rows of the Hc x Wc image when the forward is row-sharded.)"""
         Ci = x.shape[-1] + (skip.shape[-1] if skip is not None else 0)
         if "ws" in r:
-            h, raw = ops.groupnorm(x, r["n1"][0], r["n1"][1], G, 1e-5, True, dt, want_raw=True, x2=skip)
+            h, raw = self._gn(x, r["n1"], 1e-5, True, Hc, Wc, want_raw=True, x2=skip)
         else:
             assert skip is None
-            h = ops.groupnorm(x, r["n1"][0], r["n1"][1], G, 1e-5, True, dt)
+            h = self._gn(x, r["n1"], 1e-5, True, Hc, Wc)
         off, Co = self._P["temb_off"][r["name"]]
-        h = ops.conv3x3(h.view(B, Hc, Wc, Ci), r["w1"], bias=r["b1"], bias2d=temb_all[:, off:off + Co],
-                        out_dtype=torch.float32)
-        h = ops.groupnorm(h, r["n2"][0], r["n2"][1], G, 1e-5, True, dt)
+        h = self._conv(h, B, Hc, Wc, r["w1"], bias=r["b1"], bias2d=temb_all[:, off:off + Co])
+        h = self._gn(h, r["n2"], 1e-5, True, Hc, Wc)
         if "ws" in r:
             sc = ops.gemm(raw.view(-1, Ci), r["ws"], bias=r["bs"], out_dtype=torch.float32)
         else:
             sc = x.view(-1, Ci)
-        return ops.conv3x3(h.view(B, Hc, Wc, Co), r["w2"], bias=r["b2"], residual=sc, out_dtype=torch.float32)
+        return self._conv(h, B, Hc, Wc, r["w2"], bias=r["b2"], residual=sc).view(B, -1, Co)
 
-    def _transformer(self, t, x, B, ctx_kv):
-        """Transformer2DModel with use_linear_projection [ext]. x: fp32 [B, HW, C]; ctx_kv: list of cached
-        cross-attention K|V tensors [B, L, 2, heads, 64] for this transformer's blocks."""
-        G, dt, heads = self.cfg["norm_groups"], self.dtype, t["heads"]
+    def _transformer(self, t, x, B, ctx_kv, Hc, Wc):
+        """Transformer2DModel with use_linear_projection [ext]. x: fp32 [B, HW, C] (this rank's rows of the Hc x Wc image);
+        ctx_kv: list of cached cross-attention K|V tensors [B, L, 2, heads, 64] for this transformer's blocks."""
+        dt, heads = self.dtype, t["heads"]
         _, HW, C = x.shape
         hd = C // heads
         scale = hd ** -0.5
-        h = ops.groupnorm(x, t["norm"][0], t["norm"][1], G, 1e-6, False, dt)
+        sp = self.comm.world > 1
+        h = self._gn(x, t["norm"], 1e-6, False, Hc, Wc)
         hs = ops.gemm(h.view(-1, C), t["pin_w"], bias=t["pin_b"], out_dtype=torch.float32)
         nb = len(t["blocks"])
         for k, b in enumerate(t["blocks"]):
             n = ops.layernorm(hs, b["n1"][0], b["n1"][1], 1e-5, dt)
-            qkv = ops.gemm(n, b["wqkv"]).view(B, HW, 3, heads, hd)
-            att = ops.attention(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], scale)
+            if not sp:
+                qkv = ops.gemm(n, b["wqkv"]).view(B, HW, 3, heads, hd)
+                att = ops.attention(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], scale)
+            else:
+                # row-sharded self-attention: the local K | V rows are projected first and their all-gather runs on the
+                # communicator's side stream while the Q projection of the local rows is computed
+                from . import seqpar
+                kv_l = ops.gemm(n, b["wqkv"][C:]).view(B, HW, 2, heads, hd)
+                pending = self.comm.all_gather_async(kv_l)
+                q = ops.gemm(n, b["wqkv"][:C]).view(B, HW, heads, hd)
+                g = pending.wait()                                              # [tp, B, HWl, 2, heads, hd]
+                kv = g.permute(1, 0, 2, 3, 4, 5).reshape(B, g.shape[0] * HW, 2, heads, hd).contiguous()
+                att = ops.attention(q, kv[:, :, 0], kv[:, :, 1], scale)
             hs = ops.gemm(att.view(-1, C), b["wo1"], bias=b["bo1"], residual=hs, out_dtype=torch.float32)
             n = ops.layernorm(hs, b["n2"][0], b["n2"][1], 1e-5, dt)
             q = ops.gemm(n, b["wq2"]).view(B, HW, heads, hd)
@@ -327,12 +378,18 @@ class UNet2DConditionModel:
         return ops.gemm(ops.silu_cast(emb, dt), P["temb_w"], bias=P["temb_b"], out_dtype=torch.float32)
 
     def forward_nhwc(self, x_in, temb_all, ctx, B, H, W):
-        """x_in: fp32 [B, H*W, Cin] NHWC scaled latents → fp32 [B, H*W, 4] noise prediction."""
+        """x_in: fp32 [B, H*W, Cin] NHWC scaled latents → fp32 [B, H*W, 4] noise prediction. With a multi-rank ``comm`` every
+        rank passes the full x_in, works on its H/tp pixel rows in between and returns the full (all-gathered) prediction."""
         P, dt, c = self._P, self.dtype, self.cfg
-        G = c["norm_groups"]
         cin = c["in_channels"]
-        col = ops.im2col3x3_small(x_in.view(B, H, W, cin), self.cin_kpad, dt)
+        tp, rank = self.comm.world, self.comm.rank
+        if tp > 1:
+            from . import seqpar
+            assert H % (tp * 4) == 0, f"latent rows {H} must divide by 4 x the sharding degree {tp} (two 2x down-samplings)"
+        col = ops.im2col3x3_small(x_in.view(B, H, W, cin), self.cin_kpad, dt)       # conv_in: replicated (36/72-wide K)
         x = ops.gemm(col, P["conv_in_w"], bias=P["conv_in_b"], out_dtype=torch.float32).view(B, H * W, -1)
+        if tp > 1:
+            x = seqpar.local_rows(x, rank, tp, H, W)
         skips = [(x, H, W)]
         ti = 0
         Hc, Wc = H, W
@@ -340,17 +397,15 @@ class UNet2DConditionModel:
             for j, r in enumerate(blk["res"]):
                 x = self._resnet(r, x, B, Hc, Wc, temb_all)
                 if blk["attn"]:
-                    x = self._transformer(blk["attn"][j], x, B, ctx[ti])
+                    x = self._transformer(blk["attn"][j], x, B, ctx[ti], Hc, Wc)
                     ti += 1
                 skips.append((x, Hc, Wc))
             if blk["down"] is not None:
-                Ci = x.shape[-1]
-                x = ops.conv3x3(ops.cast(x, dt).view(B, Hc, Wc, Ci), blk["down"][0], bias=blk["down"][1], stride=2,
-                                out_dtype=torch.float32)
+                x = self._conv(ops.cast(x, dt), B, Hc, Wc, blk["down"][0], bias=blk["down"][1], stride=2)
                 Hc, Wc = Hc // 2, Wc // 2
                 skips.append((x, Hc, Wc))
         x = self._resnet(P["mid"]["res"][0], x, B, Hc, Wc, temb_all)
-        x = self._transformer(P["mid"]["attn"][0], x, B, ctx[ti])
+        x = self._transformer(P["mid"]["attn"][0], x, B, ctx[ti], Hc, Wc)
         ti += 1
         x = self._resnet(P["mid"]["res"][1], x, B, Hc, Wc, temb_all)
         for blk in P["up"]:
@@ -358,16 +413,18 @@ class UNet2DConditionModel:
                 s, _, _ = skips.pop()
                 x = self._resnet(r, x.contiguous(), B, Hc, Wc, temb_all, skip=s)   # torch.cat([x, skip], dim=1), fused
                 if blk["attn"]:
-                    x = self._transformer(blk["attn"][j], x, B, ctx[ti])
+                    x = self._transformer(blk["attn"][j], x, B, ctx[ti], Hc, Wc)
                     ti += 1
             if blk["up"] is not None:
-                Ci = x.shape[-1]
-                x = ops.conv3x3(ops.cast(x, dt).view(B, Hc, Wc, Ci), blk["up"][0], bias=blk["up"][1], upsample=True,
-                                out_dtype=torch.float32)
+                x = self._conv(ops.cast(x, dt), B, Hc, Wc, blk["up"][0], bias=blk["up"][1], upsample=True)
                 Hc, Wc = Hc * 2, Wc * 2
-        h = ops.groupnorm(x, P["norm_out"][0], P["norm_out"][1], G, 1e-5, True, dt)
-        return ops.conv3x3(h.view(B, Hc, Wc, x.shape[-1]), P["conv_out_w"], bias=P["conv_out_b"],
-                           out_dtype=torch.float32, n_valid=4 if c["out_channels"] == 4 else 0)
+        h = self._gn(x, P["norm_out"], 1e-5, True, Hc, Wc)
+        nv = 4 if c["out_channels"] == 4 else 0
+        out = self._conv(h, B, Hc, Wc, P["conv_out_w"], bias=P["conv_out_b"], n_valid=nv)
+        out = out.view(B, -1, out.shape[-1])
+        if tp > 1:
+            out = seqpar.gather_rows(out, self.comm)
+        return out
 
     # ---- diffusers-compatible call ---------------------------------------------------------------------------------------
     def forward(self, sample, timestep, encoder_hidden_states, added_cond_kwargs=None, cross_attention_kwargs=None,

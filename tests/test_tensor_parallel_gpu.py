@@ -91,3 +91,110 @@ def test_denoise_cfg_parallel(dev):
     e = relerr(outs[0], ref)
     print(f"CFG-parallel denoise rel-L2 vs oracle {e:.2e}")
     assert e < 5e-3
+
+
+# ---- pixel-row-sharded UNet (seedx_amd/seqpar.py): tp virtual ranks on one GPU == one rank == oracle ---------------------
+def _unet_args(cfg, B, H, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, cfg["in_channels"], H, H, generator=g)
+    ehs = torch.randn(B, 16, cfg["cross_attention_dim"], generator=g)
+    te = torch.randn(B, cfg["pooled_dim"], generator=g)
+    tid = torch.tensor([[1024.0, 1024, 0, 0, 1024, 1024]] * B)
+    return x, ehs, te, tid
+
+
+def _run_unet(dev, cfg, sd, args, dtype, comm=None):
+    from seedx_amd.unet import UNet2DConditionModel
+    x, ehs, te, tid = args
+    torch.cuda.set_device(dev)
+    m = UNet2DConditionModel(comm=comm, **cfg)
+    m.load_state_dict(dict(sd))
+    m.to(dev, dtype)
+    out = m(x.to(dev), 481.0, ehs.to(dev), added_cond_kwargs={"text_embeds": te.to(dev), "time_ids": tid.to(dev)},
+            return_dict=False)[0]
+    torch.cuda.synchronize()
+    return out.float().cpu()
+
+
+@pytest.mark.parametrize("tp,H", [(2, 16), (4, 16), (8, 32)])
+def test_unet_row_sharded_mini(dev, tp, H):
+    """Whole mini UNet (down / mid / up blocks, both samplers, attention at two resolutions), edit variant (8 input
+    channels, Bc = 3): every virtual rank returns the full prediction; ranks agree bit for bit and match one rank / oracle."""
+    from seedx_amd.parallel import run_virtual_ranks
+    cfg = dict(ru.MINI_UNET, in_channels=8)
+    sd = ru.unet_sd(cfg)
+    args = _unet_args(cfg, 3, H, 40 + tp)
+    ref = ru.unet_forward(sd, cfg, args[0], 481.0, args[1], args[2], args[3])
+    single = _run_unet(dev, cfg, sd, args, torch.float16)
+    outs = run_virtual_ranks(tp, lambda comm: _run_unet(dev, cfg, sd, args, torch.float16, comm))
+    for r in range(1, tp):
+        assert torch.equal(outs[r], outs[0])
+    e1, e2 = relerr(outs[0], ref), relerr(outs[0], single)
+    print(f"row-sharded mini UNet tp={tp}: rel-L2 vs oracle {e1:.2e}, vs one rank {e2:.2e}")
+    assert outs[0].shape == (3, 4, H, H) and e1 < 3e-3 and e2 < 2e-3
+
+
+@pytest.mark.parametrize("tp", [2, 4, 8])
+def test_unet_row_sharded_full_width(dev, tp):
+    """SDXL channel widths (320 / 640 / 1280), head counts (5 / 10 / 20 x 64) and the 2048-wide context with ONE resnet and
+    ONE transformer layer per block, 64x64 latents, CFG batch 2: the shapes that do not divide under channel sharding."""
+    from seedx_amd.parallel import run_virtual_ranks
+    cfg = dict(ru.FULL_UNET, layers_per_block=1, transformer_layers=(1, 1, 1))
+    sd = ru.unet_sd(cfg, device=dev)
+    g = torch.Generator().manual_seed(50)
+    x = torch.randn(2, 4, 64, 64, generator=g)
+    ehs = torch.randn(2, 64, 2048, generator=g)
+    te = torch.randn(2, 1280, generator=g)
+    tid = torch.tensor([[1024.0, 1024, 0, 0, 1024, 1024]] * 2)
+    with torch.no_grad():
+        ref = ru.unet_forward(sd, cfg, x.to(dev), 481.0, ehs.to(dev), te.to(dev), tid.to(dev)).cpu()
+    sd_cpu = {k: v.cpu() for k, v in sd.items()}
+    del sd
+    torch.cuda.empty_cache()
+    args = (x, ehs, te, tid)
+    ucfg = dict(cfg, in_channels=4)
+    single = _run_unet(dev, ucfg, sd_cpu, args, torch.float16)
+    outs = run_virtual_ranks(tp, lambda comm: _run_unet(dev, ucfg, sd_cpu, args, torch.float16, comm))
+    for r in range(1, tp):
+        assert torch.equal(outs[r], outs[0])
+    e1, e2 = relerr(outs[0], ref), relerr(outs[0], single)
+    print(f"row-sharded full-width UNet tp={tp}: rel-L2 vs oracle {e1:.2e}, vs one rank {e2:.2e}")
+    assert e1 < 3e-3 and e2 < 2e-3
+
+
+def test_edit_loop_row_sharded_tp4(dev):
+    """BASELINE config 4 shape of the problem (edit, Bc = 3, TP = 4): the [text, image, uncond] denoise loop with the UNet
+    sharded over 4 virtual ranks == oracle edit loop."""
+    from seedx_amd.detokenizer import EulerDiscreteScheduler, _DenoiseLoop
+    from seedx_amd.parallel import run_virtual_ranks
+    from seedx_amd.unet import UNet2DConditionModel
+    cfg = dict(ru.MINI_UNET, in_channels=8)
+    sd = ru.unet_sd(cfg)
+    g = torch.Generator().manual_seed(60)
+    pe, ne = torch.randn(1, 16, 128, generator=g), torch.randn(1, 16, 128, generator=g)
+    pp, npool = torch.randn(1, 128, generator=g), torch.randn(1, 128, generator=g)
+    tid = torch.tensor([[1024.0, 1024, 0, 0, 1024, 1024]])
+    steps = 3
+    _, _, init = ru.euler_tables(steps)
+    lat0 = torch.randn(1, 4, 16, 16, generator=g) * init
+    il = torch.randn(1, 4, 16, 16, generator=g)
+    il3 = torch.cat([il, il, torch.zeros_like(il)])
+    fn = lambda s, t, e, p, ti: ru.unet_forward(sd, cfg, s, t, e, p, ti)
+    ref = ru.edit_loop(fn, lat0, il3, pe, ne, pp, npool, tid, steps)
+
+    def run(comm):
+        torch.cuda.set_device(dev)
+        m = UNet2DConditionModel(comm=comm, **cfg)
+        m.load_state_dict(dict(sd))
+        m.to(dev, torch.float16)
+        loop = _DenoiseLoop(m, use_graph=True)                       # falls back to eager: ThreadComm is not graph-safe
+        out = loop.run(1, lat0, torch.cat([pe, ne, ne]), torch.cat([pp, npool, npool]), tid.repeat(3, 1),
+                       EulerDiscreteScheduler(), steps, 7.5, 1.5, il3)
+        torch.cuda.synchronize()
+        return out.float().cpu()
+
+    outs = run_virtual_ranks(4, run)
+    assert all(torch.equal(o, outs[0]) for o in outs[1:])
+    e = relerr(outs[0], ref)
+    print(f"edit loop, UNet row-sharded over 4 ranks: rel-L2 vs oracle {e:.2e}")
+    assert e < 5e-3
