@@ -73,10 +73,11 @@ BATCH = 16       # generations processed together per step on one GPU (set from 
 GRID_PINPOINTS = [[a * 448, b * 448] for a, b in ((1, 1), (1, 2), (1, 3), (2, 1), (3, 1), (1, 4), (4, 1), (2, 2))]
 
 
-def build_models(dev, dtype, llm_comm=None, cfg_comm=None, need=("vit", "llm", "adapter"), edit=False, max_cache_len=1024):
-    """llm_comm / cfg_comm: tensor-parallel Llama and CFG-parallel UNet communicators (tools/bench_tp_latency.py only;
-    the throughput bench leaves them None = one full replica per GPU). Returns (vit, agent, adapter); parts not in `need`
-    are None."""
+def build_models(dev, dtype, llm_comm=None, cfg_comm=None, need=("vit", "llm", "adapter"), edit=False, max_cache_len=1024,
+                 unet_comm=None):
+    """llm_comm / cfg_comm / unet_comm: tensor-parallel Llama, CFG-parallel loop and pixel-row-sharded UNet communicators
+    (tools/bench_tp_latency.py only; the throughput bench leaves them None = one full replica per GPU). Returns
+    (vit, agent, adapter); parts not in `need` are None."""
     from seedx_amd import synthetic as syn
     from seedx_amd.detokenizer import EulerDiscreteScheduler, ResamplerXLV2, SDXLAdapter, SDXLAdapterWithLatentImage
     from seedx_amd.llama import LlamaForCausalLM
@@ -102,7 +103,7 @@ def build_models(dev, dtype, llm_comm=None, cfg_comm=None, need=("vit", "llm", "
         agent.eval().to(dev, dtype)
     if "adapter" in need:
         ucfg = dict(SDXL_BASE_CONFIG, in_channels=8) if edit else dict(SDXL_BASE_CONFIG)
-        unet = UNet2DConditionModel(**ucfg)
+        unet = UNet2DConditionModel(comm=unet_comm, **ucfg)
         unet.load_state_dict(syn.unet_state_dict(unet.cfg, dev, dtype))
         res = ResamplerXLV2(normalize=False, **syn.FULL_XLV2)
         res.load_state_dict(syn.xlv2_state_dict(syn.FULL_XLV2, dev, dtype), prefix="resampler.")

@@ -1,23 +1,31 @@
-"""Latency mode: ONE generation spread over the GPUs of a node (north-star's tensor-parallel form).
+"""Latency mode: ONE generation spread over the GPUs of a node (the north-star's sharded form).
 
+    python tools/bench_tp_latency.py --gpus N [--steps 3] [--config 0|4]     (starts the N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port 29533 \
-        tools/bench_tp_latency.py --steps 3
+        tools/bench_tp_latency.py --steps 3                                   (or under an external launcher)
 
-  * Llama decoder: Megatron TP over all N ranks (seedx_amd.parallel / llama.py): 2 fp32 all-reduces per layer over RCCL
-  * SDXL UNet: CFG-parallel on ranks 0 and 1 (one eps all-gather per denoise step); ranks >= 2 idle in that phase
-  * ViT + resamplers: replicated (8.4 TFLOP, < 1 % of a generation)
+  * Llama decoder: Megatron tensor parallelism over all N ranks (seedx_amd.parallel / llama.py): heads, FFN rows and
+    vocabulary split, 2 fp32 all-reduces per layer over RCCL
+  * SDXL UNet: pixel-row sharding over all N ranks (seedx_amd/seqpar.py): weights replicated, one K|V all-gather per
+    self-attention overlapped with the Q projection on RCCL's side stream, conv halo rows, GroupNorm statistics
+    all-reduce; `--unet cfg` selects the older CFG-parallel split (2 ranks busy) instead. `--config 4` runs the edit
+    pipeline (Bc = 3, 8 input channels) — BASELINE config 4 at TP = N.
+  * ViT + resamplers + VAE: replicated (< 2 % of a generation)
 
 NOT the headline metric: replicas (bench.py) give the higher gens/s because generations are independent; this mode
-trades throughput for single-request latency. The sharded code path is validated on one GPU with virtual ranks
-(tests/test_tensor_parallel_gpu.py); this launcher itself could not be exercised on the single-GPU boxes of this pool.
+trades throughput for single-request latency. The sharded code paths are validated on one GPU with virtual ranks
+(tests/test_tensor_parallel_gpu.py) and on CPU over gloo (tests/test_cpu_suite.py); this pool's boxes have ONE GPU, so the
+RCCL timing of this launcher has not been measured.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 import torch
 
 import bench
@@ -25,30 +33,50 @@ import bench
 
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=None)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--unet-steps", type=int, default=50)
     ap.add_argument("--text-tokens", type=int, default=61)
+    ap.add_argument("--config", type=int, default=0, choices=[0, 4])
+    ap.add_argument("--unet", default="rows", choices=["rows", "cfg"])
     a = ap.parse_args()
+    if a.gpus and a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr",
+               "127.0.0.1", "--master-port", str(bench._free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.run(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")).returncode)
     import torch.distributed as dist
     from seedx_amd import dist_utils as du
     from seedx_amd.parallel import Comm, TorchDistComm
     ctx = du.init("nccl")
+    if a.gpus and ctx.world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but {ctx.world} rank(s) came up")
     torch.cuda.set_device(ctx.local)
     dev = torch.device("cuda", ctx.local)
-    llm_comm = TorchDistComm() if ctx.world > 1 else Comm()
-    cfg_group = dist.new_group([0, 1]) if ctx.world >= 2 else None          # collective call: every rank executes it
-    cfg_comm = TorchDistComm(cfg_group) if (ctx.world >= 2 and ctx.rank < 2) else None
+    multi = ctx.world > 1
+    llm_comm = TorchDistComm() if multi else Comm()
+    unet_comm = cfg_comm = None
+    edit = a.config == 4
+    if multi and a.unet == "rows":
+        unet_comm = TorchDistComm()
+    elif multi:
+        nb = 3 if edit else 2
+        assert ctx.world >= nb, "CFG-parallel needs one rank per guidance branch"
+        grp = dist.new_group(list(range(nb)))                                  # collective call: every rank executes it
+        cfg_comm = TorchDistComm(grp) if ctx.rank < nb else None
     bench.BATCH = 1
     tok = bench.BenchTokenizer()
     with torch.no_grad():
-        vit, agent, adapter = bench.build_models(dev, torch.bfloat16, llm_comm=llm_comm, cfg_comm=cfg_comm)
-        inp = bench.make_inputs(dev)
+        vit, agent, adapter = bench.build_models(dev, torch.bfloat16, llm_comm=llm_comm, cfg_comm=cfg_comm,
+                                                 unet_comm=unet_comm, edit=edit)
+        inp = bench.make_inputs(dev, extra_text=16 if edit else 0)
+        src = torch.randn(1, 4, 128, 128, generator=torch.Generator().manual_seed(7))
+        in_back = a.unet == "rows" or not multi or cfg_comm is not None
 
         def one(seed):
-            feats = bench.front_half(vit, agent, tok, inp, a.text_tokens, dev)
-            if ctx.world < 2 or ctx.rank < 2:
-                bench.back_half(adapter, feats, a.unet_steps, seed)
+            feats = bench.front_half(vit, agent, tok, inp, 8 if edit else a.text_tokens, dev)
+            if in_back:
+                bench.back_half(adapter, feats, a.unet_steps, seed, **({"image_latents": src} if edit else {}))
         for i in range(a.warmup):
             one(100 + i)
         torch.cuda.synchronize(); du.barrier(ctx); torch.cuda.synchronize()
@@ -58,11 +86,13 @@ def main():
         torch.cuda.synchronize(); du.barrier(ctx); torch.cuda.synchronize()
         dt = du.max_over_ranks(ctx, time.perf_counter() - t0)
     if ctx.rank == 0:
-        print(json.dumps({"metric": "single-request latency (img-in -> txt + 1024px latents)", "value": dt / a.steps,
-                          "unit": "s/generation", "n_gpus": ctx.world, "steps": a.steps, "warmup": a.warmup,
-                          "higher_is_better": False, "scaling": "strong", "dtype": "bf16",
-                          "config": {"workload": "as bench.py, batch 1", "parallelism":
-                                     "llama tp%d (RCCL all-reduce), unet cfg-parallel x%d" % (ctx.world, min(ctx.world, 2))}}))
+        print(json.dumps({"metric": "single-request latency (%s)" % ("edit: img+instruction -> edited 1024px image" if edit
+                                                                     else "img-in -> txt + 1024px image"),
+                          "value": dt / a.steps, "unit": "s/generation", "n_gpus": ctx.world, "steps": a.steps,
+                          "warmup": a.warmup, "higher_is_better": False, "scaling": "strong", "dtype": "bf16",
+                          "config": {"workload": "as bench.py --config %d, batch 1" % a.config, "parallelism":
+                                     "llama tp%d (RCCL all-reduce), unet %s" % (ctx.world, "pixel-row sharded x%d (K|V all-gather)"
+                                                                                 % ctx.world if a.unet == "rows" else "cfg-parallel")}}))
     du.finalize(ctx)
 
 
