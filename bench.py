@@ -299,6 +299,7 @@ class MultiTurn(Workload):                                                      
         from seedx_amd import image_ops
         T = BenchTokenizer
         reqs = requests_for(self.vit, self.inp, self.dev)                       # ViT B = 20 per request
+        self.agent._conv = {}                                                   # every step is a NEW conversation
         ids = list(self.inp[1])
         pre = []
         for turn in range(3):

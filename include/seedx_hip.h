@@ -139,7 +139,8 @@ int sx_groupnorm_sp(const float* x, const float* x2, int C1, void* y, void* raw1
 /* ------------------------------------------------------------------------------------------------
  * Attention
  * ------------------------------------------------------------------------------------------------ */
-/* Vt[b][h][d][kv] (kv padded to kv_pad, zero filled) = V[b][kv][h][d]; pre-pass for sx_attention. */
+/* Vt[b][h][d][kv] (kv padded to kv_pad, zero filled) = V[b][kv][h][d]. NOT needed by sx_attention any more (round 2: the
+ * kernel reads row-major V and transposes with ds_read_b64_tr_b16); kept as a utility. */
 int sx_transpose_v(const void* V, void* Vt, int B, int H, int Skv, int D, int kv_pad, int64_t v_batch_stride,
                    int64_t v_row_stride, int64_t v_head_stride, void* stream);
 
@@ -147,18 +148,19 @@ int sx_transpose_v(const void* V, void* Vt, int B, int H, int Skv, int D, int kv
  * replaces: bmm→softmax→bmm (qwen_visual.py:204-215), nn.MultiheadAttention core (qwen_visual.py:145),
  *           xformers memory_efficient_attention (modeling_llama_xformer.py:221-238),
  *           torch SDPA in diffusers AttnProcessor2_0 [ext].
- * Q[b][sq][h][D], K[b][skv][h][D] addressed with element strides; Vt from sx_transpose_v.
+ * Q[b][sq][h][D], K[b][skv][h][D], V[b][skv][h][D] addressed with element strides (multiples of 8 elements).
  * O[b][sq][h][D] (o_row_stride = elements between consecutive sq; heads packed at h*D).
  * causal: key j visible to query i iff j <= i + (Skv - Sq)  (bottom-right aligned; prefill and chunked decode).
  * D must be a multiple of 8 and <= 128 (104 is padded to 128 in LDS/registers only). */
 typedef struct sx_attn_args {
   const void* Q;
   const void* K;
-  const void* Vt;
+  const void* V;
   void* O;
-  int32_t B, H, Sq, Skv, D, kv_pad;
+  int32_t B, H, Sq, Skv, D, reserved;
   int64_t q_batch_stride, q_row_stride, q_head_stride;
   int64_t k_batch_stride, k_row_stride, k_head_stride;
+  int64_t v_batch_stride, v_row_stride, v_head_stride;
   int64_t o_batch_stride, o_row_stride;
   float scale;
   int32_t causal;

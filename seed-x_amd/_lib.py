@@ -31,10 +31,11 @@ class GemvArgs(C.Structure):
 
 
 class AttnArgs(C.Structure):
-    _fields_ = [("Q", c_vp), ("K", c_vp), ("Vt", c_vp), ("O", c_vp),
-                ("B", c_i32), ("H", c_i32), ("Sq", c_i32), ("Skv", c_i32), ("D", c_i32), ("kv_pad", c_i32),
+    _fields_ = [("Q", c_vp), ("K", c_vp), ("V", c_vp), ("O", c_vp),
+                ("B", c_i32), ("H", c_i32), ("Sq", c_i32), ("Skv", c_i32), ("D", c_i32), ("reserved", c_i32),
                 ("q_batch_stride", c_i64), ("q_row_stride", c_i64), ("q_head_stride", c_i64),
                 ("k_batch_stride", c_i64), ("k_row_stride", c_i64), ("k_head_stride", c_i64),
+                ("v_batch_stride", c_i64), ("v_row_stride", c_i64), ("v_head_stride", c_i64),
                 ("o_batch_stride", c_i64), ("o_row_stride", c_i64),
                 ("scale", c_f32), ("causal", c_i32), ("dtype", c_i32)]
 

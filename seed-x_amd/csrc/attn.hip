@@ -9,21 +9,28 @@
 //     over keys is permuted by loading the K rows of a tile in the order r ↔ key swap_bits23(r): lane-half hi then owns
 //     the keys 8hi..8hi+7 of every 16-key step = one 16-B piece of a V^T row (single ds_read_b128), so
 //     no cross-lane shuffle / LDS round trip of P is needed
-//   * V is transposed once per call by sx_transpose_v (V^T rows are key-contiguous), so both MFMA
-//     operands are plain "k-contiguous" LDS rows read with ds_read_b128 / ds_read_b64, XOR-swizzled
+//   * V stays in its natural row-major [key][d] layout in HBM and in LDS (DMA'd exactly like K): the key-contiguous V^T
+//     fragment the P·V MFMA wants is produced by gfx950's transposing LDS read `ds_read_b64_tr_b16` (two per 8-key
+//     fragment) — no V^T pre-pass over HBM. Routing of that instruction (probed on the MI355X, tools/probes/
+//     tr_read_probe.hip): in each 16-lane group, lane l receives element (l & 3) of the 8-byte rows addressed by lanes
+//     4j + (l >> 2), j = 0..3. The V tile's 16-B chunks are XOR-swizzled by row so the 4 rows x 2 groups of one
+//     32-lane LDS cycle fall on 64 distinct banks
 //   * head_dim 104 (ViT-G, qwen_visual.py:170) is zero-padded to 128 only in LDS/registers via the buffer
 //     range check — HBM layout stays [.., 104]
 #include "sx_common.h"
 
 namespace sxk_attn {
 
+typedef short tr4_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) tr4_t lds_tr4_t;
+
 struct AttnP {
   const unsigned short* Q;
   const unsigned short* K;
-  const unsigned short* Vt;
+  const unsigned short* V;
   unsigned short* O;
-  int B, H, Sq, Skv, D, kv_pad, q_tiles, causal;
-  long long qbs, qrs, qhs, kbs, krs, khs, obs, ors;
+  int B, H, Sq, Skv, D, q_tiles, causal;
+  long long qbs, qrs, qhs, kbs, krs, khs, vbs, vrs, vhs, obs, ors;
   float scale_log2;
 };
 
@@ -34,7 +41,7 @@ __global__ __launch_bounds__(256, (DP <= 64 ? 4 : 1)) void attn_kernel(const Att
   typedef typename TT::vec4 vec4;
   constexpr int KROW = DP * 2;                 // bytes per K row in LDS (128 | 256)
   constexpr int K_BYTES = 64 * KROW;           // K tile
-  constexpr int V_BYTES = DP * 128;            // V^T tile: DP rows x 64 keys
+  constexpr int V_BYTES = K_BYTES;             // V tile: 64 keys x DP, row-major like K
   constexpr int STAGE = K_BYTES + V_BYTES;
   constexpr int K_SLOTS = K_BYTES / 1024, V_SLOTS = V_BYTES / 1024;  // 1-KiB DMA slots
   constexpr int KCH = KROW / 16;               // 16-B chunks per K row (8 | 16)
@@ -61,9 +68,9 @@ __global__ __launch_bounds__(256, (DP <= 64 ? 4 : 1)) void attn_kernel(const Att
   }
 
   const unsigned short* Kb = p.K + b * p.kbs + h * p.khs;
-  const unsigned short* Vb = p.Vt + ((long long)(b * p.H + h) * p.D) * p.kv_pad;
+  const unsigned short* Vb = p.V + b * p.vbs + h * p.vhs;
   const int k_bytes = (int)(((long long)(p.Skv - 1) * p.krs + p.D) * 2);
-  const int v_bytes = p.D * p.kv_pad * 2;
+  const int v_bytes = (int)(((long long)(p.Skv - 1) * p.vrs + p.D) * 2);
   __amdgpu_buffer_rsrc_t rK = __builtin_amdgcn_make_buffer_rsrc((void*)Kb, 0, k_bytes, 0x00020000);
   __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc((void*)Vb, 0, v_bytes, 0x00020000);
 
@@ -84,14 +91,19 @@ __global__ __launch_bounds__(256, (DP <= 64 ? 4 : 1)) void attn_kernel(const Att
     k_row[i] = (r & ~0xC) | ((r & 4) << 1) | ((r & 8) >> 1);
     k_off[i] = (c * 8 < p.D) ? (unsigned)(c * 16) : 0x80000000u;
   }
-  // V^T: slot s holds 8 rows (d) of 128 B; lane -> (row_in_slot = lane>>3, pos = lane&7), key = (d>>1)&7
+  // V: slot s holds KRPS rows (keys, natural order) of KROW bytes; lane -> (row_in_slot, chunk position); the logical
+  // 16-B chunk stored at position pos of row r is pos ^ vswz(r), vswz chosen for the transposing reads (see header)
   unsigned v_off[V_SLOTS / 4];
+  int v_row[V_SLOTS / 4];
 #pragma unroll
   for (int i = 0; i < V_SLOTS / 4; ++i) {
     const int slot = wave * (V_SLOTS / 4) + i;
-    const int d = slot * 8 + (lane >> 3);
-    const int c = (lane & 7) ^ ((d >> 1) & 7);
-    v_off[i] = (d < p.D) ? (unsigned)(d * p.kv_pad * 2 + c * 16) : 0x80000000u;
+    const int r = slot * KRPS + lane / KCH;
+    const int pos = lane % KCH;
+    const int key = (KCH == 16) ? ((r & 3) << 2) : (((r >> 1) & 1) << 2);
+    const int c = pos ^ key;
+    v_row[i] = r;
+    v_off[i] = (c * 8 < p.D) ? (unsigned)(c * 16) : 0x80000000u;
   }
 
   auto stage = [&](int buf, int kvt) {
@@ -107,8 +119,10 @@ __global__ __launch_bounds__(256, (DP <= 64 ? 4 : 1)) void attn_kernel(const Att
     }
 #pragma unroll
     for (int i = 0; i < V_SLOTS / 4; ++i) {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rV, SX_LDS_PTR(sV + (wave * (V_SLOTS / 4) + i) * 1024), 16,
-                                               v_off[i] + (unsigned)kv0 * 2u, 0, 0, 0);
+      const int kv = kv0 + v_row[i];                 // rows past Skv are fetched as zeros (0 · P, never NaN)
+      const unsigned voff = (kv < p.Skv) ? (unsigned)((long long)kv * p.vrs * 2) + v_off[i] : 0x80000000u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rV, SX_LDS_PTR(sV + (wave * (V_SLOTS / 4) + i) * 1024), 16, voff, 0, 0,
+                                               0);
     }
   };
 
@@ -137,9 +151,16 @@ __global__ __launch_bounds__(256, (DP <= 64 ? 4 : 1)) void attn_kernel(const Att
   // K frag (A operand): row = 32jb + (lane&31), logical chunk = 2ks + hi
   const int kkey = (KCH == 16) ? (lq & 15) : ((lq >> 1) & 7);
   const unsigned k_rd = (unsigned)lq * KROW;
-  // V^T frag (A operand of O^T): row d = 32dt + (lane&31); keys 16kk + 8hi .. +7 = 16-B chunk (2kk + hi)
-  const int vkey = (lq >> 1) & 7;
-  const unsigned v_rd = (unsigned)lq * 128u;
+  // V^T frag (A operand of O^T = V^T · P^T): lane (d = 32dt + (lane & 31), hi) needs V[16kk + 8hi + i][d], i = 0..7, from
+  // the row-major tile: two ds_read_b64_tr_b16 (i = 0..3, 4..7). In its 16-lane group g = lane >> 4 lane R = lane & 15
+  // SUPPLIES the address of row 16kk + 8(g >> 1) + 4half + (R >> 2), d offset 32dt + 16(g & 1) + 4(R & 3) (4 elements)
+  const int vg = lane >> 4, vR = lane & 15;
+  const int v_r0 = 8 * (vg >> 1) + (vR >> 2);                                   // row of the lane within a 16-key step
+  const int v_key = (KCH == 16) ? ((v_r0 & 3) << 2) : (((v_r0 >> 1) & 1) << 2); // (16kk + 4half) keeps these row bits
+  const unsigned v_rd = (unsigned)v_r0 * KROW + (unsigned)(vR & 1) * 8u;
+  unsigned v_col[NDT];
+#pragma unroll
+  for (int dt = 0; dt < NDT; ++dt) v_col[dt] = (unsigned)(((4 * dt + 2 * (vg & 1) + ((vR & 3) >> 1)) ^ v_key) << 4);
 
   if (nt > 0) stage(0, 0);
   __syncthreads();
@@ -218,7 +239,12 @@ __global__ __launch_bounds__(256, (DP <= 64 ? 4 : 1)) void attn_kernel(const Att
     for (int dt = 0; dt < NDT; ++dt) {
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {  // kk = 2jb + s2 : 16 keys
-        const vec8 vf = *(const vec8*)(sV + dt * 32 * 128 + v_rd + (((2 * kk + hi) ^ vkey) << 4));
+        const unsigned char* vp = sV + v_rd + v_col[dt] + kk * 16 * KROW;
+        const tr4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr4_t*)SX_LDS_PTR(vp));
+        const tr4_t hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr4_t*)SX_LDS_PTR(vp + 4 * KROW));
+        vec8 vf;
+        __builtin_memcpy(&vf, &lo, 8);
+        __builtin_memcpy((char*)&vf + 8, &hi4, 8);
         o[dt] = TT::mfma32(vf, pb[kk], o[dt]);
       }
     }
@@ -357,31 +383,33 @@ extern "C" int sx_transpose_v(const void* V, void* Vt, int B, int H, int Skv, in
 }
 
 extern "C" int sx_attention(const sx_attn_args* a, void* stream) {
-  SX_CHECK(a && a->Q && a->K && a->Vt && a->O, "sx_attention: null pointer");
+  SX_CHECK(a && a->Q && a->K && a->V && a->O, "sx_attention: null pointer");
   SX_CHECK(a->dtype == SX_F16 || a->dtype == SX_BF16, "sx_attention: dtype");
   SX_CHECK(a->D % 8 == 0 && a->D >= 8 && a->D <= 128, "sx_attention: head_dim %d unsupported", a->D);
   SX_CHECK(a->Sq > 0 && a->Skv > 0 && a->B > 0 && a->H > 0, "sx_attention: empty problem");
-  SX_CHECK(a->kv_pad % 64 == 0 && a->kv_pad >= a->Skv, "sx_attention: kv_pad");
   SX_CHECK(a->q_row_stride % 8 == 0 && a->q_head_stride % 8 == 0 && a->q_batch_stride % 8 == 0 &&
-               a->k_row_stride % 8 == 0 && a->k_head_stride % 8 == 0 && a->k_batch_stride % 8 == 0,
-           "sx_attention: Q/K strides must be multiples of 8 elements (16 B)");
+               a->k_row_stride % 8 == 0 && a->k_head_stride % 8 == 0 && a->k_batch_stride % 8 == 0 &&
+               a->v_row_stride % 8 == 0 && a->v_head_stride % 8 == 0 && a->v_batch_stride % 8 == 0,
+           "sx_attention: Q/K/V strides must be multiples of 8 elements (16 B)");
   SX_CHECK(a->o_row_stride % 4 == 0 && a->o_batch_stride % 4 == 0, "sx_attention: O strides");
   SX_CHECK(!a->causal || a->Skv >= a->Sq, "sx_attention: causal needs Skv >= Sq");
   SX_CHECK(((int64_t)(a->Skv - 1) * a->k_row_stride + a->D) * 2 < 0x7fffffffll, "sx_attention: K range too large");
+  SX_CHECK(((int64_t)(a->Skv - 1) * a->v_row_stride + a->D) * 2 < 0x7fffffffll, "sx_attention: V range too large");
   AttnP p;
-  p.Q = (const unsigned short*)a->Q; p.K = (const unsigned short*)a->K; p.Vt = (const unsigned short*)a->Vt;
+  p.Q = (const unsigned short*)a->Q; p.K = (const unsigned short*)a->K; p.V = (const unsigned short*)a->V;
   p.O = (unsigned short*)a->O;
-  p.B = a->B; p.H = a->H; p.Sq = a->Sq; p.Skv = a->Skv; p.D = a->D; p.kv_pad = a->kv_pad;
+  p.B = a->B; p.H = a->H; p.Sq = a->Sq; p.Skv = a->Skv; p.D = a->D;
   p.q_tiles = (a->Sq + 127) / 128;
   p.causal = a->causal;
   p.qbs = a->q_batch_stride; p.qrs = a->q_row_stride; p.qhs = a->q_head_stride;
   p.kbs = a->k_batch_stride; p.krs = a->k_row_stride; p.khs = a->k_head_stride;
+  p.vbs = a->v_batch_stride; p.vrs = a->v_row_stride; p.vhs = a->v_head_stride;
   p.obs = a->o_batch_stride; p.ors = a->o_row_stride;
   p.scale_log2 = a->scale * 1.4426950408889634f;
   const int grid = a->B * a->H * p.q_tiles;
   hipStream_t st = (hipStream_t)stream;
   const int dp = a->D <= 64 ? 64 : 128;
-  const size_t lds = 2 * (size_t)(64 * dp * 2 + dp * 128);
+  const size_t lds = 2 * (size_t)(2 * 64 * dp * 2);     // 2 stages x (K tile + V tile)
   if (a->dtype == SX_BF16) {
     if (dp == 64) hipLaunchKernelGGL((attn_kernel<BF16, 64>), dim3(grid), dim3(256), lds, st, p);
     else hipLaunchKernelGGL((attn_kernel<BF16, 128>), dim3(grid), dim3(256), lds, st, p);

@@ -238,9 +238,8 @@ class _DenoiseLoop:
         ctx = unet.prepare_context(S["ehs"][lo:hi])                               # step-invariant cross-attn K/V
         if self._graph is not None and self._ctx_static is not None:
             for per_s, per_n in zip(self._ctx_static, ctx):                       # the graph holds these addresses
-                for (ka, va), (kb, vb) in zip(per_s, per_n):
-                    ka.copy_(kb)
-                    va.copy_(vb)
+                for kv_s, kv_n in zip(per_s, per_n):
+                    kv_s.copy_(kv_n)
             ctx = self._ctx_static
         else:
             self._ctx_static = ctx

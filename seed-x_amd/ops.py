@@ -233,25 +233,22 @@ def transpose_v(v):
     return vt
 
 
-def attention(q, k, v, scale, causal=False, out=None, vt=None):
-    """Flash attention on MFMA. q: [B, Sq, H, D] view, k/v: [B, Skv, H, D] views (any strides with unit D stride).
-    vt: optional precomputed transpose_v(v) (step-invariant cross-attention context). Returns [B, Sq, H*D] 16-bit."""
+def attention(q, k, v, scale, causal=False, out=None):
+    """Flash attention on MFMA. q: [B, Sq, H, D] view, k/v: [B, Skv, H, D] views (any strides that are multiples of 8
+    elements, unit D stride). V is read in this natural layout (the kernel transposes fragments with ds_read_b64_tr_b16).
+    Returns [B, Sq, H*D] 16-bit."""
     lib = _lib.load()
     B, Sq, H, D = q.shape
     Skv = k.shape[1]
-    assert k.shape == (B, Skv, H, D) and q.dtype == k.dtype
-    if vt is None:
-        assert v.shape == (B, Skv, H, D) and v.dtype == q.dtype
-        vt = transpose_v(v)
-    kv_pad = vt.shape[-1]
-    assert vt.shape == (B, H, D, kv_pad) and vt.is_contiguous()
+    assert k.shape == (B, Skv, H, D) and v.shape == (B, Skv, H, D) and q.dtype == k.dtype == v.dtype
     if out is None:
         out = torch.empty((B, Sq, H * D), dtype=q.dtype, device=q.device)
     a = AttnArgs()
-    a.Q, a.K, a.Vt, a.O = q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr()
-    a.B, a.H, a.Sq, a.Skv, a.D, a.kv_pad = B, H, Sq, Skv, D, kv_pad
+    a.Q, a.K, a.V, a.O = q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr()
+    a.B, a.H, a.Sq, a.Skv, a.D = B, H, Sq, Skv, D
     a.q_batch_stride, a.q_row_stride, a.q_head_stride = _bshd_strides(q)
     a.k_batch_stride, a.k_row_stride, a.k_head_stride = _bshd_strides(k)
+    a.v_batch_stride, a.v_row_stride, a.v_head_stride = _bshd_strides(v)
     a.o_batch_stride, a.o_row_stride = out.stride(0), out.stride(1)
     a.scale = float(scale)
     a.causal = 1 if causal else 0

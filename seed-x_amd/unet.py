@@ -329,8 +329,8 @@ class UNet2DConditionModel:
             hs = ops.gemm(att.view(-1, C), b["wo1"], bias=b["bo1"], residual=hs, out_dtype=torch.float32)
             n = ops.layernorm(hs, b["n2"][0], b["n2"][1], 1e-5, dt)
             q = ops.gemm(n, b["wq2"]).view(B, HW, heads, hd)
-            kv, vt = ctx_kv[k]
-            att = ops.attention(q, kv[:, :, 0], None, scale, vt=vt)
+            kv = ctx_kv[k]
+            att = ops.attention(q, kv[:, :, 0], kv[:, :, 1], scale)
             hs = ops.gemm(att.view(-1, C), b["wo2"], bias=b["bo2"], residual=hs, out_dtype=torch.float32)
             n = ops.layernorm(hs, b["n3"][0], b["n3"][1], 1e-5, dt)
             g = ops.gemm(n, b["wff1"], bias=b["bff1"], act="gelu", glu=True)
@@ -355,7 +355,7 @@ class UNet2DConditionModel:
             for b in t["blocks"]:
                 C = b["wq2"].shape[0]
                 kv = ops.gemm(e16, b["wkv2"]).view(B, L, 2, heads, C // heads)
-                per.append((kv, ops.transpose_v(kv[:, :, 1])))         # K view + V^T (both step-invariant)
+                per.append(kv)                                          # K | V of the context (step-invariant)
             ctx.append(per)
         self._ctx_key, self._ctx = key, ctx
         return ctx

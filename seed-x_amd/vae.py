@@ -10,8 +10,8 @@ Design: NHWC end to end, fp32 residual stream with 16-bit MFMA operands (bf16 ha
 overflow that forces the reference into fp32 does not arise; fp16 operands are accepted but inherit that risk with real
 weights). 3×3 convolutions = the implicit-GEMM kernel (nearest-2× upsample fused into the conv's gather), GroupNorm+SiLU
 kernels feed it 16-bit operands. The mid block's single 512-wide attention head over (H/8)·(W/8) pixels does not fit the
-flash kernel (head_dim ≤ 128): scores go through the GEMM per image ([HW, HW] fp32, 1 GiB at 1024 px), a row-softmax kernel
-emits 16-bit probabilities, V^T comes straight out of a GEMM with swapped operands (W_v · X^T), and V's bias is added after
+flash kernel (head_dim ≤ 128): scores go through the GEMM in blocks of 2048 query rows ([2048, HW] fp32 = 128 MB at
+1024 px instead of the 1-GiB full matrix), a row-softmax kernel emits 16-bit probabilities, V^T comes straight out of a GEMM with swapped operands (W_v · X^T), and V's bias is added after
 P·V (softmax rows sum to 1). Images are decoded one at a time: at 1024 px one image already gives every launch ≥ 4096
 tiles, and it keeps the operand descriptors under 2 GiB.
 
@@ -301,18 +301,24 @@ class AutoencoderKL:
         sc = ops.gemm(raw.view(-1, Ci), r["ws"], bias=r["bs"], out_dtype=torch.float32) if "ws" in r else x.view(-1, Ci)
         return ops.conv3x3(h.view(1, H, W, Co), r["w2"], bias=r["b2"], residual=sc, out_dtype=torch.float32)
 
-    def _mid_attention(self, m, x):
-        """Attention(heads=1, dim_head=C, residual_connection=True) over the HW pixels of ONE image. x: fp32 [1, HW, C]."""
+    def _mid_attention(self, m, x, q_chunk=2048):
+        """Attention(heads=1, dim_head=C, residual_connection=True) over the HW pixels of ONE image. x: fp32 [1, HW, C].
+        The single head is C = 512 wide — beyond the flash kernel's 128 — so scores go through the GEMM kernel, but in
+        blocks of ``q_chunk`` query rows: the fp32 score block is q_chunk x HW (128 MB at 16 384 pixels) instead of the
+        1-GiB full matrix, and each block's softmax / P·V run while it is still cache-warm."""
         dt = self.dtype
         _, HW, C = x.shape
         assert HW % 64 == 0, "latent H·W must be a multiple of 64 (it is the K of the P·V GEMM)"
         t = ops.groupnorm(x, m["gn"][0], m["gn"][1], self.config.norm_num_groups, EPS, False, dt).view(HW, C)
         q, k = ops.gemm(t, m["wq"], bias=m["bq"]), ops.gemm(t, m["wk"], bias=m["bk"])
-        scores = ops.gemm(q, k, out_dtype=torch.float32)                             # [HW, HW] = q · k^T
-        p = ops.softmax_rows(scores, 1.0 / math.sqrt(C), dt)
-        del scores
         vt = ops.gemm(m["wv"], t)                                                    # [C, HW] = W_v · X^T = (X · W_v^T)^T
-        o = ops.gemm(p, vt, bias=m["bv"])                                            # P · V + b_v  (rows of P sum to 1)
+        o = torch.empty((HW, C), dtype=dt, device=x.device)
+        scale = 1.0 / math.sqrt(C)
+        for q0 in range(0, HW, q_chunk):
+            q1 = min(HW, q0 + q_chunk)
+            scores = ops.gemm(q[q0:q1], k, out_dtype=torch.float32)                  # [rows, HW] = q · k^T
+            p = ops.softmax_rows(scores, scale, dt)
+            ops.gemm(p, vt, bias=m["bv"], out=o[q0:q1])                              # P · V + b_v  (rows of P sum to 1)
         return ops.gemm(o, m["wo"], bias=m["bo"], residual=x.view(HW, C), out_dtype=torch.float32).view(1, HW, C)
 
     def _decode_one(self, z_nchw):

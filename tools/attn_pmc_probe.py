@@ -12,7 +12,6 @@ for B, H, S, D in [(16, 10, 4096, 64), (16, 20, 1024, 64)]:
     q = torch.randn(B, S, H, D, device=dev).to(dt)
     k = torch.randn(B, S, H, D, device=dev).to(dt)
     v = torch.randn(B, S, H, D, device=dev).to(dt)
-    vt = ops.transpose_v(v)
     for _ in range(4):
-        ops.attention(q, k, v, D ** -0.5, causal=False, vt=vt)
+        ops.attention(q, k, v, D ** -0.5, causal=False)
 torch.cuda.synchronize()

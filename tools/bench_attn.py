@@ -18,8 +18,7 @@ def main():
         q = torch.randn(B, S, H, D, device=dev).to(dt)
         k = torch.randn(B, Skv, H, D, device=dev).to(dt)
         v = torch.randn(B, Skv, H, D, device=dev).to(dt)
-        vt = ops.transpose_v(v)
-        t = timeit(lambda: ops.attention(q, k, v, D ** -0.5, causal=causal, vt=vt), iters=20)
+        t = timeit(lambda: ops.attention(q, k, v, D ** -0.5, causal=causal), iters=20)
         fl = 4.0 * B * H * S * Skv * D * (0.5 if causal else 1.0)
         print("%-14s B%2d H%2d S%5d D%3d causal%d: %8.1f us  %6.0f TF" % (name, B, H, S, D, causal, t * 1e6, fl / t / 1e12), flush=True)
 
