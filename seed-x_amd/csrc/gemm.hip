@@ -51,6 +51,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const GemmP p) {
   static_assert(NW == 4 || NW == 8, "4 or 8 waves per block");
   constexpr int TM = BM / WM, TN = BN / WN;       // wave tile
   constexpr int FM = TM / 16, FN = TN / 16;       // 16x16 fragments per wave along m / n
+  constexpr bool kGlu = (FN % 2 == 0);            // GLU pairs fragments (i, i+1): tiles with an odd FN (256x320, 128x80) never run it,
+                                                  // so their epilogue carries none of its code or registers
   constexpr int BNP = (BN + 8 * NW - 1) / (8 * NW) * (8 * NW);  // W rows staged per tile (every wave issues the same count)
   constexpr int A_PER_WAVE = BM / (8 * NW);       // 1-KiB DMA slots (8 rows x 128 B) per wave per k-tile
   constexpr int B_PER_WAVE = BNP / (8 * NW);
@@ -209,8 +211,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const GemmP p) {
   for (int i = 0; i < FN; ++i) {
     const int nb = n0 + wn * TN + i * 16;
     ncol[i] = nb + lq;
-    nout[i] = p.glu ? (nb >> 1) + lq : ncol[i];
-    nok[i] = ncol[i] < p.N && nout[i] < p.n_valid && !(p.glu && (i & 1));
+    nout[i] = (kGlu && p.glu) ? (nb >> 1) + lq : ncol[i];
+    nok[i] = ncol[i] < p.N && nout[i] < p.n_valid && !((kGlu && p.glu) && (i & 1));
     if (ncol[i] >= p.N) ncol[i] = p.N - 4;
     if (nout[i] + 4 > p.ldc) nout[i] = 0;  // clamped lanes never store
     bv[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
@@ -219,7 +221,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const GemmP p) {
 #pragma unroll
     for (int i = 0; i < FN; ++i) bv[i] = *(const f32x4_t*)(p.bias + ncol[i]);
   }
-  const bool wide = p.out_dtype != SX_F32 && !p.glu && (p.ldc & 7) == 0 && (((size_t)p.C) & 15) == 0;
+  const bool wide = p.out_dtype != SX_F32 && !(kGlu && p.glu) && (p.ldc & 7) == 0 && (((size_t)p.C) & 15) == 0;
   bool pair_ok[(FN + 1) / 2];
 #pragma unroll
   for (int i = 0; i < (FN + 1) / 2; ++i) {
@@ -289,7 +291,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const GemmP p) {
 #pragma unroll
     for (int i = 0; i < FN; ++i) {
       if (wide && pair_ok[i >> 1]) continue;  // stored by the 16-B path above
-      if (p.glu) {
+      if ((kGlu && p.glu)) {
         if (i & 1) continue;
         const f32x4_t g = v[(i + 1) < FN ? (i + 1) : i];
         if (p.act == SX_ACT_GELU) {   // GEGLU (SDXL feed-forward): packed-fp32 GELU, two gates per VALU issue

@@ -378,8 +378,9 @@ static int groupnorm_impl(const float* x, const float* x2, int C1, void* y, void
   const int T = (np % 320 == 0) ? 320 : ((np % 160 == 0) ? 160 : 256);
   SX_CHECK((np + T - 1) / T <= GN_MAX_SLOTS2, "sx_groupnorm: C=%d too large", C);
   if (phase != 2) {
-    // zero the fp64 accumulators with a KERNEL node, not hipMemsetAsync: under hipGraph replay a memset node was observed
-    // to race with the neighbouring kernel nodes (NaN statistics whenever the replay started on an idle GPU)
+    // zero the fp64 accumulators with a KERNEL node, not hipMemsetAsync: under hipGraph replay the memset node was not
+    // ordered against the neighbouring kernel nodes — the chain after it ran concurrently with its producers (15.7 ms per
+    // 250-ms UNet step "faster", reading stale activations; NaN statistics whenever a replay started on an idle GPU)
     hipLaunchKernelGGL(gn_zero_kernel, dim3((2 * B * groups + 255) / 256), dim3(256), 0, st, stats, 2 * B * groups);
     SX_HIP_LAUNCH_CHECK();
     // stats: ~512 blocks in total — every block ends with 2*groups fp64 atomics on the same B*groups*2 words, so the

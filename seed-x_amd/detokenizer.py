@@ -186,6 +186,8 @@ class _DenoiseLoop:
         self.comm = comm or Comm()
         self._graph_key, self._graph, self._state = None, None, None
         self._ctx_static = None
+        self.chains = 2                      # concurrent kernel chains per denoise step (1 = one serial chain)
+        self._side = None
 
     def run(self, mode, latents_nchw, prompt_embeds, pooled, time_ids, scheduler, num_steps, guidance_scale,
             image_guidance_scale=1.5, image_latents_nchw=None, trace=None):
@@ -208,7 +210,7 @@ class _DenoiseLoop:
         ts_dev = scheduler.timesteps.to(dev)
         sig_dev = scheduler.sigmas.to(dev)
         key = (mode, G, H, W, num_steps, float(guidance_scale), float(image_guidance_scale), tuple(prompt_embeds.shape),
-               tuple(pooled.shape), tuple(time_ids.shape), unet.dtype, str(dev))
+               tuple(pooled.shape), tuple(time_ids.shape), unet.dtype, str(dev), self.chains)
         if self._state is None or self._graph_key != key:
             self._state = dict(lat=torch.empty((G, HW, Cl), dtype=torch.float32, device=dev),
                                scaled=torch.zeros((NB, HW, cin), dtype=torch.float32, device=dev),
@@ -244,9 +246,37 @@ class _DenoiseLoop:
         else:
             self._ctx_static = ctx
 
+        nloc = hi - lo
+        chains = self.chains if (nloc % self.chains == 0 and nloc >= 2 * self.chains and unet.comm.world == 1) else 1
+        if chains > 1 and self._side is None:
+            self._side = [torch.cuda.Stream() for _ in range(chains - 1)]
+
         def step_body():
-            temb = unet.time_embeddings(S["ts"], S["step"], S["pooled"][lo:hi], S["tid"][lo:hi], hi - lo)
-            eps = unet.forward_nhwc(S["scaled"][lo:hi], temb, ctx, hi - lo, H, W)
+            temb = unet.time_embeddings(S["ts"], S["step"], S["pooled"][lo:hi], S["tid"][lo:hi], nloc)
+            if chains == 1:
+                eps = unet.forward_nhwc(S["scaled"][lo:hi], temb, ctx, nloc, H, W)
+            else:
+                # the samples of a UNet batch are independent: run them as `chains` concurrent kernel chains (forked HIP
+                # streams, captured as parallel branches of the step's graph). A chain's memory-bound kernels and kernel
+                # tails then fill under the other chain's MFMA-bound GEMMs instead of serialising behind them.
+                per = nloc // chains
+                eps = torch.empty((nloc, H * W, unet.cfg["out_channels"]), dtype=torch.float32, device=dev)
+                main = torch.cuda.current_stream()
+                fork = torch.cuda.Event()
+                fork.record(main)
+                parts = []
+                for c in range(chains):
+                    sl = slice(lo + c * per, lo + (c + 1) * per)
+                    cctx = [[kv[c * per:(c + 1) * per] for kv in per_t] for per_t in ctx]
+                    st = main if c == 0 else self._side[c - 1]
+                    if c:
+                        st.wait_event(fork)
+                    with torch.cuda.stream(st):
+                        e = unet.forward_nhwc(S["scaled"][sl], temb[c * per:(c + 1) * per], cctx, per, H, W)
+                        ops.copy2d(e.view(-1, e.shape[-1]), eps[c * per:(c + 1) * per].view(-1, e.shape[-1]), 0)
+                        parts.append(e)
+                for st in self._side[:chains - 1]:
+                    main.wait_stream(st)
             if cfgp:
                 eps = comm.all_gather(eps).reshape(NB, HW, -1)                    # [nb, G, HW, C] → [branch][generation]
             ops.cfg_euler_step(eps, S["lat"], S["scaled"], S["sig"], S["step"], nb, Cl, cin, guidance_scale,
