@@ -6,7 +6,7 @@ On the GPU box:
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pf -- python bench.py --steps 1 --warmup 0 \
       --no-graph --no-cpu-baseline --no-roofline
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/pw -- python bench.py --steps 1 --warmup 0 ...
-  python tools/bench_pmc_traffic.py /tmp/pf /tmp/pw <batch> > profiles/r1_bench_pmc_traffic.json
+  python tools/bench_pmc_traffic.py /tmp/pf /tmp/pw <batch> r2 > profiles/r2_bench_pmc_traffic.json
 
 Corrections per MI355X_MICROARCH.md §HBM: both counters are in KiB; FETCH_SIZE reports half of the bytes of wide coalesced
 reads (x2 here); WRITE_SIZE is uncalibrated (as is). Bytes are L2-miss traffic towards Infinity Cache / HBM."""
@@ -31,7 +31,8 @@ def main():
     nw, write = family_sum(sys.argv[2], "WRITE_SIZE")
     assert nf > 0 and nf == nw, (nf, nw)
     fb, wb = 2 * 1024 * fetch, 1024 * write
-    print(json.dumps({"kernel": "sxk_gemm::gemm_kernel<*>", "batch_per_gpu": int(sys.argv[3]), "launches": nf,
+    print(json.dumps({"kernel": "sxk_gemm::gemm_kernel<*>", "kernels": sys.argv[4] if len(sys.argv) > 4 else "r1",
+                      "batch_per_gpu": int(sys.argv[3]), "launches": nf,
                       "fetch_bytes_per_launch": fb / nf, "write_bytes_per_launch": wb / nf,
                       "traffic_bytes_per_launch": (fb + wb) / nf,
                       "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over one eager bench step; "
