@@ -399,9 +399,14 @@ def gemm_roofline(w):
             rec.append((2.0 * a.M * a.N * a.K, s, e, byt))
             return r
 
-    graphs = [m for m in (getattr(w, "agent", None), getattr(getattr(w, "adapter", None), "_loop", None)) if m is not None]
+    loop = getattr(getattr(w, "adapter", None), "_loop", None)
+    graphs = [m for m in (getattr(w, "agent", None), loop) if m is not None]
     for m in graphs:
         m.use_graph = False
+    chains = getattr(loop, "chains", 1)
+    if loop is not None:
+        loop.chains = 1          # ONE kernel chain on ONE stream: an event pair then brackets exactly its own launch (with the
+                                 # two concurrent chains of the timed step it would also contain the other chain's kernels)
     lib.sx_gemm = Hook()
     try:
         w.step(1)
@@ -410,6 +415,8 @@ def gemm_roofline(w):
         lib.sx_gemm = real
         for m in graphs:
             m.use_graph = True
+        if loop is not None:
+            loop.chains = chains
     ms = [s.elapsed_time(e) for _, s, e, _ in rec]
     fl = sum(r_[0] for r_ in rec)
     alg_bytes = sum(r_[3] for r_ in rec)
@@ -524,6 +531,8 @@ def parse_args(argv=None):
     ap.add_argument("--batch", type=int, default=None,
                     help="independent generations processed together per GPU per step (default 16; config 5: 4; 1 = latency mode)")
     ap.add_argument("--kv-reuse", type=int, default=1, help="config 5: keep the KV cache across turns (0 = re-prefill like the reference)")
+    ap.add_argument("--chains", type=int, default=2, help="concurrent UNet kernel chains per denoise step (1 = one serial chain; "
+                    "use 1 under rocprofv3 so per-kernel durations do not contain the other chain)")
     ap.add_argument("--no-vae", action="store_true", help="stop at the denoised latents (no VAE decode)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -557,6 +566,8 @@ def main(argv=None):
     sync = torch.cuda.synchronize if gpu else (lambda: None)
     with torch.no_grad():
         w = (StubWorkload if a.stub else WORKLOADS[a.config])(a, dev, dtype)
+        if gpu and getattr(getattr(w, "adapter", None), "_loop", None) is not None:
+            w.adapter._loop.chains = a.chains
         if a.no_graph and gpu:
             for m in (getattr(w, "agent", None), getattr(getattr(w, "adapter", None), "_loop", None)):
                 if m is not None:

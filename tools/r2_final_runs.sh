@@ -10,8 +10,8 @@ for c in 1 2 3 4 5; do python bench.py --config $c --steps 2 --warmup 1 --no-cpu
 python bench.py --config 5 --kv-reuse 0 --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $O/r2_bench_config5_noreuse.json 2>> $O/r2_bench_configs.err
 python bench.py --batch 1 --steps 3 --warmup 1 --no-cpu-baseline > $O/r2_bench_b1.json 2>> $O/r2_bench_configs.err
 cd /tmp && export TMPDIR=/tmp
-B="python $R/bench.py --steps 1 --warmup 0 --no-graph --no-cpu-baseline --no-roofline"
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/r2_ks -- python $R/bench.py --steps 1 --warmup 1 --no-graph --no-cpu-baseline > $O/r2_bench_under_rocprof.log 2>&1
+B="python $R/bench.py --steps 1 --warmup 0 --no-graph --chains 1 --no-cpu-baseline --no-roofline"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/r2_ks -- python $R/bench.py --steps 1 --warmup 0 --no-graph --chains 1 --no-cpu-baseline > $O/r2_bench_under_rocprof.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pf -- $B > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/pw -- $B > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/pm -- $B > /dev/null 2>&1
