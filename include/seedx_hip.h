@@ -82,6 +82,9 @@ int sx_gemm(const sx_gemm_args* args, void* stream);
 /* tuning/test hook: force tile config 0..6 (128x128, 128x80, 64x128, 64x64, 256x256, 256x320, 256x160); -1 = automatic
  * (cost model); 100/101 = 2-D XCD partition off/on; 300+g = g tile-rows per in-XCD traversal group (300 = default) */
 int sx_gemm_force_tile(int cfg);
+/* tuning hook: `buf` = device buffer of 4 x uint64 per workgroup; following sx_gemm launches store s_memtime stamps
+ * {start, first k-tile landed, main loop done, end} per workgroup (tools/gemm_phase_probe.py). NULL switches it off. */
+int sx_gemm_debug_stamps(void* buf);
 /* host-only query (no launch): tile config 0..6 the cost model picks for an M x N x K problem (glu / conv3x3 flags) */
 int sx_gemm_pick_tile(int M, int N, int K, int glu, int conv);
 
@@ -111,7 +114,8 @@ int sx_gemv_force_valu(int on);
 int sx_layernorm(const void* x, int in_dtype, void* y, int out_dtype, const float* gamma, const float* beta,
                  int rows, int cols, float eps, int rms, void* stream);
 
-/* Row softmax y = softmax(scale * x) over the last dim, fp32 in → 16-bit out (probabilities feed the P·V GEMM).
+/* Row softmax y = softmax(scale * x) over the last dim, fp32 in → 16-bit out (probabilities feed the P·V GEMM) or fp32
+ * out (SX_F32, ldy in floats: the fp32-grade VAE mode splits it into bf16 planes).
  * replaces: the softmax inside diffusers Attention [ext] of the VAE decoder's mid block (one 512-wide head over
  * (H/8)·(W/8) pixels — head_dim 512 does not fit the flash kernel, so scores go through sx_gemm; reference call site
  * pipeline_stable_diffusion_xl_t2i_edit.py:973). */
@@ -120,7 +124,8 @@ int sx_softmax_rows(const float* x, int64_t ldx, void* y, int64_t ldy, int rows,
 
 /* GroupNorm(+SiLU) over NHWC activations x[B][HW][C] (fp32 in). replaces diffusers
  * ResnetBlock2D.norm1/norm2 + nonlinearity, Transformer2DModel.norm, conv_norm_out [ext].
- * stats: scratch fp64 [B][groups][2] (zeroed by the call). y: 16-bit normalised output.
+ * stats: scratch fp64 [B][groups][2] (zeroed by the call). y: 16-bit normalised output (SX_F32 is accepted when raw16 is
+ * NULL: the fp32-grade VAE mode).
  * raw16: optional 16-bit un-normalised copy of x (feeds the 1x1 shortcut conv), may be NULL. */
 int sx_groupnorm(const float* x, void* y, void* raw16, int out_dtype, const float* gamma, const float* beta,
                  double* stats, int B, int HW, int C, int groups, float eps, int silu, void* stream);
@@ -234,6 +239,12 @@ int sx_add_i32_n(int32_t* p, int delta, int n, void* stream);
  * Elementwise / layout helpers
  * ------------------------------------------------------------------------------------------------ */
 int sx_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, void* stream);
+/* fp32 x[rows][cols] → bf16 out[rows][3*cols] holding the planes of x = hi + lo (hi = bf16(x), lo = bf16(x - hi)):
+ * role 0 (A operand rows) = [hi | hi | lo], role 1 (W operand rows) = [hi | lo | hi], so that one sx_gemm with K = 3*cols
+ * computes Ah·Wh + Ah·Wl + Al·Wh with fp32 accumulation. cols % 4 == 0. Operand preparation of the VAE's fp32-grade mode:
+ * stands in for the fp32 VAE the reference's pipeline switches to in upcast_vae()
+ * (pipeline_stable_diffusion_xl_t2i_edit.py:509-511, :569-586, :965-977). */
+int sx_split_bf16(const float* x, void* out, int64_t rows, int cols, int role, void* stream);
 /* strided 2-D copy of fp32 rows: dst[r][dst_off + c] = src[r][c]  (channel concat of skip connections) */
 int sx_copy2d_f32(const float* src, int64_t src_ld, float* dst, int64_t dst_ld, int64_t rows, int cols,
                   void* stream);

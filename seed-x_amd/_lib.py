@@ -55,6 +55,7 @@ SIGNATURES = {
     "sx_version": [],
     "sx_gemm": [C.POINTER(GemmArgs), c_vp],
     "sx_gemm_force_tile": [c_i32],
+    "sx_gemm_debug_stamps": [c_vp],
     "sx_gemm_pick_tile": [c_i32, c_i32, c_i32, c_i32, c_i32],
     "sx_gemv": [C.POINTER(GemvArgs), c_vp],
     "sx_gemv_force_valu": [c_i32],
@@ -78,6 +79,7 @@ SIGNATURES = {
     "sx_scatter_rows": [c_vp, c_vp, c_vp, c_i32, c_i32, c_vp],
     "sx_greedy_next": [c_vp, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp],
     "sx_cast": [c_vp, c_i32, c_vp, c_i32, c_i64, c_vp],
+    "sx_split_bf16": [c_vp, c_vp, c_i64, c_i32, c_i32, c_vp],
     "sx_copy2d_f32": [c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_vp],
     "sx_add_f32": [c_vp, c_vp, c_vp, c_i64, c_vp],
     "sx_patchify": [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp],

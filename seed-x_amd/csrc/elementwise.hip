@@ -43,6 +43,32 @@ __global__ void cast_kernel(const void* src, int sdt, void* dst, int ddt, int64_
     st_from_f32(dst, ddt, i, ld_as_f32(src, sdt, i));
 }
 
+// x = hi + lo with hi = bf16(x), lo = bf16(x - hi): 16 mantissa bits in two bf16 MFMA operands. The VAE's fp32-grade mode
+// computes A·W as Ah·Wh + Ah·Wl + Al·Wh in ONE GEMM with a tripled K: A rows are laid out [hi | hi | lo] (role 0), W rows
+// [hi | lo | hi] (role 1). x - hi is exact in fp32, so the only rounding left is lo's own 2^-9 on a 2^-9-sized term.
+__global__ void split_bf16_kernel(const float* x, unsigned short* out, int64_t rows, int n4, int role) {
+  const int64_t total = rows * n4;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int64_t r = i / n4;
+    const int q = (int)(i - r * n4);
+    const f32x4_t v = ((const f32x4_t*)x)[i];
+    unsigned short h[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      h[e] = BF16::from_f32(v[e]);
+      l[e] = BF16::from_f32(v[e] - BF16::to_f32(h[e]));
+    }
+    u32x2_t oh, ol;
+    oh[0] = h[0] | ((unsigned)h[1] << 16); oh[1] = h[2] | ((unsigned)h[3] << 16);
+    ol[0] = l[0] | ((unsigned)l[1] << 16); ol[1] = l[2] | ((unsigned)l[3] << 16);
+    u32x2_t* o = (u32x2_t*)out + r * 3 * n4 + q;
+    o[0] = oh;
+    o[n4] = role ? ol : oh;
+    o[2 * n4] = role ? oh : ol;
+  }
+}
+
 __global__ void copy2d_kernel(const float* src, int64_t sld, float* dst, int64_t dld, int64_t rows, int cols4) {
   const int64_t total = rows * cols4;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -188,6 +214,14 @@ extern "C" int sx_cast(const void* src, int src_dtype, void* dst, int dst_dtype,
   SX_CHECK(src && dst && n >= 0, "sx_cast: bad args");
   if (n == 0) return SX_OK;
   hipLaunchKernelGGL(cast_kernel, grid_for(n, 4), dim3(256), 0, ST, src, src_dtype, dst, dst_dtype, n);
+  SX_HIP_LAUNCH_CHECK();
+  return SX_OK;
+}
+extern "C" int sx_split_bf16(const float* x, void* out, int64_t rows, int cols, int role, void* stream) {
+  SX_CHECK(x && out && rows >= 0 && cols > 0 && cols % 4 == 0, "sx_split_bf16: bad args (cols %% 4 must be 0)");
+  SX_CHECK(role == 0 || role == 1, "sx_split_bf16: role must be 0 (A rows: hi|hi|lo) or 1 (W rows: hi|lo|hi)");
+  if (rows == 0) return SX_OK;
+  hipLaunchKernelGGL(split_bf16_kernel, grid_for(rows * (cols / 4)), dim3(256), 0, ST, x, (unsigned short*)out, rows, cols / 4, role);
   SX_HIP_LAUNCH_CHECK();
   return SX_OK;
 }

@@ -36,6 +36,7 @@ struct GemmP {
   int tiles_m, tiles_n, xm, xn;   // tile grid and its XCD partition (xm x xn == 8, or 0 = linear remap)
   int gm;                         // tile-rows per group of the in-XCD traversal
   unsigned a_bytes, w_bytes;
+  unsigned long long* dbg;        // tuning hook: per-block s_memtime stamps [block][4] = start, first tile landed, main loop done, end
 };
 
 template <int N>
@@ -64,6 +65,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const GemmP p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
+  unsigned long long t_start = 0, t_first = 0, t_main = 0;
+  if (p.dbg) t_start = __builtin_amdgcn_s_memtime();
 
   // Tile → XCD mapping. Block b is observed on XCD b % 8 (performance heuristic only). Each XCD gets a compact
   // (tiles_m/xm) x (tiles_n/xn) rectangle of the tile grid, so its private L2 holds A-panel/xm + W-panel/xn instead of
@@ -181,6 +184,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const GemmP p) {
     if (D >= 2 && kt + 1 < nkt) wait_vmcnt<LOADS*(D - 1)>();
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();  // everyone's share landed AND everyone finished reading ring slot `nxt`
+    if (p.dbg && kt == 0) t_first = __builtin_amdgcn_s_memtime();
     if (kt + D < nkt) stage(nxt, kt + D);
     const unsigned char* sA = smem + cur * STAGE + (wm * TM) * 128;
     const unsigned char* sB = smem + cur * STAGE + A_BYTES + (wn * TN) * 128;
@@ -200,6 +204,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const GemmP p) {
     nxt = (nxt + 1 == NSTAGE) ? 0 : nxt + 1;
   }
 
+  if (p.dbg) t_main = __builtin_amdgcn_s_memtime();
   // ---- fused epilogue: lane holds C[m][n .. n+3], m = ..+(lane&15), n = ..+(lane>>4)*4 ----------
   // Loads are issued unconditionally on clamped addresses and batched per phase (bias once, then per
   // m-fragment: bias2d + residual for all n-fragments) so they overlap instead of serialising on vmcnt(0).
@@ -325,15 +330,25 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const GemmP p) {
       }
     }
   }
+  if (p.dbg) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the tile's stores have been issued and accepted
+    const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+    if (tid == 0) {
+      unsigned long long* d = p.dbg + (size_t)blockIdx.x * 4;
+      d[0] = t_start; d[1] = t_first; d[2] = t_main; d[3] = t_end;
+    }
+  }
 #endif
 }
 
+static unsigned long long* g_dbg = nullptr;   // tuning hook: timestamp buffer for the next launches (sx_gemm_debug_stamps)
 static int g_gm = 0;      // tuning hook: tile-rows per traversal group (0 = default)
 static int g_xcd_2d = 1;  // 2-D XCD tile partition on/off (tuning hook)
 
 template <typename TT, int BM, int BN, int WM, int WN, int NSTAGE>
 int launch_cfg(const GemmP& p0, int a_mode, hipStream_t st) {
   GemmP p = p0;
+  p.dbg = g_dbg;
   p.tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.N + BN - 1) / BN;
   int grid = p.tiles_m * p.tiles_n;
@@ -405,6 +420,11 @@ using namespace sxk_gemm;
 static int g_force_tile = -1;
 extern "C" int sx_gemm_pick_tile(int M, int N, int K, int glu, int conv) {  // host-only: which tile config sx_gemm would use
   return sxk_gemm::pick_tile(M, N, K, glu != 0, conv != 0, -1);
+}
+
+extern "C" int sx_gemm_debug_stamps(void* buf) {   // tuning hook: device buffer of 4 x uint64 per block, or NULL to switch off
+  sxk_gemm::g_dbg = (unsigned long long*)buf;
+  return SX_OK;
 }
 
 extern "C" int sx_gemm_force_tile(int cfg) {  // tuning / test hook: -1 = automatic; 100/101 = 2-D XCD partition off/on

@@ -280,7 +280,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* x, const flo
 // ---- row softmax (VAE mid-block attention: one 512-wide head over 16384 pixels, scores materialised by the GEMM) ---------------
 // y[r][c] = exp(scale·x[r][c] − max_r) / Σ_c …, fp32 in → 16-bit out. Block per row, three streaming passes over the row
 // (64 KB at C = 16384: it stays in L2 between passes), float4 loads, block reductions through LDS.
-template <typename TT>
+template <typename TT, bool F32OUT = false>
 __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* x, long ldx, unsigned short* y, long ldy, int C,
                                                            float scale) {
   __shared__ float red[4];
@@ -310,6 +310,11 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* x, long 
   const float inv = 1.f / (red[0] + red[1] + red[2] + red[3]);
   for (int i = tid; i < n4; i += 256) {
     const float4 v = xr[i];
+    if (F32OUT) {   // ldy counts floats here
+      ((float4*)((float*)y + (size_t)blockIdx.x * ldy))[i] =
+          make_float4(exp2f(v.x * sl2 - m) * inv, exp2f(v.y * sl2 - m) * inv, exp2f(v.z * sl2 - m) * inv, exp2f(v.w * sl2 - m) * inv);
+      continue;
+    }
     u32x2_t o;
     o[0] = pack2<TT>(exp2f(v.x * sl2 - m) * inv, exp2f(v.y * sl2 - m) * inv);
     o[1] = pack2<TT>(exp2f(v.z * sl2 - m) * inv, exp2f(v.w * sl2 - m) * inv);
@@ -369,7 +374,8 @@ static int groupnorm_impl(const float* x, const float* x2, int C1, void* y, void
   SX_CHECK(x && stats, "sx_groupnorm: null pointer");
   SX_CHECK(phase == 1 || (y && gamma && beta), "sx_groupnorm: null pointer");
   SX_CHECK(!x2 || (C1 > 0 && C1 < C && C1 % 4 == 0 && (C - C1) % 4 == 0), "sx_groupnorm2: C1=%d of C=%d", C1, C);
-  SX_CHECK(phase == 1 || out_dtype == SX_F16 || out_dtype == SX_BF16, "sx_groupnorm: output must be 16-bit");
+  SX_CHECK(phase == 1 || out_dtype == SX_F16 || out_dtype == SX_BF16 || (out_dtype == SX_F32 && !raw16),
+           "sx_groupnorm: output must be 16-bit, or fp32 without a raw copy");
   SX_CHECK(groups > 0 && groups <= 64 && C % groups == 0, "sx_groupnorm: C=%d groups=%d", C, groups);
   SX_CHECK(C % 4 == 0 && (C / groups) % 2 == 0, "sx_groupnorm: C %% 4 and (C/groups) %% 2 must be 0 (C=%d)", C);
   SX_CHECK(C / 2 <= 256 * GN_MAX_SLOTS2 && C <= GN_MAX_C, "sx_groupnorm: C=%d too large", C);
@@ -435,9 +441,11 @@ extern "C" int sx_softmax_rows(const float* x, int64_t ldx, void* y, int64_t ldy
   SX_CHECK(x && y, "sx_softmax_rows: null pointer");
   SX_CHECK(rows > 0 && cols > 0 && cols % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0, "sx_softmax_rows: rows=%d cols=%d", rows, cols);
   SX_CHECK(scale > 0.f, "sx_softmax_rows: scale must be positive");
-  SX_CHECK(out_dtype == SX_F16 || out_dtype == SX_BF16, "sx_softmax_rows: output must be 16-bit");
+  SX_CHECK(out_dtype >= SX_F16 && out_dtype <= SX_F32, "sx_softmax_rows: bad output dtype");
   hipStream_t st = (hipStream_t)stream;
-  if (out_dtype == SX_BF16)
+  if (out_dtype == SX_F32)
+    hipLaunchKernelGGL((softmax_rows_kernel<BF16, true>), dim3(rows), dim3(256), 0, st, x, (long)ldx, (unsigned short*)y, (long)ldy, cols, scale);
+  else if (out_dtype == SX_BF16)
     hipLaunchKernelGGL(softmax_rows_kernel<BF16>, dim3(rows), dim3(256), 0, st, x, (long)ldx, (unsigned short*)y, (long)ldy, cols, scale);
   else
     hipLaunchKernelGGL(softmax_rows_kernel<F16>, dim3(rows), dim3(256), 0, st, x, (long)ldx, (unsigned short*)y, (long)ldy, cols, scale);

@@ -204,7 +204,7 @@ def groupnorm(x, gamma, beta, groups, eps, silu, out_dtype, want_raw=False, x2=N
 
 
 def softmax_rows(x, scale, out_dtype):
-    """softmax(scale · x) over the last dim; x fp32 [R, C] (row stride free) → 16-bit [R, C]."""
+    """softmax(scale · x) over the last dim; x fp32 [R, C] (row stride free) → 16-bit (or fp32) [R, C]."""
     lib = _lib.load()
     assert x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
     R, Cc = x.shape
@@ -331,6 +331,18 @@ def cast(x, dtype):
     y = torch.empty(x.shape, dtype=dtype, device=x.device)
     check(lib.sx_cast(_p(x), _DT[x.dtype], _p(y), _DT[dtype], x.numel(), _stream()), "sx_cast")
     return y
+
+
+def split_bf16(x, role="a"):
+    """fp32 [..., C] → bf16 [..., 3C]: the planes of x = hi + lo laid out [hi | hi | lo] (role "a": rows of a GEMM's A
+    operand) or [hi | lo | hi] (role "w": rows of its W operand). One GEMM over K = 3C then yields Ah·Wh + Ah·Wl + Al·Wh
+    with fp32 accumulation — 16 mantissa bits per operand (the VAE's fp32-grade mode)."""
+    lib = _lib.load()
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.shape[-1] % 4 == 0
+    Cc = x.shape[-1]
+    out = torch.empty(x.shape[:-1] + (3 * Cc,), dtype=torch.bfloat16, device=x.device)
+    check(lib.sx_split_bf16(_p(x), _p(out), x.numel() // Cc, Cc, {"a": 0, "w": 1}[role], _stream()), "sx_split_bf16")
+    return out
 
 
 def copy2d(src, dst, dst_col_off=0):

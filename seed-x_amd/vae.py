@@ -6,9 +6,17 @@ Stand-in for ``diffusers.AutoencoderKL`` [ext, diffusers 0.25.0] as the referenc
 constructor config names, ``from_pretrained`` directory layout (``config.json`` + ``diffusion_pytorch_model.*``), state-dict
 keys, ``.config.scaling_factor`` / ``.config.force_upcast`` / ``.dtype`` and ``decode()`` signature.
 
-Design: NHWC end to end, fp32 residual stream with 16-bit MFMA operands (bf16 has fp32's exponent range, so the fp16
-overflow that forces the reference into fp32 does not arise; fp16 operands are accepted but inherit that risk with real
-weights). 3×3 convolutions = the implicit-GEMM kernel (nearest-2× upsample fused into the conv's gather), GroupNorm+SiLU
+Design: NHWC end to end, fp32 residual stream, fp32 accumulation, MFMA operands in one of two precisions:
+
+* ``fp32`` — the reference's pipeline upcasts an fp16 VAE with ``force_upcast`` to fp32 around every encode / decode
+  (:509-511, :967-970). There is no fp32 MFMA worth using, so fp32-grade products are built from bf16 ones: every operand
+  is carried as two bf16 planes x = hi + lo (sx_split_bf16) and A·W = Ah·Wh + Ah·Wl + Al·Wh comes out of ONE launch of the
+  same GEMM / implicit-conv kernel over a tripled K: activation rows are laid out [hi | hi | lo] per pixel, weight rows
+  [hi | lo | hi] per tap, all three products accumulate in the fp32 MFMA accumulators. 16 mantissa bits per operand, fp32's
+  exponent range (the fp16 overflow that forces the reference into fp32 cannot occur). Selected exactly when the reference would upcast
+  (dtype fp16 and ``config.force_upcast``), or by ``.to(dtype=torch.float32)``, or ``precision="fp32"``.
+* ``fast`` — single 16-bit operands of ``dtype`` (what a bf16 VAE is in the reference; ``precision="fast"`` forces it for
+  fp16 too, ≈1.3e-3 rel-L2 from the fp32 result at 1024 px with fp16 operands). 3×3 convolutions = the implicit-GEMM kernel (nearest-2× upsample fused into the conv's gather), GroupNorm+SiLU
 kernels feed it 16-bit operands. The mid block's single 512-wide attention head over (H/8)·(W/8) pixels does not fit the
 flash kernel (head_dim ≤ 128): scores go through the GEMM in blocks of 2048 query rows ([2048, HW] fp32 = 128 MB at
 1024 px instead of the 1-GiB full matrix), a row-softmax kernel emits 16-bit probabilities, V^T comes straight out of a GEMM with swapped operands (W_v · X^T), and V's bias is added after
@@ -44,8 +52,20 @@ class AutoencoderKL:
                                       latent_channels=latent_channels, norm_num_groups=norm_num_groups,
                                       scaling_factor=scaling_factor, force_upcast=force_upcast)
         self.device, self.dtype = None, torch.bfloat16
+        self.precision = "auto"              # "auto": what the reference does for this dtype / force_upcast; "fast"; "fp32"
         self._sd, self._P = None, None
         self.has_encoder = False
+
+    @property
+    def split(self):
+        """True when operands are carried as two bf16 planes (the fp32-grade mode)."""
+        if self.precision == "auto":
+            return self.dtype == torch.float32 or (self.dtype == torch.float16 and bool(self.config.force_upcast))
+        return self.precision == "fp32"
+
+    @property
+    def operand_dtype(self):
+        return torch.bfloat16 if (self.split or self.dtype == torch.float32) else self.dtype
 
     # ---- reference-compatible plumbing ---------------------------------------------------------------------------------
     @classmethod
@@ -163,18 +183,20 @@ class AutoencoderKL:
         self._sd, self._P = sd, None
         return missing, []
 
-    def to(self, device=None, dtype=None):
-        old = (self.device, self.dtype)
+    def to(self, device=None, dtype=None, precision=None):
+        """dtype fp16 / bf16 / fp32 as in the reference (fp32 = its upcast_vae()); ``precision`` overrides the operand mode."""
+        old = (self.device, self.operand_dtype, self.split)
         if device is not None:
             self.device = torch.device(device)
         if dtype is not None:
-            if dtype == torch.float32:          # the reference's upcast_vae(): our accumulation/residual path already is fp32
-                dtype = torch.bfloat16
-            assert dtype in (torch.float16, torch.bfloat16)
+            assert dtype in (torch.float16, torch.bfloat16, torch.float32)
             self.dtype = dtype
-        if (self.device, self.dtype) != old:
+        if precision is not None:
+            assert precision in ("auto", "fast", "fp32")
+            self.precision = precision
+        if (self.device, self.operand_dtype, self.split) != old:
             if self._P is not None and self._sd is None:
-                raise RuntimeError("weights were already packed for %s/%s; reload the state dict to move them" % old)
+                raise RuntimeError("weights were already packed for %s/%s (split=%s); reload the state dict to change them" % old)
             self._P = None
         return self
 
@@ -192,18 +214,38 @@ class AutoencoderKL:
             raise RuntimeError("AutoencoderKL: load_state_dict() first")
         if self.device is None or self.device.type != "cuda":
             raise RuntimeError("AutoencoderKL runs on the GPU only")
-        sd, dev, dt, c = self._sd, self.device, self.dtype, self.config
+        sd, dev, dt, c = self._sd, self.device, self.operand_dtype, self.config
+        split = self.split
 
         def f32(k):
             return sd[k].detach().to(dev, torch.float32).contiguous()
 
-        def lin16(k):
-            w = sd[k].detach().to(dev, dt)
-            return w.reshape(w.shape[0], -1).contiguous()
+        def opnd(w32, taps=1, role="w"):
+            """fp32 [N, taps*C] on the device → MFMA operand rows: 16-bit as is, or (fp32-grade mode) bf16 [N, taps*3C] with
+            the planes [hi | lo | hi] per tap (role "w"; "a" = [hi | hi | lo] for a weight used as the GEMM's A operand)."""
+            if not split:
+                return w32.to(dt).contiguous()
+            w3 = w32.reshape(w32.shape[0], taps, -1)
+            hi = w3.to(torch.bfloat16)
+            lo = (w3 - hi.float()).to(torch.bfloat16)
+            planes = [hi, lo, hi] if role == "w" else [hi, hi, lo]
+            return torch.cat(planes, dim=2).reshape(w32.shape[0], -1).contiguous()
 
-        def conv16(k):  # [Co,Ci,3,3] → [Co, 9*Ci] with (ky,kx,ci) order
-            w = sd[k].detach().to(dev, dt)
-            return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous()
+        def lin16(k, role="w"):
+            w = f32(k)
+            return opnd(w.reshape(w.shape[0], -1), role=role)
+
+        def conv32(k):  # [Co,Ci,3,3] → fp32 [Co, 9*Ci] with (ky,kx,ci) order
+            w = f32(k)
+            return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1)
+
+        def conv16(k):
+            return opnd(conv32(k), taps=9)
+
+        def padded(w32, rows, cols, taps=1):
+            wp = torch.zeros(rows, cols, dtype=torch.float32, device=dev)
+            wp[:w32.shape[0], :w32.shape[1]] = w32
+            return opnd(wp, taps=taps)
 
         def resnet(n):
             r = dict(n1=(f32(n + ".norm1.weight"), f32(n + ".norm1.bias")), w1=conv16(n + ".conv1.weight"),
@@ -217,22 +259,17 @@ class AutoencoderKL:
         assert lc == 4, "post_quant_conv / conv_in packing assumes 4 latent channels"
         top = boc[-1]
         P = {}
-        wpq = torch.zeros(16, 64, dtype=dt, device=dev)                     # 1x1 conv as a K-padded GEMM
-        wpq[:lc, :lc] = sd["post_quant_conv.weight"].detach().to(dev, dt).reshape(lc, lc)
         bpq = torch.zeros(16, dtype=torch.float32, device=dev)
         bpq[:lc] = f32("post_quant_conv.bias")
-        P["pq"] = (wpq, bpq)
+        P["pq"] = (padded(f32("post_quant_conv.weight").reshape(lc, lc), 16, 64), bpq)   # 1x1 conv as a K-padded GEMM
         self.cin_kpad = (9 * lc + 63) // 64 * 64
-        w = sd["decoder.conv_in.weight"].detach().to(dev, dt).permute(0, 2, 3, 1).reshape(top, -1)
-        wp = torch.zeros(top, self.cin_kpad, dtype=dt, device=dev)
-        wp[:, :w.shape[1]] = w
-        P["conv_in"] = (wp, f32("decoder.conv_in.bias"))
+        P["conv_in"] = (padded(conv32("decoder.conv_in.weight"), top, self.cin_kpad), f32("decoder.conv_in.bias"))
         a = "decoder.mid_block.attentions.0."
         P["mid"] = dict(r0=resnet("decoder.mid_block.resnets.0"), r1=resnet("decoder.mid_block.resnets.1"),
                         gn=(f32(a + "group_norm.weight"), f32(a + "group_norm.bias")),
                         wq=lin16(a + "to_q.weight"), bq=f32(a + "to_q.bias"),
                         wk=lin16(a + "to_k.weight"), bk=f32(a + "to_k.bias"),
-                        wv=lin16(a + "to_v.weight"), bv=f32(a + "to_v.bias"),
+                        wv=lin16(a + "to_v.weight", role="a"), bv=f32(a + "to_v.bias"),
                         wo=lin16(a + "to_out.0.weight"), bo=f32(a + "to_out.0.bias"))
         P["up"] = []
         for i in range(len(boc)):
@@ -242,20 +279,15 @@ class AutoencoderKL:
                 blk["up"] = (conv16(n + ".weight"), f32(n + ".bias"))
             P["up"].append(blk)
         P["norm_out"] = (f32("decoder.conv_norm_out.weight"), f32("decoder.conv_norm_out.bias"))
-        wo = conv16("decoder.conv_out.weight")
-        wop = torch.zeros(16, wo.shape[1], dtype=dt, device=dev)
-        wop[:wo.shape[0]] = wo
+        wo = conv32("decoder.conv_out.weight")
         bo = torch.zeros(16, dtype=torch.float32, device=dev)
         bo[:wo.shape[0]] = f32("decoder.conv_out.bias")
-        P["conv_out"] = (wop, bo)
+        P["conv_out"] = (padded(wo, 16, wo.shape[1], taps=9), bo)
         if self.has_encoder:
             E = {}
             ci = c.in_channels
             self.enc_kpad = (9 * ci + 63) // 64 * 64
-            w = sd["encoder.conv_in.weight"].detach().to(dev, dt).permute(0, 2, 3, 1).reshape(boc[0], -1)
-            wp = torch.zeros(boc[0], self.enc_kpad, dtype=dt, device=dev)
-            wp[:, :w.shape[1]] = w
-            E["conv_in"] = (wp, f32("encoder.conv_in.bias"))
+            E["conv_in"] = (padded(conv32("encoder.conv_in.weight"), boc[0], self.enc_kpad), f32("encoder.conv_in.bias"))
             E["down"] = []
             for i in range(len(boc)):
                 blk = dict(res=[resnet(f"encoder.down_blocks.{i}.resnets.{j}") for j in range(c.layers_per_block)], down=None)
@@ -268,67 +300,97 @@ class AutoencoderKL:
                             gn=(f32(a + "group_norm.weight"), f32(a + "group_norm.bias")),
                             wq=lin16(a + "to_q.weight"), bq=f32(a + "to_q.bias"),
                             wk=lin16(a + "to_k.weight"), bk=f32(a + "to_k.bias"),
-                            wv=lin16(a + "to_v.weight"), bv=f32(a + "to_v.bias"),
+                            wv=lin16(a + "to_v.weight", role="a"), bv=f32(a + "to_v.bias"),
                             wo=lin16(a + "to_out.0.weight"), bo=f32(a + "to_out.0.bias"))
             E["norm_out"] = (f32("encoder.conv_norm_out.weight"), f32("encoder.conv_norm_out.bias"))
-            wo = conv16("encoder.conv_out.weight")                                  # [2*lc, 9*top]
-            wop = torch.zeros(16, wo.shape[1], dtype=dt, device=dev)
-            wop[:wo.shape[0]] = wo
+            wo = conv32("encoder.conv_out.weight")                                  # [2*lc, 9*top]
             bo = torch.zeros(16, dtype=torch.float32, device=dev)
             bo[:wo.shape[0]] = f32("encoder.conv_out.bias")
-            E["conv_out"] = (wop, bo)
-            wq = torch.zeros(16, 64, dtype=dt, device=dev)                          # quant_conv 1x1 as a K-padded GEMM
-            wq[:2 * lc, :2 * lc] = sd["quant_conv.weight"].detach().to(dev, dt).reshape(2 * lc, 2 * lc)
+            E["conv_out"] = (padded(wo, 16, wo.shape[1], taps=9), bo)
             bq = torch.zeros(16, dtype=torch.float32, device=dev)
             bq[:2 * lc] = f32("quant_conv.bias")
-            E["quant"] = (wq, bq)
+            E["quant"] = (padded(f32("quant_conv.weight").reshape(2 * lc, 2 * lc), 16, 64), bq)   # 1x1 as a K-padded GEMM
             P["enc"] = E
         self._P, self._sd = P, None
         return P
 
     # ---- building blocks -------------------------------------------------------------------------------------------------
+    # Every GEMM / conv below is ops.gemm / ops.conv3x3 with fp32 output; in the fp32-grade mode its operands simply carry
+    # three bf16 planes per channel (K is tripled), see ops.split_bf16.
+    def _A(self, x32, role="a"):
+        """fp32 activation [..., C] → MFMA operand ([..., C] 16-bit, or [..., 3C] bf16 planes)."""
+        return ops.split_bf16(x32, role) if self.split else ops.cast(x32, self.operand_dtype)
+
+    def _gn(self, x, gb, silu, want_raw=False):
+        """GroupNorm(+SiLU) of the fp32 stream → operand (and optionally the un-normalised x as an operand)."""
+        G = self.config.norm_num_groups
+        if not self.split:
+            return ops.groupnorm(x, gb[0], gb[1], G, EPS, silu, self.operand_dtype, want_raw=want_raw)
+        y = ops.split_bf16(ops.groupnorm(x, gb[0], gb[1], G, EPS, silu, torch.float32))
+        return (y, ops.split_bf16(x)) if want_raw else y
+
     def _resnet(self, r, x, H, W):
         """x: fp32 [1, HW, Ci] → fp32 [1, HW, Co]  (ResnetBlock2D with temb=None [ext])."""
-        G, dt = self.config.norm_num_groups, self.dtype
+        f32 = torch.float32
         Ci = x.shape[-1]
         if "ws" in r:
-            h, raw = ops.groupnorm(x, r["n1"][0], r["n1"][1], G, EPS, True, dt, want_raw=True)
+            h, raw = self._gn(x, r["n1"], True, want_raw=True)
         else:
-            h = ops.groupnorm(x, r["n1"][0], r["n1"][1], G, EPS, True, dt)
-        h = ops.conv3x3(h.view(1, H, W, Ci), r["w1"], bias=r["b1"], out_dtype=torch.float32)
-        Co = h.shape[-1]
-        h = ops.groupnorm(h, r["n2"][0], r["n2"][1], G, EPS, True, dt)
-        sc = ops.gemm(raw.view(-1, Ci), r["ws"], bias=r["bs"], out_dtype=torch.float32) if "ws" in r else x.view(-1, Ci)
-        return ops.conv3x3(h.view(1, H, W, Co), r["w2"], bias=r["b2"], residual=sc, out_dtype=torch.float32)
+            h = self._gn(x, r["n1"], True)
+        h = ops.conv3x3(h.view(1, H, W, -1), r["w1"], bias=r["b1"], out_dtype=f32)
+        h = self._gn(h, r["n2"], True)
+        sc = ops.gemm(raw.view(H * W, -1), r["ws"], bias=r["bs"], out_dtype=f32) if "ws" in r else x.view(-1, Ci)
+        return ops.conv3x3(h.view(1, H, W, -1), r["w2"], bias=r["b2"], residual=sc, out_dtype=f32)
 
     def _mid_attention(self, m, x, q_chunk=2048):
         """Attention(heads=1, dim_head=C, residual_connection=True) over the HW pixels of ONE image. x: fp32 [1, HW, C].
         The single head is C = 512 wide — beyond the flash kernel's 128 — so scores go through the GEMM kernel, but in
         blocks of ``q_chunk`` query rows: the fp32 score block is q_chunk x HW (128 MB at 16 384 pixels) instead of the
         1-GiB full matrix, and each block's softmax / P·V run while it is still cache-warm."""
-        dt = self.dtype
+        dt, split, f32 = self.operand_dtype, self.split, torch.float32
         _, HW, C = x.shape
         assert HW % 64 == 0, "latent H·W must be a multiple of 64 (it is the K of the P·V GEMM)"
-        t = ops.groupnorm(x, m["gn"][0], m["gn"][1], self.config.norm_num_groups, EPS, False, dt).view(HW, C)
-        q, k = ops.gemm(t, m["wq"], bias=m["bq"]), ops.gemm(t, m["wk"], bias=m["bk"])
-        vt = ops.gemm(m["wv"], t)                                                    # [C, HW] = W_v · X^T = (X · W_v^T)^T
-        o = torch.empty((HW, C), dtype=dt, device=x.device)
+        G = self.config.norm_num_groups
+        if split:
+            t32 = ops.groupnorm(x, m["gn"][0], m["gn"][1], G, EPS, False, f32).view(HW, C)
+            t = ops.split_bf16(t32)
+            q = ops.split_bf16(ops.gemm(t, m["wq"], bias=m["bq"], out_dtype=f32))
+            k = ops.split_bf16(ops.gemm(t, m["wk"], bias=m["bk"], out_dtype=f32), "w")
+            vt = ops.split_bf16(ops.gemm(m["wv"], ops.split_bf16(t32, "w"), out_dtype=f32), "w")   # [C, 3·HW]
+            o = torch.empty((HW, C), dtype=f32, device=x.device)
+        else:
+            t = ops.groupnorm(x, m["gn"][0], m["gn"][1], G, EPS, False, dt).view(HW, C)
+            q, k = ops.gemm(t, m["wq"], bias=m["bq"]), ops.gemm(t, m["wk"], bias=m["bk"])
+            vt = ops.gemm(m["wv"], t)                                                # [C, HW] = W_v · X^T = (X · W_v^T)^T
+            o = torch.empty((HW, C), dtype=dt, device=x.device)
         scale = 1.0 / math.sqrt(C)
         for q0 in range(0, HW, q_chunk):
             q1 = min(HW, q0 + q_chunk)
-            scores = ops.gemm(q[q0:q1], k, out_dtype=torch.float32)                  # [rows, HW] = q · k^T
-            p = ops.softmax_rows(scores, scale, dt)
-            ops.gemm(p, vt, bias=m["bv"], out=o[q0:q1])                              # P · V + b_v  (rows of P sum to 1)
-        return ops.gemm(o, m["wo"], bias=m["bo"], residual=x.view(HW, C), out_dtype=torch.float32).view(1, HW, C)
+            scores = ops.gemm(q[q0:q1], k, out_dtype=f32)                            # [rows, HW] = q · k^T
+            p = ops.softmax_rows(scores, scale, f32 if split else dt)
+            ops.gemm(ops.split_bf16(p) if split else p, vt, bias=m["bv"], out=o[q0:q1],
+                     out_dtype=o.dtype)                                              # P · V + b_v  (rows of P sum to 1)
+        o = ops.split_bf16(o) if split else o
+        return ops.gemm(o, m["wo"], bias=m["bo"], residual=x.view(HW, C), out_dtype=f32).view(1, HW, C)
+
+    def _im2col(self, x, kpad):
+        """3x3 patches of a few-channel fp32 map [1, H, W, c] as the K-padded operand of the stem conv. A pure gather, so in
+        the fp32-grade mode the hi and lo planes are gathered separately (exact) and laid out [hi | hi | lo]."""
+        if not self.split:
+            return ops.im2col3x3_small(x, kpad, self.operand_dtype)
+        pl = ops.split_bf16(x.view(-1, 4))                                           # [n/4, 12] = [hi | hi | lo] per 4 values
+        hi, lo = (ops.im2col3x3_small(ops.cast(pl[:, a:a + 4].contiguous(), torch.float32).view(x.shape), kpad,
+                                      torch.bfloat16) for a in (0, 8))
+        return torch.cat([hi, hi, lo], dim=1)
 
     def _decode_one(self, z_nchw):
         """z: fp32 [1, latent, h, w] → fp32 [1, 3, 8h, 8w] (for the 4-level SDXL config)."""
-        P, dt, c = self._P, self.dtype, self.config
+        P, c, f32 = self._P, self.config, torch.float32
         _, lc, h, w = z_nchw.shape
         zp = ops.nchw_to_nhwc(z_nchw, ld=64)                                         # [1, hw, 64] fp32, channels ≥ lc are 0
-        x = ops.gemm(ops.cast(zp.view(-1, 64), dt), P["pq"][0], bias=P["pq"][1], out_dtype=torch.float32, n_valid=4)
-        col = ops.im2col3x3_small(x.view(1, h, w, lc), self.cin_kpad, dt)
-        x = ops.gemm(col, P["conv_in"][0], bias=P["conv_in"][1], out_dtype=torch.float32).view(1, h * w, -1)
+        x = ops.gemm(self._A(zp.view(-1, 64)), P["pq"][0], bias=P["pq"][1], out_dtype=f32, n_valid=4)
+        col = self._im2col(x.view(1, h, w, lc), self.cin_kpad)
+        x = ops.gemm(col, P["conv_in"][0], bias=P["conv_in"][1], out_dtype=f32).view(1, h * w, -1)
         x = self._resnet(P["mid"]["r0"], x, h, w)
         x = self._mid_attention(P["mid"], x)
         x = self._resnet(P["mid"]["r1"], x, h, w)
@@ -337,12 +399,10 @@ class AutoencoderKL:
             for r in blk["res"]:
                 x = self._resnet(r, x, H, W)
             if blk["up"] is not None:
-                Ci = x.shape[-1]
-                x = ops.conv3x3(ops.cast(x, dt).view(1, H, W, Ci), blk["up"][0], bias=blk["up"][1], upsample=True,
-                                out_dtype=torch.float32)
+                x = ops.conv3x3(self._A(x).view(1, H, W, -1), blk["up"][0], bias=blk["up"][1], upsample=True, out_dtype=f32)
                 H, W = 2 * H, 2 * W
-        hN = ops.groupnorm(x, P["norm_out"][0], P["norm_out"][1], c.norm_num_groups, EPS, True, dt)
-        y = ops.conv3x3(hN.view(1, H, W, x.shape[-1]), P["conv_out"][0], bias=P["conv_out"][1], out_dtype=torch.float32,
+        hN = self._gn(x, P["norm_out"], True)
+        y = ops.conv3x3(hN.view(1, H, W, -1), P["conv_out"][0], bias=P["conv_out"][1], out_dtype=f32,
                         n_valid=4)                                                   # [1, HW, 4]: RGB + one zero column
         return ops.nhwc_to_nchw(y, c.out_channels, H, W)
 
@@ -357,32 +417,31 @@ class AutoencoderKL:
 
     def _encode_one(self, img_nchw):
         """img: fp32 [1, 3, H, W] in [-1, 1] → mean of the posterior, fp32 [1, latent, H/8, W/8]."""
-        P, dt, c = self._P, self.dtype, self.config
+        P, c, f32 = self._P, self.config, torch.float32
         E = P["enc"]
         _, ci, H, W = img_nchw.shape
         nb = len(c.block_out_channels)
         assert H % (1 << (nb - 1)) == 0 and W % (1 << (nb - 1)) == 0
         x = ops.nchw_to_nhwc(img_nchw)                                               # [1, HW, 3] fp32
-        col = ops.im2col3x3_small(x.view(1, H, W, ci), self.enc_kpad, dt)
-        x = ops.gemm(col, E["conv_in"][0], bias=E["conv_in"][1], out_dtype=torch.float32).view(1, H * W, -1)
+        col = self._im2col(x.view(1, H, W, ci), self.enc_kpad)
+        x = ops.gemm(col, E["conv_in"][0], bias=E["conv_in"][1], out_dtype=f32).view(1, H * W, -1)
         for blk in E["down"]:
             for r in blk["res"]:
                 x = self._resnet(r, x, H, W)
             if blk["down"] is not None:                                              # Downsample2D(padding=0) + F.pad(0,1,0,1)
-                Ci = x.shape[-1]
-                x = ops.conv3x3(ops.cast(x, dt).view(1, H, W, Ci), blk["down"][0], bias=blk["down"][1], stride=2,
-                                pad_mode=1, out_dtype=torch.float32)
+                x = ops.conv3x3(self._A(x).view(1, H, W, -1), blk["down"][0], bias=blk["down"][1], stride=2, pad_mode=1,
+                                out_dtype=f32)
                 H, W = H // 2, W // 2
         x = self._resnet(E["mid"]["r0"], x, H, W)
         x = self._mid_attention(E["mid"], x)
         x = self._resnet(E["mid"]["r1"], x, H, W)
-        hN = ops.groupnorm(x, E["norm_out"][0], E["norm_out"][1], c.norm_num_groups, EPS, True, dt)
+        hN = self._gn(x, E["norm_out"], True)
         lc2 = 2 * c.latent_channels
-        y = ops.conv3x3(hN.view(1, H, W, x.shape[-1]), E["conv_out"][0], bias=E["conv_out"][1], out_dtype=torch.float32,
+        y = ops.conv3x3(hN.view(1, H, W, -1), E["conv_out"][0], bias=E["conv_out"][1], out_dtype=f32,
                         n_valid=lc2)                                                 # [1, HW, 8] moments before quant_conv
         pad = torch.zeros((H * W, 64), dtype=torch.float32, device=y.device)
         ops.copy2d(y.view(H * W, lc2), pad, 0)
-        m = ops.gemm(ops.cast(pad, dt), E["quant"][0], bias=E["quant"][1], out_dtype=torch.float32, n_valid=lc2)
+        m = ops.gemm(self._A(pad), E["quant"][0], bias=E["quant"][1], out_dtype=f32, n_valid=lc2)
         return ops.nhwc_to_nchw(m.view(1, H * W, lc2), c.latent_channels, H, W)     # mean = first latent_channels columns
 
     @torch.no_grad()
