@@ -69,6 +69,7 @@ class BenchTokenizer:
 
 
 USE_VAE = True   # set from --no-vae
+VAE_PRECISION = "fp32"   # set from --vae-precision
 BATCH = 16       # generations processed together per step on one GPU (set from --batch)
 GRID_PINPOINTS = [[a * 448, b * 448] for a, b in ((1, 1), (1, 2), (1, 3), (2, 1), (3, 1), (1, 4), (4, 1), (2, 2))]
 
@@ -114,7 +115,7 @@ def build_models(dev, dtype, llm_comm=None, cfg_comm=None, need=("vit", "llm", "
             from seedx_amd.vae import AutoencoderKL
             vae = AutoencoderKL()                                                    # SDXL vae/config.json defaults
             vae.load_state_dict(syn.vae_state_dict(vae, dev, dtype))
-            vae.to(dev, dtype)
+            vae.to(dev, dtype, precision=VAE_PRECISION)
             vae._pack()
         adapter.init_pipe(vae=vae, scheduler=EulerDiscreteScheduler(), visual_encoder=vit, image_transform=None,
                           dtype=dtype, device=dev)
@@ -534,6 +535,9 @@ def parse_args(argv=None):
     ap.add_argument("--chains", type=int, default=2, help="concurrent UNet kernel chains per denoise step (1 = one serial chain; "
                     "use 1 under rocprofv3 so per-kernel durations do not contain the other chain)")
     ap.add_argument("--no-vae", action="store_true", help="stop at the denoised latents (no VAE decode)")
+    ap.add_argument("--vae-precision", default="fp32", choices=["fp32", "fast", "auto"],
+                    help="fp32 (default): the reference's scripts decode with the VAE upcast to fp32 — operands carried as two "
+                         "bf16 planes, fp32 accumulation; fast: single 16-bit operands; auto: what the reference would do for --dtype")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: CPU launch-path test only (with --stub)")
@@ -549,10 +553,11 @@ def main(argv=None):
                "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(sys.argv[1:] if argv is None else argv)
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         raise SystemExit(subprocess.run(cmd, env=env).returncode)
-    global BATCH, USE_VAE
+    global BATCH, USE_VAE, VAE_PRECISION
     BATCH = a.batch if a.batch is not None else (4 if a.config == 5 else 16)
     a.batch = BATCH
     USE_VAE = not a.no_vae
+    VAE_PRECISION = a.vae_precision
     from seedx_amd import dist_utils as du
     ctx = du.init(a.backend)                    # RCCL over xGMI; only barrier + max-reduce of the wall time
     rank, world, local = ctx.rank, ctx.world, ctx.local
@@ -606,7 +611,9 @@ def main(argv=None):
                "data": "synthetic (seeded random uint8 image / prompt ids, random-init weights of the real dims)",
                "config": {"workload": w.describe() if gpu else "stub (launch-path test)", "baseline_config": a.config,
                           "parallelism": "replica x%d (independent generations, no data-path collective)" % world,
-                          "batch_per_gpu": a.batch, "request_pipelining": bool(a.overlap)},
+                          "batch_per_gpu": a.batch, "request_pipelining": bool(a.overlap),
+                          "vae": ("none" if not USE_VAE else {"fp32": "fp32-grade (two bf16 planes per operand, fp32 accumulation)",
+                                                              "fast": "single 16-bit operands"}.get(VAE_PRECISION, "auto"))},
                "flops_per_generation": w.flops(), "generations_per_step": a.batch}
         rec["model_tflops"] = rec["flops_per_generation"] * rec["value"] / world / 1e12
         if roof is not None:

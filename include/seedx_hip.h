@@ -29,6 +29,7 @@ extern "C" {
 #define SX_F16 0
 #define SX_BF16 1
 #define SX_F32 2
+#define SX_BF16X3 3 /* sx_groupnorm* outputs only: bf16 planes [hi | hi | lo] per row, 3*C columns (see sx_split_bf16) */
 
 /* epilogue activations */
 #define SX_ACT_NONE 0
@@ -124,8 +125,8 @@ int sx_softmax_rows(const float* x, int64_t ldx, void* y, int64_t ldy, int rows,
 
 /* GroupNorm(+SiLU) over NHWC activations x[B][HW][C] (fp32 in). replaces diffusers
  * ResnetBlock2D.norm1/norm2 + nonlinearity, Transformer2DModel.norm, conv_norm_out [ext].
- * stats: scratch fp64 [B][groups][2] (zeroed by the call). y: 16-bit normalised output (SX_F32 is accepted when raw16 is
- * NULL: the fp32-grade VAE mode).
+ * stats: scratch fp64 [B][groups][2] (zeroed by the call). y: 16-bit normalised output; SX_F32 is accepted when raw16 is
+ * NULL; SX_BF16X3 writes y (and raw16) as [B][HW][3*C] bf16 planes, the A operand of the fp32-grade VAE mode.
  * raw16: optional 16-bit un-normalised copy of x (feeds the 1x1 shortcut conv), may be NULL. */
 int sx_groupnorm(const float* x, void* y, void* raw16, int out_dtype, const float* gamma, const float* beta,
                  double* stats, int B, int HW, int C, int groups, float eps, int silu, void* stream);

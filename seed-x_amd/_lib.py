@@ -9,6 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libseedx_hip.so")
 
 SX_F16, SX_BF16, SX_F32 = 0, 1, 2
+SX_BF16X3 = 3          # sx_groupnorm* output only: bf16 planes [hi | hi | lo] per row
 SX_ACT_NONE, SX_ACT_GELU, SX_ACT_SILU = 0, 1, 2
 SX_A_LINEAR, SX_A_CONV3X3 = 0, 1
 

@@ -247,11 +247,33 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* x, const flo
     if (!TWO) return x4[i];
     return q < n4a ? x4[(row_base + row) * n4a + q] : x4b[(row_base + row) * n4b + (q - n4a)];
   };
-  auto one = [&](int i, int qi, const f32x4_t v) {
+  // SX_BF16X3: bf16 planes of the fp32 value, rows laid out [hi | hi | lo] (3*C columns) — the A operand of the VAE's
+  // fp32-grade GEMMs (see sx_split_bf16), written here instead of an fp32 tensor plus a separate split pass
+  auto store_planes = [&](void* dst, int row, int qi, const f32x4_t v) {
+    unsigned short h[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      h[e] = BF16::from_f32(v[e]);
+      l[e] = BF16::from_f32(v[e] - BF16::to_f32(h[e]));
+    }
+    u32x2_t oh, ol;
+    oh[0] = h[0] | ((unsigned)h[1] << 16); oh[1] = h[2] | ((unsigned)h[3] << 16);
+    ol[0] = l[0] | ((unsigned)l[1] << 16); ol[1] = l[2] | ((unsigned)l[3] << 16);
+    u32x2_t* o = (u32x2_t*)dst + (row_base + row) * 3 * n4 + qi;
+    o[0] = oh;
+    o[n4] = oh;
+    o[2 * n4] = ol;
+  };
+  auto one = [&](int i, int row, int qi, const f32x4_t v) {
     f32x4_t o = v * *(const f32x4_t*)(s_sc + 4 * qi) + *(const f32x4_t*)(s_sh + 4 * qi);
     if (silu) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = silu_f(o[e]);
+    }
+    if (out_dt == SX_BF16X3) {
+      store_planes(y, row, qi, o);
+      if (raw16) store_planes(raw16, row, qi, v);
+      return;
     }
     store4(y, out_dt, base4 + i, o);
     if (raw16) store4(raw16, out_dt, base4 + i, v);
@@ -265,14 +287,14 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* x, const flo
     int q2 = q1, r2_ = r1_; adv(r2_, q2);
     int q3 = q2, r3_ = r2_; adv(r3_, q3);
     const f32x4_t v0 = fetch(i, ri, qi), v1 = fetch(i + 256, r1_, q1), v2 = fetch(i + 512, r2_, q2), v3 = fetch(i + 768, r3_, q3);
-    one(i, qi, v0);
-    one(i + 256, q1, v1);
-    one(i + 512, q2, v2);
-    one(i + 768, q3, v3);
+    one(i, ri, qi, v0);
+    one(i + 256, r1_, q1, v1);
+    one(i + 512, r2_, q2, v2);
+    one(i + 768, r3_, q3, v3);
     qi = q3; ri = r3_; adv(ri, qi);
   }
   for (; i < total; i += 256) {
-    one(i, qi, fetch(i, ri, qi));
+    one(i, ri, qi, fetch(i, ri, qi));
     adv(ri, qi);
   }
 }
@@ -374,8 +396,8 @@ static int groupnorm_impl(const float* x, const float* x2, int C1, void* y, void
   SX_CHECK(x && stats, "sx_groupnorm: null pointer");
   SX_CHECK(phase == 1 || (y && gamma && beta), "sx_groupnorm: null pointer");
   SX_CHECK(!x2 || (C1 > 0 && C1 < C && C1 % 4 == 0 && (C - C1) % 4 == 0), "sx_groupnorm2: C1=%d of C=%d", C1, C);
-  SX_CHECK(phase == 1 || out_dtype == SX_F16 || out_dtype == SX_BF16 || (out_dtype == SX_F32 && !raw16),
-           "sx_groupnorm: output must be 16-bit, or fp32 without a raw copy");
+  SX_CHECK(phase == 1 || out_dtype == SX_F16 || out_dtype == SX_BF16 || out_dtype == SX_BF16X3 || (out_dtype == SX_F32 && !raw16),
+           "sx_groupnorm: output must be 16-bit, SX_BF16X3, or fp32 without a raw copy");
   SX_CHECK(groups > 0 && groups <= 64 && C % groups == 0, "sx_groupnorm: C=%d groups=%d", C, groups);
   SX_CHECK(C % 4 == 0 && (C / groups) % 2 == 0, "sx_groupnorm: C %% 4 and (C/groups) %% 2 must be 0 (C=%d)", C);
   SX_CHECK(C / 2 <= 256 * GN_MAX_SLOTS2 && C <= GN_MAX_C, "sx_groupnorm: C=%d too large", C);

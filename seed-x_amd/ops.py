@@ -176,8 +176,9 @@ def rmsnorm(x, gamma, eps, out_dtype):
     return layernorm(x, gamma, None, eps, out_dtype, rms=True)
 
 
-def groupnorm(x, gamma, beta, groups, eps, silu, out_dtype, want_raw=False, x2=None, comm=None, hw_total=None):
+def groupnorm(x, gamma, beta, groups, eps, silu, out_dtype, want_raw=False, x2=None, comm=None, hw_total=None, planes=False):
     """x: fp32 [B, HW, C] (NHWC). Returns y (16-bit) and optionally a 16-bit raw copy of x.
+    planes: y (and raw) come out as bf16 [B, HW, 3C] rows [hi | hi | lo] (split_bf16 role "a") instead.
     x2: optional second fp32 [B, HW, C2] tensor — the op then runs over the channel concatenation [x | x2] (never built).
     comm / hw_total: x holds only this rank's pixel rows of images with hw_total rows (seqpar.py): the fp64 statistics are
     all-reduced over the ranks between the statistics pass and the apply pass."""
@@ -188,14 +189,18 @@ def groupnorm(x, gamma, beta, groups, eps, silu, out_dtype, want_raw=False, x2=N
     if x2 is not None:
         assert x2.dtype == torch.float32 and x2.is_contiguous() and x2.shape[:2] == (B, HW)
         Cc = C1 + x2.shape[2]
-    y = torch.empty((B, HW, Cc), dtype=out_dtype, device=x.device)
-    raw = torch.empty((B, HW, Cc), dtype=out_dtype, device=x.device) if want_raw else None
+    if planes:
+        out_dtype, code, cols = torch.bfloat16, _lib.SX_BF16X3, 3 * Cc
+    else:
+        code, cols = _DT[out_dtype], Cc
+    y = torch.empty((B, HW, cols), dtype=out_dtype, device=x.device)
+    raw = torch.empty((B, HW, cols), dtype=out_dtype, device=x.device) if want_raw else None
     stats = torch.empty((B, groups, 2), dtype=torch.float64, device=x.device)
     if comm is None or comm.world == 1:
-        check(lib.sx_groupnorm2(_p(x), _p(x2), C1, _p(y), _p(raw), _DT[out_dtype], _p(_f32c(gamma)), _p(_f32c(beta)), _p(stats),
+        check(lib.sx_groupnorm2(_p(x), _p(x2), C1, _p(y), _p(raw), code, _p(_f32c(gamma)), _p(_f32c(beta)), _p(stats),
                                 B, HW, Cc, groups, float(eps), 1 if silu else 0, _stream()), "sx_groupnorm")
     else:
-        args = (_p(x), _p(x2), C1, _p(y), _p(raw), _DT[out_dtype], _p(_f32c(gamma)), _p(_f32c(beta)), _p(stats), B, HW,
+        args = (_p(x), _p(x2), C1, _p(y), _p(raw), code, _p(_f32c(gamma)), _p(_f32c(beta)), _p(stats), B, HW,
                 int(hw_total), Cc, groups, float(eps), 1 if silu else 0)
         check(lib.sx_groupnorm_sp(*args, 1, _stream()), "sx_groupnorm_sp(stats)")
         comm.all_reduce(stats)

@@ -326,8 +326,7 @@ class AutoencoderKL:
         G = self.config.norm_num_groups
         if not self.split:
             return ops.groupnorm(x, gb[0], gb[1], G, EPS, silu, self.operand_dtype, want_raw=want_raw)
-        y = ops.split_bf16(ops.groupnorm(x, gb[0], gb[1], G, EPS, silu, torch.float32))
-        return (y, ops.split_bf16(x)) if want_raw else y
+        return ops.groupnorm(x, gb[0], gb[1], G, EPS, silu, None, want_raw=want_raw, planes=True)
 
     def _resnet(self, r, x, H, W):
         """x: fp32 [1, HW, Ci] → fp32 [1, HW, Co]  (ResnetBlock2D with temb=None [ext])."""

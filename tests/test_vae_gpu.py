@@ -48,6 +48,19 @@ def test_split_bf16_planes(dev):
     assert e3 < 2e-5 and e1 > 1e-3
 
 
+@pytest.mark.parametrize("C,silu", [(64, True), (320, False)])
+def test_groupnorm_writes_planes_directly(dev, C, silu):
+    """SX_BF16X3 output of GroupNorm == the fp32 output put through sx_split_bf16 (bit for bit), same for the raw copy."""
+    from seedx_amd import ops
+    g = torch.Generator().manual_seed(27)
+    x = (torch.randn(2, 24 * 24, C, generator=g) * 3 + 1).to(dev)
+    ga, be = torch.randn(C, generator=g).to(dev), torch.randn(C, generator=g).to(dev)
+    y32 = ops.groupnorm(x, ga, be, 32, 1e-6, silu, torch.float32)
+    y3, raw3 = ops.groupnorm(x, ga, be, 32, 1e-6, silu, None, want_raw=True, planes=True)
+    assert y3.shape == (2, 576, 3 * C) and y3.dtype == torch.bfloat16
+    assert torch.equal(y3, ops.split_bf16(y32)) and torch.equal(raw3, ops.split_bf16(x))
+
+
 @pytest.mark.parametrize("dtype,precision,tol", MODES, ids=IDS)
 def test_vae_decode_mini_vs_oracle(dev, dtype, precision, tol):
     cfg = rv.MINI_VAE
