@@ -378,9 +378,9 @@ class Pipeline:
 
 def gemm_roofline(w):
     """Instrumented (eager, un-graphed) step with HIP events around EVERY sx_gemm launch on the launch stream: per-launch
-    algorithmic FLOPs (2·M·N·K, conv: 2·M·N·9·Cin) and duration. The GEMM/implicit-conv kernel family is the dominant
+    algorithmic FLOPs (2·M·N·K, conv: 2·M·N·9·Cin; K ÷ 3 for the fp32-grade VAE's plane-carrying launches) and duration. The GEMM/implicit-conv kernel family is the dominant
     kernel (≈85 % of algorithmic FLOPs)."""
-    from seedx_amd import _lib
+    from seedx_amd import _lib, ops
     lib = _lib.load()
     real = lib.sx_gemm
     rec = []
@@ -397,7 +397,7 @@ def gemm_roofline(w):
             a_bytes = 2.0 * (a.B * a.Hin * a.Win * a.Cin if a.a_mode == 1 else a.M * a.K)   # operands once + output once
             byt = a_bytes + 2.0 * a.N * a.K + a.M * n_st * (4.0 if a.out_dtype == 2 else 2.0) \
                 + (4.0 * a.M * n_st if a.residual else 0.0)
-            rec.append((2.0 * a.M * a.N * a.K, s, e, byt))
+            rec.append((2.0 * a.M * a.N * a.K / ops.OPERAND_PLANES, s, e, byt))   # fp32-grade VAE launches carry 3 planes in K
             return r
 
     loop = getattr(getattr(w, "adapter", None), "_loop", None)

@@ -338,6 +338,12 @@ def cast(x, dtype):
     return y
 
 
+# Accounting hint, not behaviour: while > 1, the K of the sx_gemm launches being issued is this many times the algorithmic K
+# (the VAE's fp32-grade mode triples K to carry two bf16 planes per operand). bench.py's roofline pass divides by it so that
+# "achieved" counts the FLOPs of the fp32 product being emulated, not the MFMA work spent on it.
+OPERAND_PLANES = 1
+
+
 def split_bf16(x, role="a"):
     """fp32 [..., C] → bf16 [..., 3C]: the planes of x = hi + lo laid out [hi | hi | lo] (role "a": rows of a GEMM's A
     operand) or [hi | lo | hi] (role "w": rows of its W operand). One GEMM over K = 3C then yields Ah·Wh + Ah·Wl + Al·Wh

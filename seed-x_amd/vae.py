@@ -411,7 +411,11 @@ class AutoencoderKL:
         Returns DecoderOutput(sample=[B, 3, 8h, 8w] fp32) or a 1-tuple."""
         self._pack()
         z = z.to(device=self.device, dtype=torch.float32)
-        out = torch.cat([self._decode_one(z[b:b + 1].contiguous()) for b in range(z.shape[0])], dim=0)
+        ops.OPERAND_PLANES = 3 if self.split else 1
+        try:
+            out = torch.cat([self._decode_one(z[b:b + 1].contiguous()) for b in range(z.shape[0])], dim=0)
+        finally:
+            ops.OPERAND_PLANES = 1
         return DecoderOutput(out) if return_dict else (out,)
 
     def _encode_one(self, img_nchw):
@@ -450,7 +454,11 @@ class AutoencoderKL:
             raise NotImplementedError("this AutoencoderKL was loaded without encoder.* / quant_conv.* weights")
         self._pack()
         x = x.to(device=self.device, dtype=torch.float32)
-        mean = torch.cat([self._encode_one(x[b:b + 1].contiguous()) for b in range(x.shape[0])], dim=0)
+        ops.OPERAND_PLANES = 3 if self.split else 1
+        try:
+            mean = torch.cat([self._encode_one(x[b:b + 1].contiguous()) for b in range(x.shape[0])], dim=0)
+        finally:
+            ops.OPERAND_PLANES = 1
         dist = SimpleNamespace(mode=lambda: mean, mean=mean)
         out = SimpleNamespace(latent_dist=dist)
         return out if return_dict else (dist,)
