@@ -39,6 +39,17 @@ from . import ops
 EPS = 1e-6
 
 
+def pack_planes(w32, taps=1, role="w"):
+    """fp32 [N, taps*C] → bf16 [N, taps*3C]: per tap the planes of w = hi + lo (hi = bf16(w), lo = bf16(w − hi)) laid out
+    [hi | lo | hi] (role "w": rows of a GEMM's W operand) or [hi | hi | lo] (role "a": a weight used as the A operand).
+    Host-side twin of sx_split_bf16 for weights (pack time only); activations are split on the GPU."""
+    w3 = w32.reshape(w32.shape[0], taps, -1)
+    hi = w3.to(torch.bfloat16)
+    lo = (w3 - hi.float()).to(torch.bfloat16)
+    planes = [hi, lo, hi] if role == "w" else [hi, hi, lo]
+    return torch.cat(planes, dim=2).reshape(w32.shape[0], -1).contiguous()
+
+
 class DecoderOutput:
     def __init__(self, sample):
         self.sample = sample
@@ -223,13 +234,7 @@ class AutoencoderKL:
         def opnd(w32, taps=1, role="w"):
             """fp32 [N, taps*C] on the device → MFMA operand rows: 16-bit as is, or (fp32-grade mode) bf16 [N, taps*3C] with
             the planes [hi | lo | hi] per tap (role "w"; "a" = [hi | hi | lo] for a weight used as the GEMM's A operand)."""
-            if not split:
-                return w32.to(dt).contiguous()
-            w3 = w32.reshape(w32.shape[0], taps, -1)
-            hi = w3.to(torch.bfloat16)
-            lo = (w3 - hi.float()).to(torch.bfloat16)
-            planes = [hi, lo, hi] if role == "w" else [hi, hi, lo]
-            return torch.cat(planes, dim=2).reshape(w32.shape[0], -1).contiguous()
+            return pack_planes(w32, taps, role) if split else w32.to(dt).contiguous()
 
         def lin16(k, role="w"):
             w = f32(k)

@@ -442,6 +442,37 @@ def test_thread_comm_virtual_ranks_cpu():
 
 
 # ---- VAE decoder host logic ------------------------------------------------------------------------------------------
+def test_vae_fp32_grade_mode_selection_and_weight_planes():
+    """Host logic of the VAE's fp32-grade mode: it is selected exactly when the reference's pipeline would upcast the VAE
+    (fp16 + force_upcast, pipeline_stable_diffusion_xl_t2i_edit.py:509-511 / :967-970) or on an explicit fp32 / precision
+    request; weight rows carry [hi | lo | hi] per conv tap so that a tripled-K product with [hi | hi | lo] activation rows
+    is Ah·Wh + Ah·Wl + Al·Wh ≈ A·W to 16 mantissa bits."""
+    from seedx_amd.vae import AutoencoderKL, pack_planes
+    cases = [(torch.float16, True, "auto", True), (torch.float16, False, "auto", False), (torch.bfloat16, True, "auto", False),
+             (torch.float32, False, "auto", True), (torch.float16, True, "fast", False), (torch.bfloat16, True, "fp32", True)]
+    for dt, upcast, prec, want in cases:
+        m = AutoencoderKL(block_out_channels=(64, 128), layers_per_block=1, force_upcast=upcast)
+        m.dtype, m.precision = dt, prec
+        assert m.split == want, (dt, upcast, prec)
+        assert m.operand_dtype == (torch.bfloat16 if (want or dt == torch.float32) else dt)
+    g = torch.Generator().manual_seed(3)
+    Co, taps, Cc, M = 8, 9, 16, 5
+    w = torch.randn(Co, taps * Cc, generator=g) * torch.logspace(-3, 3, taps * Cc)
+    ww, wa = pack_planes(w, taps, "w"), pack_planes(w, taps, "a")
+    assert ww.shape == wa.shape == (Co, taps * 3 * Cc) and ww.dtype == torch.bfloat16
+    w3, hi = ww.view(Co, taps, 3, Cc), w.view(Co, taps, Cc).to(torch.bfloat16)
+    assert torch.equal(w3[:, :, 0], hi) and torch.equal(w3[:, :, 2], hi)
+    assert torch.equal(wa.view(Co, taps, 3, Cc)[:, :, 2], w3[:, :, 1]) and torch.equal(wa.view(Co, taps, 3, Cc)[:, :, 1], hi)
+    rec = w3[:, :, 0].double() + w3[:, :, 1].double()
+    assert ((rec - w.view(Co, taps, Cc).double()).abs() / w.view(Co, taps, Cc).double().abs()).max() < 2.0 ** -16
+    a = torch.randn(M, taps * Cc, generator=g)                       # activation rows, same per-tap plane layout, role "a"
+    prod = pack_planes(a, taps, "a").double() @ ww.double().t()      # what the tripled-K GEMM accumulates
+    ref = a.double() @ w.double().t()
+    single = a.to(torch.bfloat16).double() @ w.to(torch.bfloat16).double().t()
+    e3, e1 = ((prod - ref).norm() / ref.norm()).item(), ((single - ref).norm() / ref.norm()).item()
+    assert e3 < 2e-5 < 1e-3 < e1, (e3, e1)
+
+
 def test_vae_inventory_matches_oracle_and_param_count():
     from oracle import restated_vae as rv
     from seedx_amd.vae import AutoencoderKL
