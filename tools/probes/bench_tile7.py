@@ -1,11 +1,11 @@
-"""Experimental tile 7 (256x256 block tile, 4 waves x 128x128 wave tiles, accumulators pinned in AGPRs, hand-ordered software
+"""(needs tools/probes/gemm_pipe4w.patch applied) Experimental tile 7 (256x256 block tile, 4 waves x 128x128 wave tiles, accumulators pinned in AGPRs, hand-ordered software
 pipeline) against tile 4 (256x256, 8 waves) and 5 (256x320): correctness on edge shapes (ragged M / N, K = 64 / 128, conv,
 epilogues) and speed on the UNet's C = 1280 call sites and 8192^3."""
 import os
 import sys
 import time
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from seedx_amd import _lib, ops
 from seedx_amd.llama import glu_pack_rows
