@@ -55,6 +55,18 @@ def main():
         print("%d UNet CFG steps (batch %d)                          %9.1f ms  (%.2f ms/step)" % (a.unet_steps, 2 * G, (t_lat - t_emb) * 1e3, (t_lat - t_emb) / a.unet_steps * 1e3))
         print("VAE decode + uint8 (%d images)                       %9.1f ms" % (G, t_img * 1e3))
         print("sum                                                  %9.1f ms" % ((t_a + t_full + t_lat + t_img) * 1e3))
+        # per-phase utilisation against the MI355X peaks (algorithmic work of SURVEY.md §8d ÷ phase wall time)
+        PF, TB = 2500.0, 8.0
+        t_dec, t_un = t_62 - t_p1, t_lat - t_emb
+        rows = [("ViT-G, %d crops" % (2 * G), 2 * G * bench.FLOP_VIT_CROP / t_a / 1e12, None),
+                ("prefill, %d tokens" % (165 * G), 165 * G * bench.FLOP_LLM_TOKEN / t_p1 / 1e12, None),
+                ("decode, 61 steps x %d sequences" % G, 61 * G * bench.FLOP_LLM_TOKEN / t_dec / 1e12, 61 * 25.71e9 / t_dec / 1e12),
+                ("UNet, %d steps x %d samples" % (a.unet_steps, 2 * G), a.unet_steps * 2 * G * bench.FLOP_UNET_SAMPLE / t_un / 1e12, None),
+                ("VAE decode, %d images (fp32-product FLOPs)" % G, G * bench.FLOP_VAE_DECODE / t_img / 1e12, None)]
+        print("utilisation (algorithmic work / wall time; peaks %.0f TFLOP/s dense 16-bit MFMA, %.0f TB/s HBM):" % (PF, TB))
+        for name, tf, tbs in rows:
+            print("  %-44s %7.1f TFLOP/s = %4.1f %% of MFMA peak%s" % (name, tf, 100 * tf / PF,
+                  "" if tbs is None else "; weights streamed at %.2f TB/s = %4.1f %% of HBM peak" % (tbs, 100 * tbs / TB)))
 
 
 if __name__ == "__main__":
