@@ -101,6 +101,9 @@ typedef struct sx_gemv_args {
   const float* residual;
   int32_t M, N, K;
   int32_t dtype, out_dtype, act, glu;
+  int32_t w_layout;    /* 0: W row-major [N][K]. 1: decode tiles [N/16][K/32][16][32] (each 16-row x 32-k MFMA operand tile
+                        * is 1 KB contiguous, tiles of a row group follow each other along K): MFMA path only (M >= 2) */
+  int32_t reserved;
 } sx_gemv_args;
 int sx_gemv(const sx_gemv_args* args, void* stream);
 /* test hook: 1 = always take the VALU path (lets the tests compare both), 0 = automatic */

@@ -28,7 +28,8 @@ class GemmArgs(C.Structure):
 class GemvArgs(C.Structure):
     _fields_ = [("x", c_vp), ("W", c_vp), ("y", c_vp), ("residual", c_vp),
                 ("M", c_i32), ("N", c_i32), ("K", c_i32),
-                ("dtype", c_i32), ("out_dtype", c_i32), ("act", c_i32), ("glu", c_i32)]
+                ("dtype", c_i32), ("out_dtype", c_i32), ("act", c_i32), ("glu", c_i32),
+                ("w_layout", c_i32), ("reserved", c_i32)]
 
 
 class AttnArgs(C.Structure):

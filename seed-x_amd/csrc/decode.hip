@@ -13,6 +13,7 @@ struct GemvP {
   void* y;
   const float* residual;
   int M, N, K, out_dtype, act, glu;
+  int packed;   // W is in the decode layout [N/16][K/32][16 rows][32 k] (one MFMA operand tile = 1 KB contiguous)
 };
 
 template <typename TT, int MR>
@@ -108,9 +109,14 @@ __global__ __launch_bounds__(NWV * 64) void gemm_skinny_kernel(const GemvP p) {
   const int ks0 = wave * nks / NWV, ks1 = (wave + 1) * nks / NWV;
   const bool mvalid = r < p.M;
   const unsigned short* xp = p.x + (size_t)(mvalid ? r : 0) * p.K + 8 * g;
+  // row-major W: a load instruction covers one 64-B half line of 16 rows (row stride 2K bytes). Decode layout: the same
+  // instruction covers one contiguous 1-KB operand tile, a wave's k range is one contiguous stream.
   const unsigned short* wp[R];
+  const size_t kstep = p.packed ? 1024 : 64, khalf = p.packed ? 512 : 32;   // elements per 64-wide k-step / to its 2nd half
 #pragma unroll
-  for (int q = 0; q < R; ++q) wp[q] = p.W + (size_t)(n0 + q * 16 + r) * p.K + 8 * g;
+  for (int q = 0; q < R; ++q)
+    wp[q] = p.packed ? p.W + (size_t)(n0 / 16 + q) * (size_t)(p.K >> 5) * 512 + r * 32 + 8 * g
+                     : p.W + (size_t)(n0 + q * 16 + r) * p.K + 8 * g;
   f32x4_t acc[R];
 #pragma unroll
   for (int q = 0; q < R; ++q) acc[q] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
@@ -124,8 +130,8 @@ __global__ __launch_bounds__(NWV * 64) void gemm_skinny_kernel(const GemvP p) {
       const size_t k = (size_t)(ks + u) * 64;
 #pragma unroll
       for (int q = 0; q < R; ++q) {
-        wa[u][q] = __builtin_nontemporal_load((const u32x4_t*)(wp[q] + k));
-        wb[u][q] = __builtin_nontemporal_load((const u32x4_t*)(wp[q] + k + 32));
+        wa[u][q] = __builtin_nontemporal_load((const u32x4_t*)(wp[q] + (size_t)(ks + u) * kstep));
+        wb[u][q] = __builtin_nontemporal_load((const u32x4_t*)(wp[q] + (size_t)(ks + u) * kstep + khalf));
       }
       xa[u] = *(const u32x4_t*)(xp + k);
       xb[u] = *(const u32x4_t*)(xp + k + 32);
@@ -146,8 +152,8 @@ __global__ __launch_bounds__(NWV * 64) void gemm_skinny_kernel(const GemvP p) {
     const vec8 a = __builtin_bit_cast(vec8, mvalid ? xa : zero), b = __builtin_bit_cast(vec8, mvalid ? xb : zero);
 #pragma unroll
     for (int q = 0; q < R; ++q) {
-      const u32x4_t wa = __builtin_nontemporal_load((const u32x4_t*)(wp[q] + k));
-      const u32x4_t wb = __builtin_nontemporal_load((const u32x4_t*)(wp[q] + k + 32));
+      const u32x4_t wa = __builtin_nontemporal_load((const u32x4_t*)(wp[q] + (size_t)ks * kstep));
+      const u32x4_t wb = __builtin_nontemporal_load((const u32x4_t*)(wp[q] + (size_t)ks * kstep + khalf));
       acc[q] = TT::mfma16(__builtin_bit_cast(vec8, wa), a, acc[q]);
       acc[q] = TT::mfma16(__builtin_bit_cast(vec8, wb), b, acc[q]);
     }
@@ -455,9 +461,12 @@ extern "C" int sx_gemv(const sx_gemv_args* a, void* stream) {
   GemvP p;
   p.x = (const unsigned short*)a->x; p.W = (const unsigned short*)a->W; p.y = a->y; p.residual = a->residual;
   p.M = a->M; p.N = a->N; p.K = a->K; p.out_dtype = a->out_dtype; p.act = a->act; p.glu = a->glu;
+  p.packed = a->w_layout;
+  SX_CHECK(a->w_layout == 0 || a->w_layout == 1, "sx_gemv: w_layout must be 0 (row-major) or 1 (decode tiles)");
   // MI355X (tools/bench_gemv.py, 13B shapes): VALU path 6.5 / 4.7 / 3.0 TB/s at M = 1 / 4 / 8, MFMA path 4.0-4.4 TB/s at any M
   const bool mfma_ok = a->M >= 2 && a->K % 64 == 0 && a->K >= 256 && a->N % 32 == 0;
-  if (mfma_ok && g_force_valu_gemv != 1 && (a->M >= 5 || g_force_valu_gemv == 2)) {
+  SX_CHECK(!a->w_layout || (mfma_ok && a->K % 64 == 0), "sx_gemv: the decode-tile layout needs M >= 2, K %% 64 == 0, K >= 256, N %% 32 == 0");
+  if (mfma_ok && g_force_valu_gemv != 1 && (a->M >= 5 || g_force_valu_gemv == 2 || a->w_layout)) {
     // MFMA skinny GEMM: R = 2 row groups per wave for GLU (one packed group) or when that still gives >= 256 blocks
     const bool r2 = a->glu || a->N / 32 >= 256;
     const dim3 grid(r2 ? a->N / 32 : a->N / 16), block(256);

@@ -147,6 +147,14 @@ class LlamaForCausalLM:
         if v1 > v0:
             lm[:v1 - v0] = sd["lm_head.weight"][v0:v1].detach().to(dev, dt)
         P["lm_head"] = lm
+
+        def tiles(w):
+            """Second copy of a weight in the decode-tile layout for the lock-step batched decode (G >= 5 rows take the MFMA
+            skinny GEMM, whose wave-wide loads then cover whole contiguous kilobytes: 2.85 → 4.2 TB/s per layer in situ,
+            tools/bench_gemv_layout.py). Costs the weights' size again (25.7 GB of 288 GB at 13B); prefill keeps row-major."""
+            N, K = w.shape
+            return ops.pack_decode_tiles(w) if (self.G >= 5 and N % 32 == 0 and K % 64 == 0 and K >= 256) else None
+        P["lm_head_t"] = tiles(lm)
         for i in range(self.L):
             p = f"model.layers.{i}."
             sh = llama_tp_shard(sd, p, r, tp, self.nh, self.hd)
@@ -155,6 +163,9 @@ class LlamaForCausalLM:
             P["layers"].append(dict(
                 ln1=f32(sd[p + "input_layernorm.weight"]), ln2=f32(sd[p + "post_attention_layernorm.weight"]),
                 wqkv=w16(qkv), wo=w16(sh["o"]), wgu=gu, wd=w16(sh["down"])))
+            lw = P["layers"][-1]
+            for k in ("wqkv", "wo", "wgu", "wd"):
+                lw[k + "_t"] = tiles(lw[k])
         inv = 1.0 / (self.config.rope_base ** (torch.arange(0, self.hd, 2).float() / self.hd))
         fr = torch.outer(torch.arange(self.Tmax).float(), inv)           # [Tmax, hd/2] fp32 (:97-113)
         P["cos"], P["sin"] = fr.cos().to(dev).contiguous(), fr.sin().to(dev).contiguous()
@@ -244,14 +255,16 @@ class LlamaForCausalLM:
         scale = 1.0 / math.sqrt(hd)
         for li, lw in enumerate(P["layers"]):
             h = ops.rmsnorm(x, lw["ln1"], eps, dt)
-            qkv = ops.gemv(h, lw["wqkv"])                                             # [G, 3H]
+            qkv = ops.gemv(h, lw["wqkv"], w_tiles=lw["wqkv_t"])                       # [G, 3H]
             ops.rope_kv_append_b(qkv, P["kc"][li], P["vc"][li], P["cos"], P["sin"], P["pos"], G, 1, nh, hd)
             q = qkv[:, :H] if G == 1 else qkv[:, :H].contiguous()                    # [G, H] (plumbing copy for G > 1)
             att = ops.attn_decode_b(q.view(G, nh, hd), P["kc"][li], P["vc"][li], P["ctx"], scale)
-            x = comm.all_reduce(ops.gemv(att, lw["wo"], residual=x if lead else None, out_dtype=torch.float32))
+            x = comm.all_reduce(ops.gemv(att, lw["wo"], residual=x if lead else None, out_dtype=torch.float32,
+                                         w_tiles=lw["wo_t"]))
             h = ops.rmsnorm(x, lw["ln2"], eps, dt)
-            g = ops.gemv(h, lw["wgu"], act="silu", glu=True)
-            x = comm.all_reduce(ops.gemv(g, lw["wd"], residual=x if lead else None, out_dtype=torch.float32))
+            g = ops.gemv(h, lw["wgu"], act="silu", glu=True, w_tiles=lw["wgu_t"])
+            x = comm.all_reduce(ops.gemv(g, lw["wd"], residual=x if lead else None, out_dtype=torch.float32,
+                                         w_tiles=lw["wd_t"]))
         ops.add_i32(P["pos"], 1)
         ops.add_i32(P["ctx"], 1)
         return x
@@ -328,7 +341,8 @@ class LlamaForCausalLM:
         x = self._layers_single(x)
         hn = ops.rmsnorm(x, P["norm"], self.config.rms_norm_eps, torch.float32)
         ops.scatter_rows_step(hn, P["step"], hid_buf)
-        logits = ops.gemv(ops.cast(hn, self.dtype), P["lm_head"], out_dtype=torch.float32)   # [G, Vpad / tp]
+        logits = ops.gemv(ops.cast(hn, self.dtype), P["lm_head"], out_dtype=torch.float32,
+                          w_tiles=P["lm_head_t"])                                      # [G, Vpad / tp]
         if self.tp > 1:
             logits = self.comm.all_gather(logits).permute(1, 0, 2).reshape(self.G, self.Vpad).contiguous()
         ops.greedy_next_b(logits, self.V, img_ids_dev, P["cur"], out_ids, P["step"])

@@ -129,7 +129,17 @@ def conv3x3(x, w, bias=None, bias2d=None, residual=None, stride=1, upsample=Fals
     return out.view(B, Hout * Wout, n_store)
 
 
-def gemv(x, w, residual=None, act=None, glu=False, out_dtype=None):
+def pack_decode_tiles(w):
+    """Row-major [N, K] 16-bit weight → the decode layout [N/16][K/32][16][32] (same shape, other element order): every
+    16-row x 32-k MFMA operand tile is 1 KB contiguous and the tiles of a row group follow each other along K, so the skinny
+    GEMM's wave-wide loads are whole contiguous kilobytes instead of 64-B pieces of 16 rows 2K bytes apart."""
+    N, K = w.shape
+    assert N % 16 == 0 and K % 32 == 0
+    return w.view(N // 16, 16, K // 32, 32).permute(0, 2, 1, 3).contiguous().view(N, K)
+
+
+def gemv(x, w, residual=None, act=None, glu=False, out_dtype=None, w_tiles=None):
+    """w_tiles: the same weight in the decode layout (pack_decode_tiles); used instead of w when the MFMA path runs."""
     lib = _lib.load()
     assert x.dim() == 2 and x.is_contiguous() and w.is_contiguous() and x.dtype == w.dtype
     M, K = x.shape
@@ -144,6 +154,9 @@ def gemv(x, w, residual=None, act=None, glu=False, out_dtype=None):
         args.residual = residual.data_ptr()
     args.M, args.N, args.K = M, N, K
     args.dtype, args.out_dtype, args.act, args.glu = _DT[x.dtype], _DT[out_dtype], ACT[act], 1 if glu else 0
+    if w_tiles is not None and M >= 5 and K % 64 == 0 and K >= 256 and N % 32 == 0:
+        assert w_tiles.shape == w.shape and w_tiles.dtype == w.dtype and w_tiles.is_contiguous()
+        args.W, args.w_layout = w_tiles.data_ptr(), 1
     check(lib.sx_gemv(C.byref(args), _stream()), "sx_gemv")
     return y
 
@@ -154,7 +167,9 @@ def linear(x, w, **kw):
             and kw.get("out") is None and not kw.get("n_valid"):
         res = kw.get("residual")
         if res is None or res.is_contiguous():
-            return gemv(x, w, residual=res, act=kw.get("act"), glu=kw.get("glu", False), out_dtype=kw.get("out_dtype"))
+            return gemv(x, w, residual=res, act=kw.get("act"), glu=kw.get("glu", False), out_dtype=kw.get("out_dtype"),
+                        w_tiles=kw.get("w_tiles"))
+    kw.pop("w_tiles", None)
     return gemm(x, w, **kw)
 
 

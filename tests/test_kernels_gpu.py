@@ -321,6 +321,27 @@ def test_gemv_mfma_rows(dev, dtype, M, N, K):
         lib.sx_gemv_force_valu(0)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,K", [(5, 512, 256), (16, 5120, 5120), (8, 8192, 1728), (16, 32384, 512)])
+def test_gemv_decode_tile_layout(dev, dtype, M, N, K):
+    """The decode-tile weight layout [N/16][K/32][16][32] (ops.pack_decode_tiles) must give bit-identical results to the
+    row-major weight on the MFMA skinny path: plain, fp32 residual epilogue, and GLU-packed rows."""
+    from seedx_amd import ops
+    x, w = rnd((M, K), dtype, dev, seed=44), rnd((N, K), dtype, dev, 0.05, seed=45)
+    res = rnd((M, N), torch.float32, dev, seed=46)
+    t = ops.pack_decode_tiles(w)
+    assert t.shape == w.shape and not torch.equal(t, w)
+    # element (n, k) of the row-major weight sits at tile (n // 16, k // 32), row n % 16, column k % 32
+    assert torch.equal(t.view(N // 16, K // 32, 16, 32)[3, 1, 5], w[3 * 16 + 5, 32:64])
+    assert torch.equal(ops.gemv(x, w), ops.gemv(x, w, w_tiles=t))
+    a = ops.gemv(x, w, residual=res, out_dtype=torch.float32)
+    assert torch.equal(a, ops.gemv(x, w, residual=res, out_dtype=torch.float32, w_tiles=t))
+    assert relerr(a, x.float() @ w.float().t() + res) < 5e-5
+    assert torch.equal(ops.gemv(x, w, act="silu", glu=True), ops.gemv(x, w, act="silu", glu=True, w_tiles=t))
+    # fewer than 5 rows keep the VALU path and the row-major weight (w_tiles is ignored)
+    assert torch.equal(ops.gemv(x[:2].contiguous(), w), ops.gemv(x[:2].contiguous(), w, w_tiles=t))
+
+
 @pytest.mark.parametrize("ctx", [1, 17, 166, 1000])
 def test_attn_decode(dev, ctx):
     from seedx_amd import ops
