@@ -442,6 +442,30 @@ def test_thread_comm_virtual_ranks_cpu():
 
 
 # ---- VAE decoder host logic ------------------------------------------------------------------------------------------
+def test_decode_tile_weight_layout_cpu():
+    """ops.pack_decode_tiles (host-side re-ordering of a weight for the batched-decode skinny GEMM): element (n, k) of the
+    row-major weight lands in tile (n // 16, k // 32) at [n % 16][k % 32], tiles of one 16-row group are consecutive along K,
+    every tile is 1 KB contiguous, and the lane that feeds the 16x16x32 MFMA — row r = lane & 15, k-slots [8g, 8g + 8) with
+    g = lane >> 4 — reads 16 contiguous bytes at byte offset r*64 + g*16 of its tile (what csrc/decode.hip computes)."""
+    from seedx_amd import ops
+    N, K = 64, 128
+    w = torch.arange(N * K, dtype=torch.int32).to(torch.float32).view(N, K).to(torch.bfloat16)   # values are not unique in
+    idx = torch.arange(N * K, dtype=torch.int64).view(N, K)                                       # bf16: track indices too
+    t = ops.pack_decode_tiles(w)
+    ti = idx.view(N // 16, 16, K // 32, 32).permute(0, 2, 1, 3).contiguous().view(-1)
+    assert t.shape == w.shape and t.is_contiguous()
+    flat = w.reshape(-1)
+    assert torch.equal(t.view(-1), flat[ti])
+    for n, k in ((0, 0), (17, 5), (33, 64), (63, 127)):
+        tile, r, c = (n // 16) * (K // 32) + k // 32, n % 16, k % 32
+        assert ti[tile * 512 + r * 32 + c] == n * K + k
+    for lane in (0, 5, 16, 37, 63):                       # operand slice of one lane for tile (group 2, k-block 3)
+        r, g = lane & 15, lane >> 4
+        base = (2 * (K // 32) + 3) * 512 + r * 32 + 8 * g
+        assert ti[base:base + 8].tolist() == [(2 * 16 + r) * K + 3 * 32 + 8 * g + e for e in range(8)]
+        assert (base * 2) % 1024 == r * 64 + g * 16
+
+
 def test_vae_fp32_grade_mode_selection_and_weight_planes():
     """Host logic of the VAE's fp32-grade mode: it is selected exactly when the reference's pipeline would upcast the VAE
     (fp16 + force_upcast, pipeline_stable_diffusion_xl_t2i_edit.py:509-511 / :967-970) or on an explicit fp32 / precision
