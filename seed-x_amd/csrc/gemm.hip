@@ -20,29 +20,9 @@
 //     columns of one row → vector bias/residual loads and 8/16-byte stores in the fused epilogue
 //   * 1-D grid; block b runs on XCD b % 8, each XCD owns a compact rectangle of the tile grid and walks it in groups of
 //     8 tile-rows, so its private 4-MB L2 serves most operand re-reads (small grids: bijective XCD remap)
-#include "sx_common.h"
+#include "gemm_common.h"
 
 namespace sxk_gemm {
-
-struct GemmP {
-  const void* A;
-  const void* W;
-  void* C;
-  const float* bias;
-  const float* bias2d;
-  const float* residual;
-  int M, N, K, ldc, ldr, n_valid, res_mod, bias2d_rows, out_dtype, act, glu;
-  int Hin, Win, Cin, Hout, Wout, stride, upsample, ldb2, pad;
-  int tiles_m, tiles_n, xm, xn;   // tile grid and its XCD partition (xm x xn == 8, or 0 = linear remap)
-  int gm;                         // tile-rows per group of the in-XCD traversal
-  unsigned a_bytes, w_bytes;
-  unsigned long long* dbg;        // tuning hook: per-block s_memtime stamps [block][4] = start, first tile landed, main loop done, end
-};
-
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
 
 template <typename TT, int BM, int BN, int WM, int WN, int NSTAGE, int AMODE>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const GemmP p) {
@@ -68,31 +48,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const GemmP p) {
   unsigned long long t_start = 0, t_first = 0, t_main = 0;
   if (p.dbg) t_start = __builtin_amdgcn_s_memtime();
 
-  // Tile → XCD mapping. Block b is observed on XCD b % 8 (performance heuristic only). Each XCD gets a compact
-  // (tiles_m/xm) x (tiles_n/xn) rectangle of the tile grid, so its private L2 holds A-panel/xm + W-panel/xn instead of
-  // re-streaming whole panels from Infinity Cache / HBM (PMC: profiles/r1_pmc_hbm.json).
   int tile_m, tile_n;
-  if (p.xm == 0) {
-    const int t = xcd_remap(blockIdx.x, gridDim.x);
-    tile_m = t % p.tiles_m;
-    tile_n = t / p.tiles_m;
-  } else {
-    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-    const int xr = xcd / p.xn, xc = xcd - xr * p.xn;
-    const int ms = xr * p.tiles_m / p.xm, me = (xr + 1) * p.tiles_m / p.xm;
-    const int ns = xc * p.tiles_n / p.xn, ne = (xc + 1) * p.tiles_n / p.xn;
-    const int rm = me - ms, rn = ne - ns;
-    if (idx >= rm * rn) return;  // padding block of an uneven split (exits before any barrier)
-    // grouped order inside the rectangle: the ~32 blocks resident on an XCD at one time form a gm x (32/gm) patch (not a
-    // 32 x 1 column), and consecutive rounds keep the same gm A tile-rows while sweeping n → per round the XCD's L2 pulls
-    // gm + 32/gm operand tile-rows instead of 33 (PMC: FETCH_SIZE of the GEGLU GEMM 8.8x → see profiles/r1_pmc_summary.json)
-    const int per_group = p.gm * rn;
-    const int g = idx / per_group, first = g * p.gm;
-    const int gsz = (rm - first) < p.gm ? (rm - first) : p.gm;
-    const int r = idx - g * per_group;
-    tile_m = ms + first + r % gsz;
-    tile_n = ns + r / gsz;
-  }
+  if (!tile_coords(p, blockIdx.x, gridDim.x, tile_m, tile_n)) return;  // padding block of an uneven split (exits before any barrier)
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)p.a_bytes, 0x00020000);
@@ -162,10 +119,27 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const GemmP p) {
   };
 
   f32x4_t acc[FN][FM];
+  if (p.res_init) {
+    // fp32 residual (no activation, no GLU) is the accumulators' initial value — same rounding order in every tile
+    // config (gemm_pp.hip does the same), and the epilogue keeps no loads behind its stores
 #pragma unroll
-  for (int i = 0; i < FN; ++i)
+    for (int j = 0; j < FM; ++j) {
+      const int m = m0 + wm * TM + j * 16 + (lane & 15);
+      const int mc = m < p.M ? m : p.M - 1;
+      const float* rr = p.residual + (size_t)(p.res_mod ? (mc % p.res_mod) : mc) * p.ldr;
 #pragma unroll
-    for (int j = 0; j < FM; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      for (int i = 0; i < FN; ++i) {
+        int c = n0 + wn * TN + i * 16 + (lane >> 4) * 4;
+        if (c + 4 > p.ldr) c = 0;
+        acc[i][j] = *(const f32x4_t*)(rr + c);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+      for (int j = 0; j < FM; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  }
 
   // fragment read offsets: row = base + (lane & 15), logical chunk = ks*4 + (lane >> 4), key = lane & 7
   const unsigned frag_row = (unsigned)(lane & 15) * 128u;
@@ -249,7 +223,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const GemmP p) {
 #pragma unroll
       for (int i = 0; i < FN; ++i) v[i] += *(const f32x4_t*)(b2 + ncol[i]);
     }
-    if (p.residual) {
+    if (p.residual && !p.res_init) {
       const float* rr = p.residual + (size_t)(p.res_mod ? (mc % p.res_mod) : mc) * p.ldr;
 #pragma unroll
       for (int i = 0; i < FN; ++i) {
@@ -341,44 +315,41 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const GemmP p) {
 #endif
 }
 
-static unsigned long long* g_dbg = nullptr;   // tuning hook: timestamp buffer for the next launches (sx_gemm_debug_stamps)
-static int g_gm = 0;      // tuning hook: tile-rows per traversal group (0 = default)
-static int g_xcd_2d = 1;  // 2-D XCD tile partition on/off (tuning hook)
+unsigned long long* g_dbg = nullptr;   // tuning hook: timestamp buffer for the next launches (sx_gemm_debug_stamps)
+int g_gm = 0;      // tuning hook: tile-rows per traversal group (0 = default)
+int g_xcd_2d = 1;  // 2-D XCD tile partition on/off (tuning hook)
 
 template <typename TT, int BM, int BN, int WM, int WN, int NSTAGE>
 int launch_cfg(const GemmP& p0, int a_mode, hipStream_t st) {
   GemmP p = p0;
   p.dbg = g_dbg;
-  p.tiles_m = (p.M + BM - 1) / BM;
-  p.tiles_n = (p.N + BN - 1) / BN;
-  int grid = p.tiles_m * p.tiles_n;
-  p.xm = p.xn = 0;
-  p.gm = 1;
-  if (grid >= 16 && g_xcd_2d) {
-    // choose the 8-way split that minimises fabric traffic  A_bytes * xn + W_bytes * xm  among the least padded ones
-    const double ab = (double)p.M * p.K, wb = (double)p.N * p.K;
-    double best = 1e300;
-    for (int xm = 1; xm <= 8; xm *= 2) {
-      const int xn = 8 / xm;
-      if (xm > p.tiles_m || xn > p.tiles_n) continue;
-      const long padded = 8L * ((p.tiles_m + xm - 1) / xm) * ((p.tiles_n + xn - 1) / xn);
-      const double cost = (ab * xn + wb * xm) * (1.0 + 4.0 * (double)(padded - grid) / grid);
-      if (cost < best) { best = cost; p.xm = xm; p.xn = xn; }
-    }
-    if (p.xm) grid = 8 * ((p.tiles_m + p.xm - 1) / p.xm) * ((p.tiles_n + p.xn - 1) / p.xn);
-    p.gm = g_gm > 0 ? g_gm : 8;   // tools/bench_gm.py: 8 is best or within 1 % on every multi-round shape
-  }
+  const int grid = plan_grid(p, BM, BN, g_xcd_2d, g_gm);
   constexpr int NW = WM * WN;
   const size_t lds = (size_t)NSTAGE * (BM + (BN + 8 * NW - 1) / (8 * NW) * (8 * NW)) * 128;
+  // the LDS opt-in is a per-device function attribute: cache it per device (a VAE on a second GPU needs its own call)
+  auto reserve = [&](const void* k, hipError_t* attr, bool* done) -> hipError_t {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    dev &= 15;
+    if (!done[dev]) {
+      attr[dev] = lds > 65536 ? hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) : hipSuccess;
+      done[dev] = true;
+    }
+    return attr[dev];
+  };
   if (a_mode == SX_A_LINEAR) {
     auto k = gemm_kernel<TT, BM, BN, WM, WN, NSTAGE, SX_A_LINEAR>;
-    static const hipError_t attr = lds > 65536 ? hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) : hipSuccess;
-    SX_CHECK(attr == hipSuccess, "sx_gemm: cannot reserve %zu B of LDS for the %dx%d tile: %s", lds, BM, BN, hipGetErrorString(attr));
+    static hipError_t attr[16];
+    static bool done[16];
+    const hipError_t e = reserve((const void*)k, attr, done);
+    SX_CHECK(e == hipSuccess, "sx_gemm: cannot reserve %zu B of LDS for the %dx%d tile: %s", lds, BM, BN, hipGetErrorString(e));
     hipLaunchKernelGGL(k, dim3(grid), dim3(NW * 64), lds, st, p);
   } else {
     auto k = gemm_kernel<TT, BM, BN, WM, WN, NSTAGE, SX_A_CONV3X3>;
-    static const hipError_t attr = lds > 65536 ? hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) : hipSuccess;
-    SX_CHECK(attr == hipSuccess, "sx_gemm: cannot reserve %zu B of LDS for the %dx%d tile: %s", lds, BM, BN, hipGetErrorString(attr));
+    static hipError_t attr[16];
+    static bool done[16];
+    const hipError_t e = reserve((const void*)k, attr, done);
+    SX_CHECK(e == hipSuccess, "sx_gemm: cannot reserve %zu B of LDS for the %dx%d tile: %s", lds, BM, BN, hipGetErrorString(e));
     hipLaunchKernelGGL(k, dim3(grid), dim3(NW * 64), lds, st, p);
   }
   SX_HIP_LAUNCH_CHECK();
@@ -418,6 +389,7 @@ inline int pick_tile(int M, int N, int K, bool glu, bool conv, int force) {
 using namespace sxk_gemm;
 
 static int g_force_tile = -1;
+namespace sxk_gemm { int g_use_pp = 1; }  // 0 = lock-step kernels only (A/B hook, sx_gemm_force_tile(200))
 extern "C" int sx_gemm_pick_tile(int M, int N, int K, int glu, int conv) {  // host-only: which tile config sx_gemm would use
   return sxk_gemm::pick_tile(M, N, K, glu != 0, conv != 0, -1);
 }
@@ -430,6 +402,8 @@ extern "C" int sx_gemm_debug_stamps(void* buf) {   // tuning hook: device buffer
 extern "C" int sx_gemm_force_tile(int cfg) {  // tuning / test hook: -1 = automatic; 100/101 = 2-D XCD partition off/on
   if (cfg == 100 || cfg == 101) { sxk_gemm::g_xcd_2d = cfg - 100; return SX_OK; }
   if (cfg >= 300 && cfg <= 364) { sxk_gemm::g_gm = cfg - 300; return SX_OK; }
+  if (cfg >= 400 && cfg <= 409) { sxk_gemm::g_pp_variant = cfg - 400; return SX_OK; }
+  if (cfg == 200 || cfg == 201) { sxk_gemm::g_use_pp = cfg - 200; return SX_OK; }
   g_force_tile = cfg;
   return SX_OK;
 }
@@ -479,7 +453,21 @@ extern "C" int sx_gemm(const sx_gemm_args* a, void* stream) {
   p.a_bytes = (unsigned)a_bytes;
   p.w_bytes = (unsigned)w_bytes;
   hipStream_t st = (hipStream_t)stream;
-  const int cfg = pick_tile(a->M, a->N, a->K, a->glu != 0, a->a_mode == SX_A_CONV3X3, g_force_tile);
+  p.res_init = (p.residual && p.act == SX_ACT_NONE && !p.glu) ? 1 : 0;
+  // tile configs 0..6: lock-step kernels (this file); 7 / 8: ping-pong 256x256 / 256x320 (gemm_pp.hip). The cost model
+  // ranks the lock-step menu; where it picks a 256-row 8-wave tile, the ping-pong kernel of the same shape runs instead
+  // when its epilogue combination exists (forced 4 / 5 keep the lock-step kernels for A/B runs).
+  int cfg = g_force_tile;
+  if (cfg == 7 || cfg == 8) {
+    const int bn = cfg == 7 ? 256 : 320;
+    SX_CHECK(pp_supported(p, a->dtype, bn, a->a_mode), "sx_gemm: forced ping-pong tile has no kernel for this epilogue");
+    return launch_pp(p, a->dtype, bn, a->a_mode, st);
+  }
+  cfg = pick_tile(a->M, a->N, a->K, a->glu != 0, a->a_mode == SX_A_CONV3X3, g_force_tile);
+  if (g_force_tile < 0 && g_use_pp && (cfg == 4 || cfg == 5)) {
+    const int bn = cfg == 4 ? 256 : 320;
+    if (pp_supported(p, a->dtype, bn, a->a_mode)) return launch_pp(p, a->dtype, bn, a->a_mode, st);
+  }
 #define SX_GEMM_DISPATCH(TT)                                                  \
   switch (cfg) {                                                              \
     case 0: return launch_cfg<TT, 128, 128, 2, 2, 2>(p, a->a_mode, st);       \

@@ -1,0 +1,93 @@
+// Shared between the two GEMM translation units (gemm.hip: lock-step tiles + dispatch, gemm_pp.hip: ping-pong 256-row tiles).
+#pragma once
+#include "sx_common.h"
+
+namespace sxk_gemm {
+
+struct GemmP {
+  const void* A;
+  const void* W;
+  void* C;
+  const float* bias;
+  const float* bias2d;
+  const float* residual;
+  int M, N, K, ldc, ldr, n_valid, res_mod, bias2d_rows, out_dtype, act, glu;
+  int Hin, Win, Cin, Hout, Wout, stride, upsample, ldb2, pad;
+  int tiles_m, tiles_n, xm, xn;   // tile grid and its XCD partition (xm x xn == 8, or 0 = linear remap)
+  int gm;                         // tile-rows per group of the in-XCD traversal
+  int res_init;                   // residual is the accumulators' initial value (act == none, no GLU): no epilogue loads
+  int n_tiles;                    // persistent kernels: logical grid size (blocks loop bid += gridDim.x)
+  unsigned a_bytes, w_bytes;
+  unsigned long long* dbg;        // tuning hook: per-block s_memtime stamps [block][4] = start, first tile landed, main loop done, end
+};
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// Tile → XCD mapping. Block b is observed on XCD b % 8 (performance heuristic only). Each XCD gets a compact
+// (tiles_m/xm) x (tiles_n/xn) rectangle of the tile grid, so its private L2 holds A-panel/xm + W-panel/xn instead of
+// re-streaming whole panels from Infinity Cache / HBM (PMC: profiles/r1_pmc_hbm.json). Returns false for the padding
+// blocks of an uneven split.
+__device__ __forceinline__ bool tile_coords(const GemmP& p, int bid, int nblk, int& tile_m, int& tile_n) {
+  if (p.xm == 0) {
+    const int t = xcd_remap(bid, nblk);
+    tile_m = t % p.tiles_m;
+    tile_n = t / p.tiles_m;
+    return true;
+  }
+  const int xcd = bid & 7, idx = bid >> 3;
+  const int xr = xcd / p.xn, xc = xcd - xr * p.xn;
+  const int ms = xr * p.tiles_m / p.xm, me = (xr + 1) * p.tiles_m / p.xm;
+  const int ns = xc * p.tiles_n / p.xn, ne = (xc + 1) * p.tiles_n / p.xn;
+  const int rm = me - ms, rn = ne - ns;
+  if (idx >= rm * rn) return false;
+  // grouped order inside the rectangle: the ~32 blocks resident on an XCD at one time form a gm x (32/gm) patch (not a
+  // 32 x 1 column), and consecutive rounds keep the same gm A tile-rows while sweeping n → per round the XCD's L2 pulls
+  // gm + 32/gm operand tile-rows instead of 33 (PMC: FETCH_SIZE of the GEGLU GEMM 8.8x → see profiles/r1_pmc_summary.json)
+  const int per_group = p.gm * rn;
+  const int g = idx / per_group, first = g * p.gm;
+  const int gsz = (rm - first) < p.gm ? (rm - first) : p.gm;
+  const int r = idx - g * per_group;
+  tile_m = ms + first + r % gsz;
+  tile_n = ns + r / gsz;
+  return true;
+}
+
+// host side: fill tiles_m/tiles_n/xm/xn/gm for a BM x BN tiling; returns the launch grid
+inline int plan_grid(GemmP& p, int BM, int BN, int xcd_2d, int gm_force) {
+  p.tiles_m = (p.M + BM - 1) / BM;
+  p.tiles_n = (p.N + BN - 1) / BN;
+  int grid = p.tiles_m * p.tiles_n;
+  p.xm = p.xn = 0;
+  p.gm = 1;
+  if (grid >= 16 && xcd_2d) {
+    // choose the 8-way split that minimises fabric traffic  A_bytes * xn + W_bytes * xm  among the least padded ones
+    const double ab = (double)p.M * p.K, wb = (double)p.N * p.K;
+    double best = 1e300;
+    for (int xm = 1; xm <= 8; xm *= 2) {
+      const int xn = 8 / xm;
+      if (xm > p.tiles_m || xn > p.tiles_n) continue;
+      const long padded = 8L * ((p.tiles_m + xm - 1) / xm) * ((p.tiles_n + xn - 1) / xn);
+      const double cost = (ab * xn + wb * xm) * (1.0 + 4.0 * (double)(padded - grid) / grid);
+      if (cost < best) { best = cost; p.xm = xm; p.xn = xn; }
+    }
+    if (p.xm) grid = 8 * ((p.tiles_m + p.xm - 1) / p.xm) * ((p.tiles_n + p.xn - 1) / p.xn);
+    p.gm = gm_force > 0 ? gm_force : 8;   // tools/bench_gm.py: 8 is best or within 1 % on every multi-round shape
+  }
+  p.n_tiles = grid;
+  return grid;
+}
+
+// ping-pong tiles (gemm_pp.hip). bn = 256 | 320. Returns SX_OK, or -1 when the epilogue combination is not instantiated
+// (caller falls back to the lock-step kernel).
+int launch_pp(const GemmP& p, int dtype, int bn, int a_mode, hipStream_t st);
+bool pp_supported(const GemmP& p, int dtype, int bn, int a_mode);
+
+extern unsigned long long* g_dbg;
+extern int g_gm;
+extern int g_xcd_2d;
+extern int g_pp_variant;   // tuning hook (sx_gemm_force_tile 4xx)
+
+}  // namespace sxk_gemm
