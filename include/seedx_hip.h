@@ -80,13 +80,15 @@ typedef struct sx_gemm_args {
                        padding=0 + F.pad(x, (0,1,0,1)): the stride-2 convs of the VAE encoder [ext])                 */
 } sx_gemm_args;
 int sx_gemm(const sx_gemm_args* args, void* stream);
-/* tuning/test hook: force tile config 0..6 (128x128, 128x80, 64x128, 64x64, 256x256, 256x320, 256x160); -1 = automatic
- * (cost model); 100/101 = 2-D XCD partition off/on; 300+g = g tile-rows per in-XCD traversal group (300 = default) */
+/* tuning/test hook: force tile config 0..8 (lock-step 128x128, 128x80, 64x128, 64x64, 256x256, 256x320, 256x160; ping-pong
+ * 256x256, 256x320 — the two-wave-group schedule of csrc/gemm_pp.hip); -1 = automatic (cost model); 100/101 = 2-D XCD
+ * partition off/on; 200/201 = ping-pong tiles excluded from / offered to the cost model; 300+g = g tile-rows per in-XCD
+ * traversal group (300 = default); 400+v = ping-pong schedule variant v (A/B builds of the bf16 256x256 linear kernel) */
 int sx_gemm_force_tile(int cfg);
 /* tuning hook: `buf` = device buffer of 4 x uint64 per workgroup; following sx_gemm launches store s_memtime stamps
  * {start, first k-tile landed, main loop done, end} per workgroup (tools/gemm_phase_probe.py). NULL switches it off. */
 int sx_gemm_debug_stamps(void* buf);
-/* host-only query (no launch): tile config 0..6 the cost model picks for an M x N x K problem (glu / conv3x3 flags) */
+/* host-only query (no launch): tile config 0..8 the cost model picks for an M x N x K problem (glu / conv3x3 flags) */
 int sx_gemm_pick_tile(int M, int N, int K, int glu, int conv);
 
 /* 1..16-row GEMV for single-token decode of up to 16 lock-step sequences (HBM-bound weight streaming).

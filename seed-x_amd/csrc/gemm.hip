@@ -363,19 +363,23 @@ int launch_cfg(const GemmP& p0, int a_mode, hipStream_t st) {
 // 0.1 % (conv) of the per-shape best config on the re-run of that sweep with the final kernels (worst shape 9 %); the N = k*320 channel counts of the SDXL UNet are why the
 // 256x320 / 256x160 tiles exist (they split N without a ragged last tile and land on whole rounds of 256 tiles).
 struct TileCfg { int bm, bn; bool glu_ok; int slots; float a_lin, b_lin, a_conv, b_conv; };
-static const int kNumTiles = 7;
+static const int kNumTiles = 9;   // 0..6 lock-step kernels (this file), 7 / 8 ping-pong 256x256 / 256x320 (gemm_pp.hip)
 static const TileCfg kTiles[kNumTiles] = {
-    {128, 128, true, 512, 9.50f, 0.00979f, 13.66f, 0.01376f},  {128, 80, false, 256, 3.99f, 0.00725f, 3.79f, 0.01106f},
-    {64, 128, true, 256, 1.70f, 0.00476f, 0.10f, 0.00568f},    {64, 64, true, 256, 0.58f, 0.00337f, 0.10f, 0.00360f},
-    {256, 256, true, 256, 13.61f, 0.01984f, 16.43f, 0.02363f}, {256, 320, false, 256, 20.69f, 0.02429f, 25.02f, 0.02848f},
-    {256, 160, false, 256, 9.60f, 0.01534f, 13.43f, 0.01882f}};
+    // round 3 fit (tools/lab/gemm_lab model → tools/fit_tile_model.py, profiles/r3_tile_model.jsonl): argmin of the model
+    // is within 0.2 % of the per-shape best config summed over the sweep (worst shape 8 %)
+    {128, 128, true, 512, 7.85f, 0.01202f, 15.26f, 0.01513f},  {128, 80, false, 256, 3.45f, 0.00766f, 3.59f, 0.01135f},
+    {64, 128, true, 256, 1.37f, 0.00479f, 1.63f, 0.00546f},    {64, 64, true, 256, 0.33f, 0.00301f, 0.82f, 0.00313f},
+    {256, 256, true, 256, 11.34f, 0.02161f, 13.19f, 0.02365f}, {256, 320, false, 256, 17.95f, 0.02566f, 18.01f, 0.02985f},
+    {256, 160, false, 256, 8.13f, 0.01579f, 9.06f, 0.01897f},  {256, 256, true, 256, 10.56f, 0.01592f, 12.81f, 0.01840f},
+    {256, 320, false, 256, 13.32f, 0.01928f, 15.12f, 0.02173f}};
 
-inline int pick_tile(int M, int N, int K, bool glu, bool conv, int force) {
+inline int pick_tile(int M, int N, int K, bool glu, bool conv, int force, unsigned allow = 0x7f) {
   if (force >= 0 && force < kNumTiles && (!glu || kTiles[force].glu_ok)) return force;
   int best = 2;
   float best_t = 1e30f;
   for (int c = 0; c < kNumTiles; ++c) {
     const TileCfg& t = kTiles[c];
+    if (!((allow >> c) & 1u)) continue;
     if (glu && !t.glu_ok) continue;
     const long tiles = (long)((M + t.bm - 1) / t.bm) * ((N + t.bn - 1) / t.bn);
     const long rounds = (tiles + t.slots - 1) / t.slots;
@@ -391,7 +395,7 @@ using namespace sxk_gemm;
 static int g_force_tile = -1;
 namespace sxk_gemm { int g_use_pp = 1; }  // 0 = lock-step kernels only (A/B hook, sx_gemm_force_tile(200))
 extern "C" int sx_gemm_pick_tile(int M, int N, int K, int glu, int conv) {  // host-only: which tile config sx_gemm would use
-  return sxk_gemm::pick_tile(M, N, K, glu != 0, conv != 0, -1);
+  return sxk_gemm::pick_tile(M, N, K, glu != 0, conv != 0, -1, 0x1ff);
 }
 
 extern "C" int sx_gemm_debug_stamps(void* buf) {   // tuning hook: device buffer of 4 x uint64 per block, or NULL to switch off
@@ -457,17 +461,15 @@ extern "C" int sx_gemm(const sx_gemm_args* a, void* stream) {
   // tile configs 0..6: lock-step kernels (this file); 7 / 8: ping-pong 256x256 / 256x320 (gemm_pp.hip). The cost model
   // ranks the lock-step menu; where it picks a 256-row 8-wave tile, the ping-pong kernel of the same shape runs instead
   // when its epilogue combination exists (forced 4 / 5 keep the lock-step kernels for A/B runs).
-  int cfg = g_force_tile;
-  if (cfg == 7 || cfg == 8) {
-    const int bn = cfg == 7 ? 256 : 320;
-    SX_CHECK(pp_supported(p, a->dtype, bn, a->a_mode), "sx_gemm: forced ping-pong tile has no kernel for this epilogue");
-    return launch_pp(p, a->dtype, bn, a->a_mode, st);
-  }
-  cfg = pick_tile(a->M, a->N, a->K, a->glu != 0, a->a_mode == SX_A_CONV3X3, g_force_tile);
-  if (g_force_tile < 0 && g_use_pp && (cfg == 4 || cfg == 5)) {
-    const int bn = cfg == 4 ? 256 : 320;
-    if (pp_supported(p, a->dtype, bn, a->a_mode)) return launch_pp(p, a->dtype, bn, a->a_mode, st);
-  }
+  // tile configs 0..6: lock-step kernels (this file); 7 / 8: ping-pong 256x256 / 256x320 (gemm_pp.hip), offered to the cost
+  // model when their epilogue combination is instantiated
+  unsigned allow = 0x7f;
+  if (g_use_pp || g_force_tile == 7) allow |= pp_supported(p, a->dtype, 256, a->a_mode) ? 0x80u : 0u;
+  if (g_use_pp || g_force_tile == 8) allow |= pp_supported(p, a->dtype, 320, a->a_mode) ? 0x100u : 0u;
+  SX_CHECK(!(g_force_tile == 7 || g_force_tile == 8) || ((allow >> g_force_tile) & 1u),
+           "sx_gemm: forced ping-pong tile has no kernel for this epilogue");
+  const int cfg = pick_tile(a->M, a->N, a->K, a->glu != 0, a->a_mode == SX_A_CONV3X3, g_force_tile, allow);
+  if (cfg == 7 || cfg == 8) return launch_pp(p, a->dtype, cfg == 7 ? 256 : 320, a->a_mode, st);
 #define SX_GEMM_DISPATCH(TT)                                                  \
   switch (cfg) {                                                              \
     case 0: return launch_cfg<TT, 128, 128, 2, 2, 2>(p, a->a_mode, st);       \

@@ -629,8 +629,10 @@ def test_gemm_tile_picker_host_logic():
     through the C-ABI query, without launching anything."""
     from seedx_amd import _lib
     lib = _lib.load()
-    names = ["128x128", "128x80", "64x128", "64x64", "256x256", "256x320", "256x160"]
+    # 7 / 8 = the ping-pong schedule (csrc/gemm_pp.hip) of the 256x256 / 256x320 tiles
+    names = ["128x128", "128x80", "64x128", "64x64", "256x256", "256x320", "256x160", "256x256", "256x320"]
     pick = lambda M, N, K, glu=0, conv=0: names[lib.sx_gemm_pick_tile(M, N, K, glu, conv)]
+    assert lib.sx_gemm_pick_tile(32768, 3840, 1280, 0, 0) == 8 and lib.sx_gemm_pick_tile(32768, 10240, 1280, 1, 0) == 7
     # SDXL channel counts are k*320: whole rounds of 256 tiles beat the ragged 256x256 grid
     assert pick(16384, 1280, 1280) == "256x320"          # 64 x 4 = 256 tiles = one round
     assert pick(8192, 1280, 1280) == "256x160"           # 32 x 8 = 256 tiles
@@ -646,4 +648,4 @@ def test_gemm_tile_picker_host_logic():
     assert pick(262144, 320, 2880, conv=1) == "256x320"
     assert pick(32768, 320, 2880, conv=1) == "256x160"
     for M, N, K in [(1, 64, 64), (7, 5120, 5120), (1000000, 128, 1152)]:
-        assert 0 <= lib.sx_gemm_pick_tile(M, N, K, 0, 0) <= 6
+        assert 0 <= lib.sx_gemm_pick_tile(M, N, K, 0, 0) <= 8

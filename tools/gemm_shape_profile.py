@@ -64,7 +64,7 @@ def main():
         g[2] += fl
         g[3] += byt
     tot = sum(g[1] for g in groups.values())
-    names = ["128x128", "128x80", "64x128", "64x64", "256x256", "256x320", "256x160"]
+    names = ["128x128", "128x80", "64x128", "64x64", "256x256", "256x320", "256x160", "pp256x256", "pp256x320"]
     rows = sorted(groups.items(), key=lambda kv: -kv[1][1])
     print("GEMM family: %d launches, %.3f s per step (UNet steps %d, batch %d) — %.0f TFLOP/s overall"
           % (len(rec), tot, a.unet_steps, a.batch, sum(g[2] for g in groups.values()) / tot / 1e12))
