@@ -150,11 +150,6 @@ int sx_groupnorm_sp(const float* x, const float* x2, int C1, void* y, void* raw1
 /* ------------------------------------------------------------------------------------------------
  * Attention
  * ------------------------------------------------------------------------------------------------ */
-/* Vt[b][h][d][kv] (kv padded to kv_pad, zero filled) = V[b][kv][h][d]. NOT needed by sx_attention any more (round 2: the
- * kernel reads row-major V and transposes with ds_read_b64_tr_b16); kept as a utility. */
-int sx_transpose_v(const void* V, void* Vt, int B, int H, int Skv, int D, int kv_pad, int64_t v_batch_stride,
-                   int64_t v_row_stride, int64_t v_head_stride, void* stream);
-
 /* Flash-style fused attention on MFMA (online softmax in fp32, LDS-staged K / V^T tiles).
  * replaces: bmm→softmax→bmm (qwen_visual.py:204-215), nn.MultiheadAttention core (qwen_visual.py:145),
  *           xformers memory_efficient_attention (modeling_llama_xformer.py:221-238),

@@ -67,7 +67,6 @@ SIGNATURES = {
     "sx_groupnorm2": [c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_i32, c_vp],
     "sx_groupnorm_sp": [c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_i32,
                         c_i32, c_vp],
-    "sx_transpose_v": [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64, c_i64, c_i64, c_vp],
     "sx_attention": [C.POINTER(AttnArgs), c_vp],
     "sx_attention_small": [C.POINTER(AttnSmallArgs), c_vp],
     "sx_attn_decode": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_i32, c_vp],

@@ -1,8 +1,8 @@
-// Fused attention for gfx950 (MI355X): flash-style MFMA kernel + V^T pre-pass + small generic VALU kernel.
+// Fused attention for gfx950 (MI355X): flash-style MFMA kernel + small generic VALU kernel.
 //
 // MFMA kernel:
 //   * block = 4 waves, 128 query rows (32 per wave); KV tile = 64 keys; 2-stage LDS ring filled by
-//     `buffer_load_dwordx4 … lds` DMA (K tile [64][DP], V^T tile [DP][64]); one barrier per KV tile
+//     `buffer_load_dwordx4 … lds` DMA (K tile [64][DP], V tile [64][DP], both row-major); one barrier per KV tile
 //   * S^T = K · Q^T with v_mfma_f32_32x32x16: the lane that owns query q = lane&31 holds 16 of the 32
 //     scores of a key block in registers → row max / row sum are lane-local plus ONE lane^32 exchange
 //   * O^T = V^T · P^T reuses the score registers directly as the MFMA B operand: the contraction order
@@ -276,29 +276,6 @@ __global__ __launch_bounds__(256, (DP <= 64 ? 4 : 1)) void attn_kernel(const Att
 #endif
 }
 
-// V[b][kv][h][d] (strided) -> Vt[b][h][d][kv_pad], zero padded along kv
-__global__ __launch_bounds__(256) void transpose_v_kernel(const unsigned short* V, unsigned short* Vt, int H, int Skv,
-                                                          int D, int kv_pad, long long vbs, long long vrs,
-                                                          long long vhs) {
-  __shared__ unsigned short tile[64][258];
-  const int kv0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
-  const unsigned short* Vb = V + b * vbs + h * vhs;
-  for (int idx = threadIdx.x; idx < 64 * (D / 2); idx += 256) {
-    const int r = idx / (D / 2), c2 = idx % (D / 2);
-    unsigned v = 0;
-    if (kv0 + r < Skv) v = *(const unsigned*)(Vb + (long long)(kv0 + r) * vrs + 2 * c2);
-    tile[r][2 * c2] = (unsigned short)(v & 0xffff);
-    tile[r][2 * c2 + 1] = (unsigned short)(v >> 16);
-  }
-  __syncthreads();
-  unsigned short* Ob = Vt + ((long long)(b * H + h) * D) * kv_pad + kv0;
-  for (int idx = threadIdx.x; idx < D * 32; idx += 256) {
-    const int d = idx >> 5, kp = idx & 31;
-    const unsigned w = (unsigned)tile[2 * kp][d] | ((unsigned)tile[2 * kp + 1][d] << 16);
-    *(unsigned*)(Ob + (long long)d * kv_pad + 2 * kp) = w;
-  }
-}
-
 // ---- small generic attention: one wave per (b, h, q) row; scores staged in LDS ------------------------------
 struct AttnSmallP {
   const unsigned short* Q;
@@ -368,19 +345,6 @@ __global__ __launch_bounds__(256) void attn_small_kernel(const AttnSmallP p) {
 
 }  // namespace sxk_attn
 using namespace sxk_attn;
-
-extern "C" int sx_transpose_v(const void* V, void* Vt, int B, int H, int Skv, int D, int kv_pad,
-                              int64_t v_batch_stride, int64_t v_row_stride, int64_t v_head_stride, void* stream) {
-  SX_CHECK(V && Vt, "sx_transpose_v: null pointer");
-  SX_CHECK(D % 2 == 0 && D <= 256 && kv_pad % 64 == 0 && kv_pad >= Skv, "sx_transpose_v: D=%d kv_pad=%d Skv=%d", D,
-           kv_pad, Skv);
-  SX_CHECK(v_row_stride % 2 == 0 && v_head_stride % 2 == 0 && v_batch_stride % 2 == 0, "sx_transpose_v: odd stride");
-  hipLaunchKernelGGL(transpose_v_kernel, dim3(kv_pad / 64, H, B), dim3(256), 0, (hipStream_t)stream,
-                     (const unsigned short*)V, (unsigned short*)Vt, H, Skv, D, kv_pad, (long long)v_batch_stride,
-                     (long long)v_row_stride, (long long)v_head_stride);
-  SX_HIP_LAUNCH_CHECK();
-  return SX_OK;
-}
 
 extern "C" int sx_attention(const sx_attn_args* a, void* stream) {
   SX_CHECK(a && a->Q && a->K && a->V && a->O, "sx_attention: null pointer");

@@ -466,7 +466,8 @@ extern "C" int sx_gemv(const sx_gemv_args* a, void* stream) {
   // MI355X (tools/bench_gemv.py, 13B shapes): VALU path 6.5 / 4.7 / 3.0 TB/s at M = 1 / 4 / 8, MFMA path 4.0-4.4 TB/s at any M
   const bool mfma_ok = a->M >= 2 && a->K % 64 == 0 && a->K >= 256 && a->N % 32 == 0;
   SX_CHECK(!a->w_layout || (mfma_ok && a->K % 64 == 0), "sx_gemv: the decode-tile layout needs M >= 2, K %% 64 == 0, K >= 256, N %% 32 == 0");
-  if (mfma_ok && g_force_valu_gemv != 1 && (a->M >= 5 || g_force_valu_gemv == 2 || a->w_layout)) {
+  // the decode-tile layout only exists for the MFMA kernel: it overrides the VALU test hook
+  if (mfma_ok && (a->w_layout || (g_force_valu_gemv != 1 && (a->M >= 5 || g_force_valu_gemv == 2)))) {
     // MFMA skinny GEMM: R = 2 row groups per wave for GLU (one packed group) or when that still gives >= 256 blocks
     const bool r2 = a->glu || a->N / 32 >= 256;
     const dim3 grid(r2 ? a->N / 32 : a->N / 16), block(256);
@@ -479,6 +480,7 @@ extern "C" int sx_gemv(const sx_gemv_args* a, void* stream) {
     return SX_OK;
   }
   SX_CHECK(a->M <= 8, "sx_gemv: M=%d > 8 needs K %% 64 == 0 and N %% 32 == 0 (MFMA path)", a->M);
+  SX_CHECK(p.packed == 0, "sx_gemv: the VALU kernel reads row-major weights only");
   const int pairs = (a->N + 1) / 2;
   const dim3 grid((pairs + 3) / 4), block(256);
   const int mr = a->M == 1 ? 1 : (a->M == 2 ? 2 : (a->M <= 4 ? 4 : 8));

@@ -72,6 +72,7 @@ class LlamaForCausalLM:
         self.device, self.dtype = None, torch.float16
         self._sd, self._P = None, None
         self._graph = None
+        self.kv_epoch = 0               # bumped whenever the KV cache is reset or written outside generate_batch
 
     # ---- reference-compatible plumbing ---------------------------------------------------------------------
     @classmethod
@@ -185,6 +186,7 @@ class LlamaForCausalLM:
     # ---- core passes ---------------------------------------------------------------------------------------------------
     def reset(self, seq=None):
         P = self._pack()
+        self.kv_epoch += 1              # invalidates ContinuousLVLM's cross-turn prefix bookkeeping
         s = slice(None) if seq is None else slice(seq, seq + 1)
         P["pos"][s] = 0
         P["step"][s] = 0
@@ -273,6 +275,7 @@ class LlamaForCausalLM:
         """inputs_embeds: fp32 [T, H] on the GPU, appended to sequence `seq` at its current cache position.
         Returns (logits fp32 [Vpad] of the LAST position or None, final-norm hidden states fp32 [T, H])."""
         P = self._pack()
+        self.kv_epoch += 1              # a write outside generate_batch: cached-prefix records no longer describe the cache
         x = inputs_embeds.to(device=self.device, dtype=torch.float32).contiguous()
         T = x.shape[0]
         if T == 1 and self.G == 1:

@@ -163,7 +163,10 @@ def gemv(x, w, residual=None, act=None, glu=False, out_dtype=None, w_tiles=None)
 
 def linear(x, w, **kw):
     """Dispatch M <= 16 rows to the weight-streaming GEMV / skinny GEMM (when the epilogue allows), else the MFMA GEMM."""
-    if x.shape[0] <= 16 and kw.get("bias") is None and kw.get("bias2d") is None and not kw.get("res_mod") \
+    M, K, N = x.shape[0], x.shape[1], w.shape[0]
+    # 9..16 rows only exist on the MFMA skinny kernel (K % 64 == 0, K >= 256, N % 32 == 0); other shapes keep the tiled GEMM
+    skinny_ok = M <= 8 or (K % 64 == 0 and K >= 256 and N % 32 == 0)
+    if M <= 16 and skinny_ok and kw.get("bias") is None and kw.get("bias2d") is None and not kw.get("res_mod") \
             and kw.get("out") is None and not kw.get("n_valid"):
         res = kw.get("residual")
         if res is None or res.is_contiguous():
@@ -240,17 +243,6 @@ def softmax_rows(x, scale, out_dtype):
 def _bshd_strides(t):
     assert t.dim() == 4 and t.stride(3) == 1, "expected a [B, S, H, D] view with unit stride on D"
     return t.stride(0), t.stride(1), t.stride(2)
-
-
-def transpose_v(v):
-    """V [B, Skv, H, D] (strided view) → V^T [B, H, D, kv_pad] zero-padded along keys (operand layout of sx_attention)."""
-    lib = _lib.load()
-    B, Skv, H, D = v.shape
-    kv_pad = (Skv + 63) // 64 * 64
-    vt = torch.empty((B, H, D, kv_pad), dtype=v.dtype, device=v.device)
-    vb, vr, vh = _bshd_strides(v)
-    check(lib.sx_transpose_v(_p(v), _p(vt), B, H, Skv, D, kv_pad, vb, vr, vh, _stream()), "sx_transpose_v")
-    return vt
 
 
 def attention(q, k, v, scale, causal=False, out=None):

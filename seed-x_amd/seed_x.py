@@ -29,7 +29,8 @@ class ContinuousLVLM:
         self.device, self.dtype = None, torch.float16
         self.use_graph = True
         self.chunk_forced_image_tokens = True
-        self._conv = {}                  # sequence → (token ids, row fingerprints) currently held by its KV cache
+        self._conv = {}                  # sequence → (token ids, row fingerprints, LLM cache epoch) held by its KV cache
+        self._sig_w = {}
         self.last_prefill_tokens = []
 
     @classmethod
@@ -99,8 +100,15 @@ class ContinuousLVLM:
 
     @torch.no_grad()
     def _row_sig(self, x):
-        """Per-row fingerprint of prompt embeddings (fp32 [T, H]) used to validate a cached prefix bit for bit."""
-        return x.view(torch.int32).sum(dim=1, dtype=torch.int64)
+        """Per-row fingerprint of prompt embeddings (fp32 [T, H]) used to validate a cached prefix: two independent
+        position-weighted sums of the rows' bit patterns (int64 [T, 2]) — a plain sum would not see permuted columns."""
+        bits = x.view(torch.int32).to(torch.int64)
+        w = self._sig_w.get((x.shape[1], x.device))
+        if w is None:
+            gen = torch.Generator().manual_seed(0x5EED)
+            w = (torch.randint(1, 1 << 20, (x.shape[1], 2), generator=gen, dtype=torch.int64) * 2 + 1).to(x.device)
+            self._sig_w[(x.shape[1], x.device)] = w
+        return torch.stack([(bits * w[:, 0]).sum(dim=1), (bits * w[:, 1]).sum(dim=1)], dim=1)
 
     def _reuse_prefix(self, prompts):
         """Cross-turn KV reuse (no reference counterpart: seed_x.py:184-189 re-prefills the whole conversation every turn).
@@ -111,13 +119,15 @@ class ContinuousLVLM:
         for g, (ids, x) in enumerate(prompts):
             prev = self._conv.get(g)
             p = 0
+            if prev is not None and prev[2] != self.llm.kv_epoch:
+                prev = None                      # the cache was reset / written behind our back (llm.reset, llm.forward, ...)
             if prev is not None:
-                old_ids, old_sig = prev
+                old_ids, old_sig, _ = prev
                 m = min(len(old_ids), len(ids) - 1)                                   # >= 1 token must be forwarded
                 while p < m and old_ids[p] == ids[p]:
                     p += 1
                 if p:
-                    same = (self._row_sig(x[:p]) == old_sig[:p]).to(torch.int32)
+                    same = (self._row_sig(x[:p]) == old_sig[:p]).all(dim=1).to(torch.int32)
                     p = int(torch.cumprod(same, 0).sum().item())
             starts.append(p)
         return starts
@@ -130,7 +140,7 @@ class ContinuousLVLM:
             P = self.llm._P
             e = ops.embedding(torch.tensor(gen_ids_fed, dtype=torch.int32, device=x.device), P["embed"])
             sig = torch.cat([sig, self._row_sig(e)])
-        self._conv[g] = (list(ids) + list(gen_ids_fed), sig)
+        self._conv[g] = (list(ids) + list(gen_ids_fed), sig, self.llm.kv_epoch)
 
     @torch.no_grad()
     def generate_batch(self, tokenizer, requests, num_img_gen_tokens=64, max_new_tokens=120, eos_token_id="auto",

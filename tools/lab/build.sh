@@ -8,3 +8,4 @@ for t in gemm_lab; do
       -L"$LIB" -lseedx_hip -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,'$ORIGIN/../../seed-x_amd/lib' -Wl,-rpath,/opt/rocm/lib
 done
 echo "built lab tools in $HERE"
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -Wno-unused-result "$HERE/tile_io_bench.hip" -o "$HERE/tile_io_bench"
