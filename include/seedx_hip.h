@@ -173,6 +173,8 @@ typedef struct sx_attn_args {
   int32_t dtype;
 } sx_attn_args;
 int sx_attention(const sx_attn_args* args, void* stream);
+/* tuning hook (tools/lab/attn_lab): A/B builds of the flash kernel; 0 = shipped */
+int sx_attention_variant(int v);
 
 /* Small generic attention (any D <= 256, VALU, one wave per query row). Used where FLOPs are negligible:
  * Resampler MHA with head_dim 160 (agent_seed_x_i.yaml:2-7), AttentionPool2d (resampler.py:89-116),

@@ -68,6 +68,7 @@ SIGNATURES = {
     "sx_groupnorm_sp": [c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_i32,
                         c_i32, c_vp],
     "sx_attention": [C.POINTER(AttnArgs), c_vp],
+    "sx_attention_variant": [c_i32],
     "sx_attention_small": [C.POINTER(AttnSmallArgs), c_vp],
     "sx_attn_decode": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_i32, c_vp],
     "sx_rope_kv_append": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp],

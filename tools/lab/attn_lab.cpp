@@ -1,0 +1,127 @@
+// Attention lab: sx_attention on the UNet / ViT / LLM shapes through the C-ABI — fp64 spot check, repeatability, timing.
+//   tools/lab/attn_lab [rounds] [variant...]     variants are passed to sx_attention_variant() (0 = shipped kernel)
+// Also the target of the rocprofv3 --pmc passes in tools/lab/attn_pmc.sh (no Python start-up inside the profiled process).
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "../../include/seedx_hip.h"
+
+#define HCHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); exit(2); } } while (0)
+#define SXCHECK(x) do { int r_ = (x); if (r_ != 0) { fprintf(stderr, "sx error %d: %s at line %d\n", r_, sx_last_error(), __LINE__); exit(3); } } while (0)
+
+extern "C" int sx_attention_variant(int v);   // tuning hook (csrc/attn.hip)
+
+static uint64_t rng_state = 0x243F6A8885A308D3ull;
+static inline uint32_t rng() { rng_state ^= rng_state << 13; rng_state ^= rng_state >> 7; rng_state ^= rng_state << 17; return (uint32_t)(rng_state >> 32); }
+static inline float urand() { return (float)(rng() >> 8) * (2.0f / 16777216.0f) - 1.0f; }
+static inline float nrand() { float s = 0; for (int i = 0; i < 6; ++i) s += urand(); return s * 0.7071f; }  // ~N(0,1)
+static inline uint16_t f2bf(float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7fff + ((u >> 16) & 1); return (uint16_t)(u >> 16); }
+static inline float bf2f(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
+
+struct Shape { const char* name; int B, H, Sq, Skv, D, causal; };
+
+int main(int argc, char** argv) {
+  const int rounds = argc > 1 ? atoi(argv[1]) : 5;
+  std::vector<int> variants;
+  for (int i = 2; i < argc; ++i) variants.push_back(atoi(argv[i]));
+  if (variants.empty()) variants.push_back(0);
+  const Shape shapes[] = {{"unet 64^2", 16, 10, 4096, 4096, 64, 0}, {"unet 32^2", 16, 20, 1024, 1024, 64, 0}, {"unet cross", 16, 10, 4096, 64, 64, 0},
+                          {"vit 2 crops", 2, 16, 1024, 1024, 104, 0}, {"llm 2048", 1, 40, 2048, 2048, 128, 1}, {"ragged", 3, 5, 1000, 777, 64, 0}};
+  int bad = 0;
+  for (const Shape& s : shapes) {
+    const size_t nq = (size_t)s.B * s.Sq * s.H * s.D, nk = (size_t)s.B * s.Skv * s.H * s.D;
+    std::vector<uint16_t> hq(nq), hk(nk), hv(nk);
+    for (auto& x : hq) x = f2bf(nrand());
+    for (auto& x : hk) x = f2bf(nrand());
+    for (auto& x : hv) x = f2bf(nrand());
+    void *q, *k, *v, *o;
+    HCHECK(hipMalloc(&q, nq * 2)); HCHECK(hipMalloc(&k, nk * 2)); HCHECK(hipMalloc(&v, nk * 2)); HCHECK(hipMalloc(&o, nq * 2));
+    HCHECK(hipMemcpy(q, hq.data(), nq * 2, hipMemcpyHostToDevice));
+    HCHECK(hipMemcpy(k, hk.data(), nk * 2, hipMemcpyHostToDevice));
+    HCHECK(hipMemcpy(v, hv.data(), nk * 2, hipMemcpyHostToDevice));
+    sx_attn_args a;
+    memset(&a, 0, sizeof(a));
+    a.Q = q; a.K = k; a.V = v; a.O = o;
+    a.B = s.B; a.H = s.H; a.Sq = s.Sq; a.Skv = s.Skv; a.D = s.D;
+    a.q_batch_stride = (int64_t)s.Sq * s.H * s.D; a.q_row_stride = (int64_t)s.H * s.D; a.q_head_stride = s.D;   // [B][S][H][D]
+    a.k_batch_stride = (int64_t)s.Skv * s.H * s.D; a.k_row_stride = a.q_row_stride; a.k_head_stride = s.D;
+    a.v_batch_stride = a.k_batch_stride; a.v_row_stride = a.q_row_stride; a.v_head_stride = s.D;
+    a.o_batch_stride = a.q_batch_stride; a.o_row_stride = a.q_row_stride;
+    a.scale = 1.0f / sqrtf((float)s.D); a.causal = s.causal; a.dtype = SX_BF16;
+    const double flops = 4.0 * s.B * s.H * (double)s.Sq * s.Skv * s.D * (s.causal ? 0.5 : 1.0);
+    printf("== %-12s B%d H%d Sq%d Skv%d D%d causal%d\n", s.name, s.B, s.H, s.Sq, s.Skv, s.D, s.causal);
+    std::vector<uint16_t> ho(nq), ho2(nq);
+    for (int var : variants) {
+      SXCHECK(sx_attention_variant(var));
+      HCHECK(hipMemset(o, 0xff, nq * 2));
+      SXCHECK(sx_attention(&a, nullptr));
+      HCHECK(hipDeviceSynchronize());
+      HCHECK(hipMemcpy(ho.data(), o, nq * 2, hipMemcpyDeviceToHost));
+      // fp64 spot check of 24 random (b, h, q) rows
+      double worst = 0;
+      for (int t = 0; t < 24; ++t) {
+        const int b = rng() % s.B, h = rng() % s.H, qi = rng() % s.Sq;
+        const int kmax = s.causal ? qi + (s.Skv - s.Sq) : s.Skv - 1;
+        std::vector<double> sc(kmax + 1);
+        double mx = -1e300;
+        for (int j = 0; j <= kmax; ++j) {
+          double d = 0;
+          for (int e = 0; e < s.D; ++e)
+            d += (double)bf2f(hq[((size_t)(b * s.Sq + qi) * s.H + h) * s.D + e]) * (double)bf2f(hk[((size_t)(b * s.Skv + j) * s.H + h) * s.D + e]);
+          sc[j] = d * a.scale;
+          mx = std::max(mx, sc[j]);
+        }
+        double den = 0;
+        for (int j = 0; j <= kmax; ++j) { sc[j] = exp(sc[j] - mx); den += sc[j]; }
+        for (int e = 0; e < s.D; ++e) {
+          double acc = 0;
+          for (int j = 0; j <= kmax; ++j) acc += sc[j] * (double)bf2f(hv[((size_t)(b * s.Skv + j) * s.H + h) * s.D + e]);
+          acc /= den;
+          const double got = bf2f(ho[((size_t)(b * s.Sq + qi) * s.H + h) * s.D + e]);
+          worst = std::max(worst, fabs(got - acc));
+        }
+      }
+      // repeatability
+      size_t rep_bad = 0;
+      for (int r = 0; r < 3; ++r) {
+        SXCHECK(sx_attention(&a, nullptr));
+        HCHECK(hipDeviceSynchronize());
+        HCHECK(hipMemcpy(ho2.data(), o, nq * 2, hipMemcpyDeviceToHost));
+        if (memcmp(ho.data(), ho2.data(), nq * 2) != 0) rep_bad++;
+      }
+      const bool ok = worst < 2e-2 && rep_bad == 0;   // |O| <= ~3 with N(0,1) values; bf16 P and O rounding
+      printf("   variant %d: max |O - fp64| over 24 rows %.3e, %zu non-repeating launches → %s\n", var, worst, rep_bad, ok ? "ok" : "BAD");
+      if (!ok) bad++;
+    }
+    hipEvent_t e0, e1;
+    HCHECK(hipEventCreate(&e0)); HCHECK(hipEventCreate(&e1));
+    const int iters = std::max(3, (int)(1.5e12 / flops));
+    std::vector<std::vector<double>> us(variants.size());
+    for (int r = 0; r < rounds + 1; ++r)
+      for (size_t vi = 0; vi < variants.size(); ++vi) {
+        SXCHECK(sx_attention_variant(variants[vi]));
+        HCHECK(hipEventRecord(e0, nullptr));
+        for (int it = 0; it < iters; ++it) SXCHECK(sx_attention(&a, nullptr));
+        HCHECK(hipEventRecord(e1, nullptr));
+        HCHECK(hipEventSynchronize(e1));
+        float ms;
+        HCHECK(hipEventElapsedTime(&ms, e0, e1));
+        if (r > 0) us[vi].push_back(ms * 1e3 / iters);
+      }
+    for (size_t vi = 0; vi < variants.size(); ++vi) {
+      std::sort(us[vi].begin(), us[vi].end());
+      const double m = us[vi][us[vi].size() / 2];
+      printf("   variant %d: median %9.1f us  %7.1f TF   (best %9.1f us)\n", variants[vi], m, flops / m * 1e-6, us[vi][0]);
+    }
+    fflush(stdout);
+    (void)hipFree(q); (void)hipFree(k); (void)hipFree(v); (void)hipFree(o);
+  }
+  SXCHECK(sx_attention_variant(0));
+  printf("%s: %d failing checks\n", bad ? "ATTN LAB FAILED" : "ATTN LAB OK", bad);
+  return bad ? 1 : 0;
+}
