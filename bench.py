@@ -376,87 +376,229 @@ class Pipeline:
         return out
 
 
-def gemm_roofline(w):
-    """Instrumented (eager, un-graphed) step with HIP events around EVERY sx_gemm launch on the launch stream: per-launch
-    algorithmic FLOPs (2·M·N·K, conv: 2·M·N·9·Cin; K ÷ 3 for the fp32-grade VAE's plane-carrying launches) and duration. The GEMM/implicit-conv kernel family is the dominant
-    kernel (≈85 % of algorithmic FLOPs)."""
+PEAK_HBM_GBPS = 8000.0       # HBM3E peak (spec), MI355X_MICROARCH.md
+
+
+def _kernel_source_sha():
+    """Hash of the GEMM kernel sources: a stored PMC traffic profile is only quoted while these files are unchanged."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("gemm.hip", "gemm_pp.hip", "gemm_common.h", "sx_common.h"):
+        with open(os.path.join(ROOT, "seed-x_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def measure_roofline(w):
+    """Instrumented (eager, un-graphed, ONE kernel chain) step with HIP events on the launch stream around EVERY sx_gemm,
+    sx_gemv and sx_attention launch, and around every phase of the step (ViT / prefill / decode / UNet loop / VAE):
+      * per launch: algorithmic FLOPs (2·M·N·K, conv 2·M·N·9·Cin; K ÷ 3 for the fp32-grade VAE's plane-carrying launches;
+        attention 4·Sq·Skv·D per head) and algorithmic bytes (operands once + output once), duration from the event pair
+      * per phase: wall time between its two events, the FLOPs / bytes of the launches issued inside it
+    Returns (roofline of the dominant kernel family, per-phase dict)."""
     from seedx_amd import _lib, ops
     lib = _lib.load()
-    real = lib.sx_gemm
-    rec = []
+    real = {n: getattr(lib, n) for n in ("sx_gemm", "sx_gemv", "sx_attention")}
+    rec = []                       # (family, phase, flops, bytes, start, end)
+    stack = ["other"]
+    spans = {}                     # phase -> list of (start, end)
 
-    class Hook:
-        def __call__(self, args_ref, stream):
-            a = args_ref._obj
+    def timed(fam, fl, byt, fn, *args):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        r = fn(*args)
+        e.record()
+        rec.append((fam, stack[-1], fl, byt, s, e))
+        return r
+
+    def h_gemm(args_ref, stream):
+        a = args_ref._obj
+        n_out = a.N // 2 if a.glu else a.N
+        n_st = a.n_valid if a.n_valid else n_out
+        a_bytes = 2.0 * (a.B * a.Hin * a.Win * a.Cin if a.a_mode == 1 else a.M * a.K)   # operands once + output once
+        byt = a_bytes + 2.0 * a.N * a.K + a.M * n_st * (4.0 if a.out_dtype == 2 else 2.0) + (4.0 * a.M * n_st if a.residual else 0.0)
+        return timed("gemm", 2.0 * a.M * a.N * a.K / ops.OPERAND_PLANES, byt, real["sx_gemm"], args_ref, stream)
+
+    def h_gemv(args_ref, stream):
+        a = args_ref._obj
+        n_out = a.N // 2 if a.glu else a.N
+        byt = 2.0 * a.N * a.K + 2.0 * a.M * a.K + a.M * n_out * (4.0 if a.out_dtype == 2 else 2.0) + (4.0 * a.M * n_out if a.residual else 0.0)
+        return timed("gemv", 2.0 * a.M * a.N * a.K, byt, real["sx_gemv"], args_ref, stream)
+
+    def h_attn(args_ref, stream):
+        a = args_ref._obj
+        fl = 4.0 * a.B * a.H * a.Sq * a.Skv * a.D * (0.5 if a.causal else 1.0)
+        byt = 2.0 * a.B * a.H * a.D * (2 * a.Sq + 2 * a.Skv)
+        return timed("attention", fl, byt, real["sx_attention"], args_ref, stream)
+
+    def phase_wrap(obj, name, phase):
+        cls = type(obj)
+        orig = getattr(cls, name)
+
+        def wrapped(self_, *args, **kw):
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            stack.append(phase)
             s.record()
-            r = real(args_ref, stream)
-            e.record()
-            n_out = a.N // 2 if a.glu else a.N
-            n_st = a.n_valid if a.n_valid else n_out
-            a_bytes = 2.0 * (a.B * a.Hin * a.Win * a.Cin if a.a_mode == 1 else a.M * a.K)   # operands once + output once
-            byt = a_bytes + 2.0 * a.N * a.K + a.M * n_st * (4.0 if a.out_dtype == 2 else 2.0) \
-                + (4.0 * a.M * n_st if a.residual else 0.0)
-            rec.append((2.0 * a.M * a.N * a.K / ops.OPERAND_PLANES, s, e, byt))   # fp32-grade VAE launches carry 3 planes in K
-            return r
+            try:
+                return orig(self_, *args, **kw)
+            finally:
+                e.record()
+                stack.pop()
+                spans.setdefault(phase, []).append((s, e))
+        setattr(cls, name, wrapped)
+        return cls, name, orig
 
     loop = getattr(getattr(w, "adapter", None), "_loop", None)
-    graphs = [m for m in (getattr(w, "agent", None), loop) if m is not None]
+    agent = getattr(w, "agent", None)
+    graphs = [m for m in (agent, loop) if m is not None]
     for m in graphs:
         m.use_graph = False
     chains = getattr(loop, "chains", 1)
     if loop is not None:
         loop.chains = 1          # ONE kernel chain on ONE stream: an event pair then brackets exactly its own launch (with the
                                  # two concurrent chains of the timed step it would also contain the other chain's kernels)
-    lib.sx_gemm = Hook()
+    patched = []
     try:
+        if getattr(w, "vit", None) is not None:
+            patched.append(phase_wrap(w.vit, "__call__", "vit"))
+        if agent is not None:
+            patched.append(phase_wrap(agent.llm, "forward_embeds_batch", "prefill"))
+            patched.append(phase_wrap(agent.llm, "decode_step", "decode"))
+        if loop is not None:
+            patched.append(phase_wrap(loop, "run", "unet"))
+            patched.append(phase_wrap(w.adapter, "_finish", "vae"))
+        lib.sx_gemm, lib.sx_gemv, lib.sx_attention = h_gemm, h_gemv, h_attn
         w.step(1)
         torch.cuda.synchronize()
     finally:
-        lib.sx_gemm = real
+        for n, f in real.items():
+            setattr(lib, n, f)
+        for cls, name, orig in patched:
+            setattr(cls, name, orig)
         for m in graphs:
             m.use_graph = True
         if loop is not None:
             loop.chains = chains
-    ms = [s.elapsed_time(e) for _, s, e, _ in rec]
-    fl = sum(r_[0] for r_ in rec)
-    alg_bytes = sum(r_[3] for r_ in rec)
-    tot_s = sum(ms) * 1e-3
-    n = len(rec)
-    # traffic: bytes per launch from the rocprofv3 --pmc passes of THIS command (tools/bench_pmc_traffic.py; graph replay
-    # crashes the counter collection on this pool, so the passes run the same step with eager launches). Only quoted
-    # when the stored profile was taken at the batch size / config being run.
-    traffic, tnote = None, "no PMC profile for this batch size / config"
-    for name in ("r2_bench_pmc_traffic.json", "r1_bench_pmc_traffic.json"):
-        try:
-            prof = json.load(open(os.path.join(ROOT, "profiles", name)))
-            if prof.get("batch_per_gpu") == BATCH and w.a.config == 0 and prof.get("kernels", "r1") == \
-                    ("r2" if name.startswith("r2") else "r1"):
-                traffic, tnote = prof["traffic_bytes_per_launch"], prof["method"]
-                break
-        except (OSError, ValueError, KeyError):
-            pass
-    return {"bound": "mfma", "achieved": fl / tot_s / 1e12, "peak": PEAK_TFLOPS_16BIT, "unit": "TFLOP/s",
+
+    fam = {}
+    for f, ph, fl, byt, s, e in rec:
+        d = fam.setdefault(f, {"n": 0, "s": 0.0, "flop": 0.0, "bytes": 0.0})
+        d["n"] += 1; d["s"] += s.elapsed_time(e) * 1e-3; d["flop"] += fl; d["bytes"] += byt
+    phases = {}
+    for ph, sp in spans.items():
+        wall = sum(s.elapsed_time(e) for s, e in sp) * 1e-3
+        inside = [r_ for r_ in rec if r_[1] == ph]
+        fl = sum(r_[2] for r_ in inside)
+        byt_gemv = sum(r_[3] for r_ in inside if r_[0] == "gemv")
+        t_fam = {f: sum(r_[4].elapsed_time(r_[5]) for r_ in inside if r_[0] == f) * 1e-3 for f in ("gemm", "gemv", "attention")}
+        fl_fam = {f: sum(r_[2] for r_ in inside if r_[0] == f) for f in ("gemm", "gemv", "attention")}
+        d = {"wall_ms": wall * 1e3, "calls": len(sp), "algorithmic_tflop": fl / 1e12,
+             "tflops": fl / wall / 1e12 if wall > 0 else 0.0, "mfma_frac": fl / wall / 1e12 / PEAK_TFLOPS_16BIT if wall > 0 else 0.0,
+             "kernel_time_share": {f: (t_fam[f] / wall if wall > 0 else 0.0) for f in t_fam},
+             "family_tflops": {f: (fl_fam[f] / t_fam[f] / 1e12 if t_fam[f] > 0 else None) for f in t_fam}}
+        if ph == "decode":         # weight streaming: every skinny-GEMM launch reads its weight matrix once
+            d.update({"bound": "hbm", "achieved": byt_gemv / wall / 1e9, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                      "frac": byt_gemv / wall / 1e9 / PEAK_HBM_GBPS,
+                      "gemv_kernel_gbps": byt_gemv / t_fam["gemv"] / 1e9 if t_fam["gemv"] > 0 else None})
+        else:
+            d.update({"bound": "mfma", "achieved": d["tflops"], "peak": PEAK_TFLOPS_16BIT, "unit": "TFLOP/s", "frac": d["mfma_frac"]})
+        phases[ph] = d
+    if "attention" in fam and fam["attention"]["s"] > 0:
+        d = fam["attention"]
+        phases["attention_kernels"] = {"bound": "mfma", "achieved": d["flop"] / d["s"] / 1e12, "peak": PEAK_TFLOPS_16BIT, "unit": "TFLOP/s",
+                                       "frac": d["flop"] / d["s"] / 1e12 / PEAK_TFLOPS_16BIT, "launches": d["n"], "kernel_time_s": d["s"]}
+    phases["_method"] = ("one eager step, one kernel chain; wall = HIP events around each phase on the launch stream; FLOPs / bytes = "
+                         "algorithmic work of the sx_gemm / sx_gemv / sx_attention launches issued inside the phase")
+
+    # dominant kernel family by summed launch time
+    g, v = fam.get("gemm"), fam.get("gemv")
+    if v is not None and (g is None or v["s"] > g["s"]):
+        roof = {"bound": "hbm", "achieved": v["bytes"] / v["s"] / 1e9, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                "frac": v["bytes"] / v["s"] / 1e9 / PEAK_HBM_GBPS, "traffic": None, "traffic_unit": "bytes/launch",
+                "traffic_source": "no PMC pass for this config", "algorithmic_bytes_per_launch": v["bytes"] / v["n"],
+                "kernel": "sxk_decode::gemm_skinny_kernel<*> / gemv_kernel<*>", "launches_per_step": v["n"],
+                "avg_launch_us": v["s"] / v["n"] * 1e6, "kernel_time_s_per_step": v["s"]}
+        return roof, phases
+    fl, tot_s, n, alg_bytes = g["flop"], g["s"], g["n"], g["bytes"]
+    # traffic: bytes per launch from rocprofv3 --pmc passes of THIS command (tools/bench_pmc_traffic.py; eager launches).
+    # Only quoted when the stored profile was taken with the GEMM sources as they are now, at this batch size / config.
+    traffic, tnote = None, "no PMC profile taken with the current GEMM kernels at this batch size / config"
+    try:
+        prof = json.load(open(os.path.join(ROOT, "profiles", "r3_bench_pmc_traffic.json")))
+        if prof.get("batch_per_gpu") == BATCH and w.a.config == 0 and prof.get("kernel_source_sha") == _kernel_source_sha():
+            traffic, tnote = prof["traffic_bytes_per_launch"], prof["method"]
+    except (OSError, ValueError, KeyError):
+        pass
+    roof = {"bound": "mfma", "achieved": fl / tot_s / 1e12, "peak": PEAK_TFLOPS_16BIT, "unit": "TFLOP/s",
             "frac": fl / tot_s / 1e12 / PEAK_TFLOPS_16BIT, "traffic": traffic, "traffic_unit": "bytes/launch",
             "traffic_source": tnote, "algorithmic_bytes_per_launch": alg_bytes / n,
-            "kernel": "sxk_gemm::gemm_kernel<*>",
+            "kernel": "sxk_gemm::gemm_pp_kernel<*> + gemm_kernel<*> (every sx_gemm launch)",
             "launches_per_step": n, "avg_launch_us": tot_s / n * 1e6, "avg_launch_gflop": fl / n / 1e9,
             "gemm_time_s_per_step": tot_s}
+    return roof, phases
 
 
-def cpu_baseline():
-    """Bounded sample of the CPU oracle ("port": the functions of oracle/restated*.py, fp32 torch on the host's PHYSICAL
-    cores), extrapolated by layer count / algorithmic FLOPs to one config-0 generation."""
+def _median_time(fn, reps=3, warm=1):
+    """SURVEY.md §8(d) protocol: `warm` untimed calls, then the median of `reps` timed calls."""
+    for _ in range(warm):
+        fn()
+    ts = []
+    for _ in range(reps):
+        t0 = time.time()
+        fn()
+        ts.append(time.time() - t0)
+    ts.sort()
+    return ts[len(ts) // 2]
+
+
+def cpu_baseline(config=0, full_config1=False):
+    """CPU oracle ("port": the functions of oracle/restated*.py, fp32 torch on the host's PHYSICAL cores), 1 warm-up + 3
+    timed repetitions (median) of every sampled piece, extrapolated by layer count / algorithmic FLOPs to one config-0
+    generation. `full_config1` (bench.py --config 1 --cpu-baseline full): BASELINE config 1 end to end, un-extrapolated
+    (full ViT-G forward of 2 crops + ResamplerXLV2 + ONE full SDXL-UNet CFG-2 step), one timed run after a warm-up block."""
     from oracle import restated, restated_unet as ru, weights
     try:
         import psutil
         cores = psutil.cpu_count(logical=False) or os.cpu_count()
     except Exception:
         cores = os.cpu_count()
-    torch.set_num_threads(max(1, cores))
-    cores = torch.get_num_threads()
+    # thread count: the fastest of {16, 32, 64, all physical cores} on one ViT block (fp32 GEMMs of this size stop scaling
+    # long before 128 threads; the reported `cores` is the count actually used)
     g = torch.Generator().manual_seed(0)
-    t_total = 0.0
+    cfg1 = dict(weights.FULL_VIT, layers=1)
+    sd1 = weights.vit_sd(cfg1)
+    x1 = torch.randn(1, 3, 448, 448, generator=g)
+    best = (1e30, max(1, cores))
+    for nt_ in sorted({min(c_, max(1, cores)) for c_ in (16, 32, 64, cores)}):
+        torch.set_num_threads(nt_)
+        t_ = _median_time(lambda: restated.vit_forward(sd1, cfg1, x1), reps=2)
+        if t_ < best[0]:
+            best = (t_, nt_)
+    del sd1
+    torch.set_num_threads(best[1])
+    cores = torch.get_num_threads()
+    if full_config1:
+        cfg = dict(weights.FULL_VIT)
+        sd = weights.vit_sd(cfg)
+        x = torch.randn(2, 3, 448, 448, generator=g)
+        restated.vit_forward(sd, dict(cfg, layers=1), x[:1])                      # warm-up (allocator, thread pool)
+        t0 = time.time()
+        restated.vit_forward(sd, cfg, x)
+        t_vit = time.time() - t0
+        del sd
+        ucfg = ru.FULL_UNET
+        usd = {k: torch.randn(s_, generator=g) * (0.02 if len(s_) > 1 else 1.0) for k, s_ in ru.unet_param_shapes(ucfg).items()}
+        lat = torch.randn(2, 4, 128, 128, generator=g)
+        ehs = torch.randn(2, 64, 2048, generator=g)
+        t0 = time.time()
+        ru.unet_forward(usd, ucfg, lat, torch.tensor(999.0), ehs, torch.randn(2, 1280, generator=g),
+                        torch.tensor([[1024., 1024., 0., 0., 1024., 1024.]] * 2))
+        t_unet = time.time() - t0
+        t_total = t_vit + t_unet
+        return {"value": 1.0 / t_total, "unit": "gens/s", "cores": cores, "kind": "port",
+                "sample": "BASELINE config 1 un-extrapolated on %d host threads: oracle ViT-G forward of 2 crops %.1fs + ONE full "
+                          "SDXL-UNet CFG-2 step at 128x128 latents %.1fs (single timed run each after a thread-pool warm-up; "
+                          "ResamplerXLV2 < 0.1 s omitted)" % (cores, t_vit, t_unet)}
     # (1) oracle ViT (restated.vit_forward) at full width with 1 and 2 of the 48 blocks, B = 2 crops: the difference is one
     #     block, the 1-block run carries patchify + attn_pool + proj
     x = torch.randn(2, 3, 448, 448, generator=g)
@@ -464,22 +606,22 @@ def cpu_baseline():
     for layers in (1, 2):
         cfg = dict(weights.FULL_VIT, layers=layers)
         sd = weights.vit_sd(cfg)
-        restated.vit_forward(sd, cfg, x[:1])                                    # warm-up (allocator, threads)
-        t0 = time.time()
-        restated.vit_forward(sd, cfg, x)
-        t_vit.append(time.time() - t0)
+        t_vit.append(_median_time(lambda: restated.vit_forward(sd, cfg, x)))
         del sd
     t_block = max(t_vit[1] - t_vit[0], 1e-3)
-    t_total += t_vit[0] + 47 * t_block
-    # (2) oracle Llama (restated.llama_forward), one of 40 layers: prefill T=165 and 4 cached decode steps
+    t_total = t_vit[0] + 47 * t_block
+    # (2) oracle Llama (restated.llama_forward), one of 40 layers: prefill T=165 and cached decode steps
     cfg = dict(weights.FULL_LLM, num_hidden_layers=1, vocab_size=512)
     sd = weights.llama_sd(cfg)
     xe = torch.randn(1, 165, 5120, generator=g)
-    t0 = time.time(); _, past, _ = restated.llama_forward(sd, cfg, xe); t_pre = time.time() - t0
-    t0 = time.time()
-    for _ in range(4):
-        _, past, _ = restated.llama_forward(sd, cfg, xe[:, :1], past)
-    t_dec = (time.time() - t0) / 4
+    t_pre = _median_time(lambda: restated.llama_forward(sd, cfg, xe))
+    _, past0, _ = restated.llama_forward(sd, cfg, xe)
+
+    def dec4():
+        past = past0
+        for _ in range(4):
+            _, past, _ = restated.llama_forward(sd, cfg, xe[:, :1], past)
+    t_dec = _median_time(dec4) / 4
     n_new = 128
     t_total += 40 * (t_pre + n_new * t_dec)
     # (3) oracle SDXL UNet pieces (restated_unet._resnet / _transformer): mid-block resnet + one of its 10 transformer
@@ -487,27 +629,28 @@ def cpu_baseline():
     ucfg = ru.FULL_UNET
     shapes = ru.unet_param_shapes(ucfg)
     usd = {}
-    for k, s in shapes.items():
+    for k, s_ in shapes.items():
         if k.startswith("mid_block.resnets.0") or k.startswith("mid_block.attentions.0.norm") or \
                 k.startswith("mid_block.attentions.0.proj") or k.startswith("mid_block.attentions.0.transformer_blocks.0."):
-            usd[k] = torch.randn(s, generator=g) * (0.02 if len(s) > 1 else 1.0)
+            usd[k] = torch.randn(s_, generator=g) * (0.02 if len(s_) > 1 else 1.0)
     xs = torch.randn(2, 1280, 32, 32, generator=g)
     emb = torch.randn(2, 1280, generator=g)
     ehs = torch.randn(2, 64, 2048, generator=g)
-    t0 = time.time()
-    h = ru._resnet(usd, "mid_block.resnets.0", xs, emb, 32)
-    ru._transformer(usd, "mid_block.attentions.0", h, ehs, 20, 1, 32)
-    t_u = time.time() - t0
+
+    def unet_piece():
+        h = ru._resnet(usd, "mid_block.resnets.0", xs, emb, 32)
+        ru._transformer(usd, "mid_block.attentions.0", h, ehs, 20, 1, 32)
+    t_u = _median_time(unet_piece)
     C, HW, B = 1280, 1024, 2
     fl_sample = B * (2 * 2 * HW * C * 9 * C + 2 * HW * C * C * 2            # resnet convs + proj_in/out
                      + 2 * HW * C * (3 * C + C + C + C + 8 * C + 4 * C)        # qkv, out, q2, out2, geglu, ff2
                      + 4 * HW * HW * C + 4 * HW * 64 * C + 2 * 2 * 64 * 2048 * C)
     t_total += 50 * t_u * (2 * FLOP_UNET_SAMPLE / fl_sample)
     return {"value": 1.0 / t_total, "unit": "gens/s", "cores": cores, "kind": "port",
-            "sample": "oracle/restated*.py fp32 torch on %d host threads (physical cores): ViT-G with 1 and 2 of 48 blocks "
-                      "(B=2) %.2fs / %.2fs, 1 of 40 Llama-13B-dim layers (prefill T=165 %.2fs, cached decode %.3fs/token), "
-                      "SDXL mid-block resnet + 1 transformer layer @32x32 CFG-2 %.2fs; extrapolated by layer count / "
-                      "algorithmic FLOPs to one config-0 generation (%.0f s)"
+            "sample": "oracle/restated*.py fp32 torch on %d host threads (physical cores), 1 warm-up + median of 3 runs per piece: "
+                      "ViT-G with 1 and 2 of 48 blocks (B=2) %.2fs / %.2fs, 1 of 40 Llama-13B-dim layers (prefill T=165 %.2fs, cached "
+                      "decode %.3fs/token), SDXL mid-block resnet + 1 transformer layer @32x32 CFG-2 %.2fs; extrapolated by layer "
+                      "count / algorithmic FLOPs to one config-0 generation (%.0f s)"
                       % (cores, t_vit[0], t_vit[1], t_pre, t_dec, t_u, t_total)}
 
 
@@ -539,6 +682,9 @@ def parse_args(argv=None):
                     help="fp32 (default): the reference's scripts decode with the VAE upcast to fp32 — operands carried as two "
                          "bf16 planes, fp32 accumulation; fast: single 16-bit operands; auto: what the reference would do for --dtype")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline", default="sample", choices=["sample", "full"],
+                    help="sample (default): bounded pieces, 1 warm-up + median of 3, extrapolated to a config-0 generation; full (with "
+                         "--config 1): BASELINE config 1 end to end on the host, un-extrapolated (minutes)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: CPU launch-path test only (with --stub)")
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)
@@ -598,9 +744,9 @@ def main(argv=None):
         du.barrier(ctx)
         sync()
         dt = du.max_over_ranks(ctx, time.perf_counter() - t0)
-        roof = None
+        roof = phases = None
         if rank == 0 and gpu and not a.no_roofline:
-            roof = gemm_roofline(w)
+            roof, phases = measure_roofline(w)
     if rank == 0:
         total = du.total_units(ctx, a.steps) * a.batch
         rec = {"metric": "end-to-end generations/sec (img-in -> txt + 1024px-img-out)" if a.config == 0 else
@@ -618,9 +764,10 @@ def main(argv=None):
         rec["model_tflops"] = rec["flops_per_generation"] * rec["value"] / world / 1e12
         if roof is not None:
             rec["roofline"] = roof
+            rec["roofline_phases"] = phases
         if gpu and not a.no_cpu_baseline and world == 1:
             try:
-                rec["cpu_baseline"] = cpu_baseline()
+                rec["cpu_baseline"] = cpu_baseline(a.config, full_config1=(a.cpu_baseline == "full" and a.config == 1))
             except Exception as ex:  # the oracle is optional infrastructure; never fail the measurement on it
                 rec["cpu_baseline"] = {"error": repr(ex)}
         print(json.dumps(rec), flush=True)

@@ -22,7 +22,7 @@ def main():
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"]
-            fam = "gemm" if "gemm_kernel" in k else "attention" if "attn_kernel" in k else None
+            fam = "gemm" if ("gemm_kernel" in k or "gemm_pp_kernel" in k) else "attention" if "attn_kernel" in k else None
             if fam is None:
                 continue
             cnt[fam][r["Counter_Name"]] += float(r["Counter_Value"])
@@ -32,7 +32,7 @@ def main():
     for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"]
-            fam = "gemm" if "gemm_kernel" in k else "attention" if "attn_kernel" in k else None
+            fam = "gemm" if ("gemm_kernel" in k or "gemm_pp_kernel" in k) else "attention" if "attn_kernel" in k else None
             if fam:
                 dur[fam] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
     out = {}

@@ -20,10 +20,22 @@ def family_sum(dirname, counter):
     n, tot = 0, 0.0
     for f in glob.glob(dirname + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            if r.get("Counter_Name") == counter and "gemm_kernel" in r["Kernel_Name"]:
+            if r.get("Counter_Name") == counter and ("gemm_kernel" in r["Kernel_Name"] or "gemm_pp_kernel" in r["Kernel_Name"]):
                 n += 1
                 tot += float(r["Counter_Value"])
     return n, tot
+
+
+def kernel_source_sha():
+    """Same hash bench.py computes: the profile is only quoted while the GEMM sources are unchanged."""
+    import hashlib
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    for f in ("gemm.hip", "gemm_pp.hip", "gemm_common.h", "sx_common.h"):
+        with open(os.path.join(root, "seed-x_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def main():
@@ -31,7 +43,8 @@ def main():
     nw, write = family_sum(sys.argv[2], "WRITE_SIZE")
     assert nf > 0 and nf == nw, (nf, nw)
     fb, wb = 2 * 1024 * fetch, 1024 * write
-    print(json.dumps({"kernel": "sxk_gemm::gemm_kernel<*>", "kernels": sys.argv[4] if len(sys.argv) > 4 else "r1",
+    print(json.dumps({"kernel": "sxk_gemm::gemm_pp_kernel<*> + gemm_kernel<*>", "kernels": sys.argv[4] if len(sys.argv) > 4 else "r1",
+                      "kernel_source_sha": kernel_source_sha(),
                       "batch_per_gpu": int(sys.argv[3]), "launches": nf,
                       "fetch_bytes_per_launch": fb / nf, "write_bytes_per_launch": wb / nf,
                       "traffic_bytes_per_launch": (fb + wb) / nf,
