@@ -132,10 +132,20 @@ def run_reference_detok():
                           callback=lambda i, t, l: traj.append(l.clone()))
         img = ad.generate(image_tensor=inp["image_tensor"], height=128, width=128, num_inference_steps=2,
                           latents=inp["noise"].clone(), output_type="pt")
+        # -- SDXLAdapter.forward (adapter_modules.py:39-52): one UNet forward on noisy latents + the MSE against the noise --
+        gf = torch.Generator().manual_seed(515)
+        fwd_noisy = torch.randn(2, 4, 16, 16, generator=gf)
+        fwd_noise = torch.randn(2, 4, 16, 16, generator=gf)
+        fwd_feats = torch.randn(2, 16, 256, generator=gf)
+        fwd_t = torch.tensor([981.0, 37.0])
+        fwd_tid = torch.tensor([[128.0, 128, 0, 0, 128, 128]] * 2)
+        fwd = ad(fwd_noisy, fwd_t, fwd_feats, None, fwd_noise, fwd_tid)
         out["t2i_mini.npz"] = dict(image_tensor=inp["image_tensor"], feats=inp["feats"], noise=inp["noise"],
                                    tensor_prompt=pe, tensor_prompt_neg=pen, tensor_pooled=po, tensor_pooled_neg=pon,
                                    embeds_prompt=pe2, embeds_prompt_neg=pen2, embeds_pooled=po2, embeds_pooled_neg=pon2,
-                                   latents_traj=torch.stack(traj), latents=lat, image_pt=img)
+                                   latents_traj=torch.stack(traj), latents=lat, image_pt=img,
+                                   fwd_noisy=fwd_noisy, fwd_noise=fwd_noise, fwd_feats=fwd_feats, fwd_t=fwd_t, fwd_time_ids=fwd_tid,
+                                   fwd_noise_pred=fwd["noise_pred"], fwd_loss=fwd["total_loss"].reshape(1))
         # -- edit (SDXLAdapterWithLatentImage.generate :249-287 → reference pipeline __call__ :618-994) ---------------
         ad = build_reference_adapter(edit=True)
         traj = []

@@ -2,6 +2,7 @@
 
 Follows src/models/detokenizer/adapter_modules.py:
   * get_image_embeds (:96-130): three mutually exclusive inputs; pooling ONLY on the image_embeds branch (:109-116)
+  * SDXLAdapter.forward (:39-52): resampler → one UNet forward → MSE against the noise
   * SDXLAdapter.generate (:132-169) → t2i loop, order [uncond, text]
   * SDXLAdapterWithLatentImage.generate (:249-287) → edit loop (pipeline_stable_diffusion_xl_t2i_edit.py:900-963)
 """
@@ -25,6 +26,13 @@ def get_image_embeds(sd_vit, cfg_vit, sd_x, cfg_x, image_tensor=None, image_embe
     prompt, pooled = restated.resampler_xlv2_forward(sd_x, cfg_x, feats)               # :118-120 (discrete model = identity)
     n = prompt.shape[0] // 2
     return prompt[:n], prompt[n:], pooled[:n], pooled[n:]                              # :122-124
+
+
+def adapter_forward(sd_x, cfg_x, sd_unet, cfg_unet, noisy_latents, timesteps, image_embeds, noise, time_ids):
+    """adapter_modules.py:39-52: (`text_embeds` is ignored by the reference) → (total_loss, noise_pred)."""
+    prompt, pooled = restated.resampler_xlv2_forward(sd_x, cfg_x, image_embeds.float())        # :41
+    noise_pred = ru.unet_forward(sd_unet, cfg_unet, noisy_latents.float(), timesteps, prompt, pooled, time_ids)   # :43-45
+    return F.mse_loss(noise_pred.float(), noise.float(), reduction="mean"), noise_pred     # :48
 
 
 def adapter_generate(sd_vit, cfg_vit, sd_x, cfg_x, sd_unet, cfg_unet, latents, steps, image_tensor=None,

@@ -386,6 +386,19 @@ class SDXLAdapter:
     def eval(self):
         return self
 
+    @torch.no_grad()
+    def forward(self, noisy_latents, timesteps, image_embeds, text_embeds, noise, time_ids):
+        """adapter_modules.py:39-52 (the training-time forward, inference-only here: no autograd): resampler → ONE UNet
+        forward conditioned on the resampled image tokens + pooled vector (`text_embeds` is accepted and ignored, exactly
+        like the reference) → {'total_loss': mse(noise_pred, noise), 'noise_pred': [B, 4, h, w]}."""
+        image_embeds, pooled_image_embeds = self.resampler(image_embeds)
+        unet_added_conditions = {"time_ids": time_ids, "text_embeds": pooled_image_embeds}
+        noise_pred = self.unet(noisy_latents, timesteps, image_embeds, added_cond_kwargs=unet_added_conditions).sample
+        loss = torch.nn.functional.mse_loss(noise_pred.float(), noise.to(noise_pred.device).float(), reduction="mean")
+        return {"total_loss": loss, "noise_pred": noise_pred}
+
+    __call__ = forward
+
     def encode_image_embeds(self, image_embeds):
         return self.resampler(image_embeds)                                         # adapter_modules.py:54-57
 

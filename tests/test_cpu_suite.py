@@ -82,6 +82,10 @@ def test_oracle_detok_matches_reference_executed_golden():
     kw = dict(height=128, width=128)
     lat = ra.adapter_generate(sd_vit, V, sd_x, X, ru.unet_sd(u4), u4, t2i["noise"], 5, image_embeds=t2i["feats"], **kw)
     assert _rel(lat, t2i["latents"]) < 5e-5
+    # SDXLAdapter.forward (adapter_modules.py:39-52), executed by the reference class → fwd_* arrays
+    loss, npred = ra.adapter_forward(sd_x, X, ru.unet_sd(u4), u4, t2i["fwd_noisy"], t2i["fwd_t"], t2i["fwd_feats"],
+                                     t2i["fwd_noise"], t2i["fwd_time_ids"])
+    assert _rel(npred, t2i["fwd_noise_pred"]) < 2e-5 and abs(float(loss) - float(t2i["fwd_loss"][0])) < 1e-5
     sd8 = ru.unet_sd(u8)
     lat = ra.adapter_generate(sd_vit, V, sd_x, X, sd8, u8, edit["noise"], 5, image_embeds=edit["feats"],
                               image_latents=edit["image_latents"], **kw)

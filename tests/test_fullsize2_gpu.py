@@ -4,7 +4,8 @@ the checker; the HIP path runs fp16 (the reference scripts' dtype) with the same
   * a 50-step t2i CFG loop at full size with the drift reported at steps 1 / 10 / 25 / 50
   * the real SDXL VAE decoder at 128x128 latents (1024x1024 px) and the encoder at 1024 px
   * ViT-G width with B = 20 crops (BASELINE config 5) and a 1536-token Llama prefill
-Each test prints its rel-L2 and the north-star's 1e-3 verdict; the asserted bound is the stated fp16 tolerance."""
+Each test prints its rel-L2; full-size fp16 results are asserted against the north-star's 1e-3 itself (round 3: the bounds
+used to be 2-8x looser than what was measured), bf16 (the bench dtype, eps = 7.8e-3) against its own stated bounds."""
 import pytest
 import torch
 
@@ -46,11 +47,16 @@ def test_unet_full_8ch_bc3_forward(dev):
     out = m(x.to(dev), 481.0, ehs.to(dev), added_cond_kwargs={"text_embeds": te.to(dev), "time_ids": tid.to(dev)},
             return_dict=False)[0]
     e = relerr(out, ref)
-    _verdict("FULL 8-channel SDXL UNet, Bc=3, 128x128 latents, fp16", e, 4e-3)
-    assert out.shape == (3, 4, 128, 128) and torch.isfinite(out).all() and e < 4e-3
+    _verdict("FULL 8-channel SDXL UNet, Bc=3, 128x128 latents, fp16", e, 1e-3)
+    assert out.shape == (3, 4, 128, 128) and torch.isfinite(out).all() and e < 1e-3
 
 
-def test_full_size_50_step_t2i_loop_drift(dev):
+# (dtype, generations G, kernel chains, bound at step 1, bound at step 50)
+#   fp16 (the reference scripts' dtype): the north-star's 1e-3 at every mark
+#   bf16 (the bench dtype) at the bench's geometry: G = 2 generations → UNet batch 4 → the step graph forks into two concurrent
+#   kernel chains exactly like the timed bench step; bound 1.2e-2 at step 1 (≈1.5 bf16 eps per module), 2.5e-2 at step 50
+@pytest.mark.parametrize("dtype,G,chains,tol1,tol50", [(torch.float16, 1, 1, 1e-3, 1e-3), (torch.bfloat16, 2, 2, 1.2e-2, 2.5e-2)])
+def test_full_size_50_step_t2i_loop_drift(dev, dtype, G, chains, tol1, tol50):
     """50 Euler steps of the complete UNet at 128x128 latents, CFG 7.5: HIP graph loop vs the oracle loop (fp32 on the
     GPU), latents compared after 1 / 10 / 25 / 50 steps."""
     from seedx_amd.detokenizer import EulerDiscreteScheduler, _DenoiseLoop
@@ -58,11 +64,11 @@ def test_full_size_50_step_t2i_loop_drift(dev):
     cfg = ru.FULL_UNET
     sd = ru.unet_sd(cfg, device=dev)
     g = torch.Generator().manual_seed(21)
-    pe, pen = torch.randn(1, 64, 2048, generator=g), torch.randn(1, 64, 2048, generator=g)
-    po, pon = torch.randn(1, 1280, generator=g), torch.randn(1, 1280, generator=g)
-    tid = torch.tensor([[1024.0, 1024, 0, 0, 1024, 1024]])
+    pe, pen = torch.randn(G, 64, 2048, generator=g), torch.randn(G, 64, 2048, generator=g)
+    po, pon = torch.randn(G, 1280, generator=g), torch.randn(G, 1280, generator=g)
+    tid = torch.tensor([[1024.0, 1024, 0, 0, 1024, 1024]] * G)
     ts, sig, init = ru.euler_tables(50)
-    lat0 = torch.randn(1, 4, 128, 128, generator=g) * init
+    lat0 = torch.randn(G, 4, 128, 128, generator=g) * init
     marks = (1, 10, 25, 50)
     ref = {}
     with torch.no_grad():
@@ -80,19 +86,20 @@ def test_full_size_50_step_t2i_loop_drift(dev):
                 ref[i + 1] = lat.clone()
     m = UNet2DConditionModel(**SDXL_BASE_CONFIG)
     m.load_state_dict(sd)
-    m.to(dev, torch.float16)
+    m.to(dev, dtype)
     m._pack()
     del sd
     torch.cuda.empty_cache()
     trace = {k: None for k in marks}
     loop = _DenoiseLoop(m, use_graph=True)
+    loop.chains = chains
     out = loop.run(0, lat0.clone(), torch.cat([pen, pe]), torch.cat([pon, po]), torch.cat([tid, tid]),
                    EulerDiscreteScheduler(), 50, 7.5, trace=trace)
     errs = {k: relerr(trace[k], ref[k]) for k in marks}
-    print("full-size 50-step t2i loop, fp16, latents rel-L2 vs fp32 oracle after N steps: "
-          + ", ".join(f"{k}: {v:.2e}" for k, v in errs.items()))
+    print(f"full-size 50-step t2i loop, {dtype}, {G} generation(s), {chains} kernel chain(s), latents rel-L2 vs fp32 oracle "
+          "after N steps: " + ", ".join(f"{k}: {v:.2e}" for k, v in errs.items()))
     assert torch.isfinite(out).all() and relerr(out, ref[50]) == errs[50]
-    assert errs[1] < 2e-3 and errs[50] < 8e-3                            # no blow-up over 50 steps
+    assert errs[1] < tol1 and max(errs.values()) < tol50                 # no blow-up over 50 steps
 
 
 def test_vae_full_config_1024px(dev):
@@ -138,8 +145,8 @@ def test_vit_b20_and_long_prefill(dev):
     m.load_state_dict(sd)
     m.eval().to(dev, dtype=torch.float16)
     e = relerr(m(x), ref)
-    _verdict("ViT-G width, B = 20 crops, fp16", e, 2e-3)
-    assert e < 2e-3
+    _verdict("ViT-G width, B = 20 crops, fp16", e, 1e-3)
+    assert e < 1e-3
     lcfg = dict(weights.FULL_LLM, num_hidden_layers=2)
     lsd = weights.llama_sd(lcfg)
     xe = torch.randn(1, 1536, 5120, generator=torch.Generator().manual_seed(6)) * 0.5
@@ -151,6 +158,6 @@ def test_vit_b20_and_long_prefill(dev):
     llm.eval().to(dev, dt)
     out = llm(inputs_embeds=xe.to(dev), output_hidden_states=True)
     e_l, e_h = relerr(out["logits"][0, 0], lref[0, -1]), relerr(out["hidden_states"][-1], href)
-    _verdict("Llama-13B dims, 1536-token prefill, fp16: last-position logits", e_l, 3e-3)
-    _verdict("Llama-13B dims, 1536-token prefill, fp16: final-norm states", e_h, 3e-3)
-    assert e_l < 3e-3 and e_h < 3e-3
+    _verdict("Llama-13B dims, 1536-token prefill, fp16: last-position logits", e_l, 1e-3)
+    _verdict("Llama-13B dims, 1536-token prefill, fp16: final-norm states", e_h, 1e-3)
+    assert e_l < 1e-3 and e_h < 1e-3

@@ -39,7 +39,7 @@ def test_vit_full_width_two_layers(dev):
     y = m(x)
     e = relerr(y, ref)
     print(f"full-width ViT (2 layers) fp16 rel-L2 {e:.3e}")
-    assert y.shape == (2, 256, 4096) and e < 2e-3
+    assert y.shape == (2, 256, 4096) and e < 1e-3                     # fp16 at full width: the north-star bound itself
 
 
 def test_llama_full_dims_two_layers(dev):
@@ -58,7 +58,7 @@ def test_llama_full_dims_two_layers(dev):
     out = llm(inputs_embeds=x.to(dev), output_hidden_states=True)
     e_l, e_h = relerr(out["logits"][0, 0], lref[0, -1]), relerr(out["hidden_states"][-1], href)
     print(f"full-dim Llama (2 layers) bf16 prefill: logits rel-L2 {e_l:.3e} hidden {e_h:.3e}")
-    assert e_l < 1.6e-2 and e_h < 1.6e-2
+    assert e_l < 1.2e-2 and e_h < 1.2e-2                              # bf16 bound (eps = 7.8e-3; measured 9.1e-3 / 8.4e-3)
     # three cached single-token steps through the GEMV / split-KV path
     toks = [17, 31999, 5]
     for t in toks:
@@ -91,7 +91,7 @@ def test_unet_full_sdxl_forward(dev):
             return_dict=False)[0]
     e = relerr(out, ref)
     print(f"FULL SDXL UNet (2.567 B params, 128x128 latents, CFG-2) fp16 rel-L2 {e:.3e} (ref std {ref.std():.3f})")
-    assert out.shape == (2, 4, 128, 128) and torch.isfinite(out).all() and e < 4e-3
+    assert out.shape == (2, 4, 128, 128) and torch.isfinite(out).all() and e < 1e-3   # fp16, complete UNet: north-star bound
 
 
 def test_full_size_kernel_properties(dev):

@@ -125,7 +125,7 @@ def test_llm_generate_vs_oracle(dev, dtype):
         # own top-2 gap is within 16-bit noise of its score scale
         trace = []
         ref = restated.lvlm_generate(sd_llm, sd_agent, cfg, rc, ids, image_embeds, emask, mask, ppos,
-                                     [400] + list(range(401, 417)) + [465], 400, 465, max_new, 16, None, None, new, trace)
+                                     [400] + list(range(401, 417)) + [465], 400, 465, max_new, 16, None, dtype, new, trace)
         tol_gap = 0.02 if dtype == torch.float16 else 0.12
         for step, (o_arg, forced, gap, std) in enumerate(trace):
             assert o_arg == forced or gap < tol_gap * max(std, 1.0), (step, o_arg, forced, gap, std)
