@@ -107,6 +107,12 @@ def install(reference_root=None):
         d.__spec__ = importlib.machinery.ModuleSpec("diffusers", None)
         d._seedx_dropin = True
         d.AutoencoderKL, d.UNet2DConditionModel, d.EulerDiscreteScheduler = AutoencoderKL, UNet2DConditionModel, EulerDiscreteScheduler
+
+        class Transformer2DModel:   # eval_img2edit_seed_x_edit.py:8 imports the name and never uses it
+            def __init__(self, *a, **kw):
+                raise NotImplementedError("diffusers.Transformer2DModel is only imported, never used, by the SEED-X inference "
+                                          "scripts; the UNet's transformer blocks live inside seedx_amd.unet.UNet2DConditionModel")
+        d.Transformer2DModel = Transformer2DModel
         if "diffusers" not in sys.modules:
             _INSTALLED.append("diffusers")
         sys.modules["diffusers"] = d
