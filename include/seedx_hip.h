@@ -140,6 +140,8 @@ int sx_groupnorm(const float* x, void* y, void* raw16, int out_dtype, const floa
  * CrossAttnUpBlock2D / UpBlock2D [ext]) without materialising the concatenation. x2 == NULL: plain sx_groupnorm. */
 int sx_groupnorm2(const float* x, const float* x2, int C1, void* y, void* raw16, int out_dtype, const float* gamma,
                   const float* beta, double* stats, int B, int HW, int C, int groups, float eps, int silu, void* stream);
+/* tuning hook: key 0 = target block count of the GroupNorm statistics pass (default 512) */
+int sx_norm_tune(int key, int value);
 /* the same split in two calls for pixel-sharded (sequence-parallel) UNet ranks: phase 1 = zero `stats` and accumulate the
  * fp64 sum / sum-of-squares of THIS rank's HW rows per (sample, group); the caller all-reduces `stats` across ranks;
  * phase 2 = normalise this rank's rows with statistics that cover hw_total rows per sample. */

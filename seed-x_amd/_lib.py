@@ -69,6 +69,7 @@ SIGNATURES = {
                         c_i32, c_vp],
     "sx_attention": [C.POINTER(AttnArgs), c_vp],
     "sx_attention_variant": [c_i32],
+    "sx_norm_tune": [c_i32, c_i32],
     "sx_attention_small": [C.POINTER(AttnSmallArgs), c_vp],
     "sx_attn_decode": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_i32, c_vp],
     "sx_rope_kv_append": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp],

@@ -125,6 +125,8 @@ __global__ __launch_bounds__(256) void layernorm_block_kernel(const void* x, voi
   }
 }
 
+static int g_gn_stat_blocks = 512;   // tuning hook (sx_norm_tune): target block count of the GroupNorm statistics pass
+
 // ---- GroupNorm over NHWC fp32 -----------------------------------------------------------------
 constexpr int GN_MAX_SLOTS2 = 6;  // C/2 pairs per row / 256 threads  (C <= 3072)
 constexpr int GN_MAX_SLOTS4 = 3;  // C/4 quads per row / 256 threads
@@ -418,7 +420,7 @@ static int groupnorm_impl(const float* x, const float* x2, int C1, void* y, void
     SX_HIP_LAUNCH_CHECK();
     // stats: ~512 blocks in total — every block ends with 2*groups fp64 atomics on the same B*groups*2 words, so the
     // block count (not the byte count) bounds this kernel once the atomics serialise in L2
-    int rows_stats = (HW * B + 511) / 512;
+    int rows_stats = (HW * B + g_gn_stat_blocks - 1) / g_gn_stat_blocks;
     if (rows_stats < 8) rows_stats = 8;
     const dim3 grid_s((HW + rows_stats - 1) / rows_stats, B);
     if (x2)
@@ -437,6 +439,11 @@ static int groupnorm_impl(const float* x, const float* x2, int C1, void* y, void
     SX_HIP_LAUNCH_CHECK();
   }
   return SX_OK;
+}
+
+extern "C" int sx_norm_tune(int key, int value) {   // tuning hook: key 0 = block count of the GroupNorm statistics pass
+  if (key == 0 && value >= 64 && value <= 65536) { g_gn_stat_blocks = value; return SX_OK; }
+  SX_FAIL("sx_norm_tune: unknown key %d / value %d", key, value);
 }
 
 extern "C" int sx_groupnorm2(const float* x, const float* x2, int C1, void* y, void* raw16, int out_dtype, const float* gamma,

@@ -190,6 +190,26 @@ static int run_case(Case c, int rounds, int iters_scale) {
     }
     const double tol = c.out32 ? 2e-5 : 8e-3;
     const bool ok = (ndiff == 0) || (maxrel <= tol);
+    if (!ok) {   // where are the wrong elements? (first few + a per-256-row-tile / per-16-column histogram of bad entries)
+      int shown = 0;
+      std::vector<size_t> by_col(n_out / 16 + 1, 0), by_row16(16, 0);
+      for (size_t i = 0; i < n; ++i) {
+        const float x = c.out32 ? ((float*)hout.data())[i] : bf2f(((uint16_t*)hout.data())[i]);
+        const float r = c.out32 ? ((float*)href.data())[i] : bf2f(((uint16_t*)href.data())[i]);
+        if (!(fabs((double)x - r) / (fabs((double)r) + 1.0) <= tol)) {
+          const size_t m = i / n_out, nn = i % n_out;
+          by_col[nn / 16]++; by_row16[(m % 256) / 16]++;
+          if (shown++ < 6) printf("      bad [%zu][%zu]: got %g ref %g (diff %g) residual %g residual[m+16] %g [m-16] %g [n+16] %g [n-16] %g\n", m, nn, x, r, x - r,
+                                  c.res ? hres[i] : 0.f, c.res && m + 16 < (size_t)c.M ? hres[i + 16 * n_out] : 0.f, c.res && m >= 16 ? hres[i - 16 * n_out] : 0.f,
+                                  c.res && nn + 16 < (size_t)n_out ? hres[i + 16] : 0.f, c.res && nn >= 16 ? hres[i - 16] : 0.f);
+        }
+      }
+      printf("      bad per 16-row block of a 256-row tile:");
+      for (size_t v : by_row16) printf(" %zu", v);
+      printf("\n      bad per 16-column block (first 24):");
+      for (size_t q = 0; q < by_col.size() && q < 24; ++q) printf(" %zu", by_col[q]);
+      printf("\n");
+    }
     // race screen: 20 more launches, each must reproduce the first bit for bit
     size_t races = 0;
     std::vector<uint8_t> h2(b.c_bytes);
@@ -386,6 +406,12 @@ int main(int argc, char** argv) {
     cases.push_back({"conv320", 0, 320, 0, 0, 0, 0, 1, 1, 1, 32, 128, 128, 320, 1, 0, 5, {5, 1100}});
     cases.push_back({"conv_up640", 0, 640, 0, 0, 0, 0, 1, 1, 1, 32, 32, 32, 640, 1, 1, 5, {5, 1100}});
     cases.push_back({"conv_s2_640", 0, 640, 0, 0, 0, 0, 1, 1, 1, 32, 64, 64, 640, 2, 0, 5, {5, 1100}});
+  }
+  if (suite == "rs") {
+    cases.push_back({"rs_small", 1024, 1280, 1280, 0, 0, 1, 1, 1, 0, 0, 0, 0, 0, 1, 0, 5, {5, 1100, 1000}});
+    cases.push_back({"outproj_res", 32768, 1280, 1280, 0, 0, 1, 1, 1, 0, 0, 0, 0, 0, 1, 0, 5, {5, 1100, 1000}});
+    cases.push_back({"rs_k1536", 4096, 1280, 1536, 0, 0, 1, 1, 1, 0, 0, 0, 0, 0, 1, 0, 5, {5, 1100, 1000}});
+    cases.push_back({"ff2_res", 32768, 1280, 5120, 0, 0, 1, 1, 1, 0, 0, 0, 0, 0, 1, 0, 5, {5, 1100, 1000}});
   }
   if (suite == "edge" || suite == "all") {
     // ragged M / N, K = 64 (one k-tile), K = 128, odd k-tile counts, n_valid-free GLU
