@@ -140,7 +140,7 @@ int sx_groupnorm(const float* x, void* y, void* raw16, int out_dtype, const floa
  * CrossAttnUpBlock2D / UpBlock2D [ext]) without materialising the concatenation. x2 == NULL: plain sx_groupnorm. */
 int sx_groupnorm2(const float* x, const float* x2, int C1, void* y, void* raw16, int out_dtype, const float* gamma,
                   const float* beta, double* stats, int B, int HW, int C, int groups, float eps, int silu, void* stream);
-/* tuning hook: key 0 = target block count of the GroupNorm statistics pass (default 512) */
+/* tuning hook: key 0 = block count of the GroupNorm statistics pass (0 = chosen by input size, the default) */
 int sx_norm_tune(int key, int value);
 /* the same split in two calls for pixel-sharded (sequence-parallel) UNet ranks: phase 1 = zero `stats` and accumulate the
  * fp64 sum / sum-of-squares of THIS rank's HW rows per (sample, group); the caller all-reduces `stats` across ranks;
@@ -319,6 +319,35 @@ int sx_marker_mask(const int64_t* ids, int T, int64_t boi, int64_t bop, int64_t 
 /* F.normalize(x) with its default dim=1 on x[B][T][D] fp32 (the token axis — ResamplerXLV2(normalize=True),
  * src/models/detokenizer/resampler.py:271-272): y = x / max(||x[b,:,d]||_2, eps). */
 int sx_l2norm_dim1(const float* x, float* y, int B, int T, int D, float eps, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * One-shot all-reduce / all-gather over peer-mapped device memory (csrc/comm.hip): the tensor-parallel decode step's
+ * 20 KB - 320 KB collectives as ONE graph-capturable kernel launch per rank. No reference counterpart (the reference is
+ * single-device inference; src/train/dist_utils.py:5-34 is its only collective code): north_star's TP requirement.
+ * The payload is cut into chunks of `chunk` floats (SX_ONESHOT_CHUNK unless overridden); one workgroup per chunk runs the
+ * whole publish / signal / wait / reduce protocol on its own epoch counter and flag row, all chunks in flight at once.
+ * Set-up (once): every rank sx_comm_alloc()s a staging area (2 x cap floats) and a flag array ((cap / chunk) x world x uint32),
+ * sx_ipc_export()s both, sends the 64-byte handles to its peers (any transport), sx_ipc_open()s the peers' handles and
+ * stores the world pointers in two DEVICE arrays (own buffers at index rank).
+ * ------------------------------------------------------------------------------------------------ */
+int sx_comm_alloc(void** ptr, uint64_t bytes);          /* zero-initialised device memory that can be exported        */
+int sx_comm_free(void* ptr);
+int sx_ipc_export(void* ptr, unsigned char* handle64);  /* hipIpcGetMemHandle: 64 opaque bytes                        */
+int sx_ipc_open(const unsigned char* handle64, void** ptr);
+int sx_ipc_close(void* ptr);
+#define SX_ONESHOT_CHUNK 4096 /* floats per workgroup: 16 KB                                                          */
+typedef struct sx_oneshot_args {
+  void* data;         /* fp32 [n]: all-reduce in place (gather_out == NULL) or the all-gather input                    */
+  void* gather_out;   /* fp32 [world][n] or NULL                                                                       */
+  const void* stage;  /* DEVICE array of `world` pointers: rank r's staging area                                       */
+  const void* flags;  /* DEVICE array of `world` pointers: rank r's flag array                                         */
+  void* epoch;        /* this rank's uint32 epoch counters [cap / chunk] (device, zero at start; advanced by the kernel) */
+  void* status;       /* uint32 (device): non-zero after a peer failed to arrive within max_spin polls                */
+  int32_t n, cap, rank, world;
+  uint32_t max_spin;  /* 0 = default (2^22 polls, a few seconds)                                                       */
+  int32_t chunk;      /* floats per workgroup, even, divides cap; 0 = SX_ONESHOT_CHUNK. Fixed for the life of the buffers */
+} sx_oneshot_args;
+int sx_allreduce_oneshot(const sx_oneshot_args* args, void* stream);
 
 #ifdef __cplusplus
 }

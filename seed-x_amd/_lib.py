@@ -32,6 +32,11 @@ class GemvArgs(C.Structure):
                 ("w_layout", c_i32), ("reserved", c_i32)]
 
 
+class OneshotArgs(C.Structure):
+    _fields_ = [("data", c_vp), ("gather_out", c_vp), ("stage", c_vp), ("flags", c_vp), ("epoch", c_vp), ("status", c_vp),
+                ("n", c_i32), ("cap", c_i32), ("rank", c_i32), ("world", c_i32), ("max_spin", C.c_uint32), ("chunk", c_i32)]
+
+
 class AttnArgs(C.Structure):
     _fields_ = [("Q", c_vp), ("K", c_vp), ("V", c_vp), ("O", c_vp),
                 ("B", c_i32), ("H", c_i32), ("Sq", c_i32), ("Skv", c_i32), ("D", c_i32), ("reserved", c_i32),
@@ -70,6 +75,12 @@ SIGNATURES = {
     "sx_attention": [C.POINTER(AttnArgs), c_vp],
     "sx_attention_variant": [c_i32],
     "sx_norm_tune": [c_i32, c_i32],
+    "sx_comm_alloc": [C.POINTER(c_vp), C.c_uint64],
+    "sx_comm_free": [c_vp],
+    "sx_ipc_export": [c_vp, C.c_char_p],
+    "sx_ipc_open": [C.c_char_p, C.POINTER(c_vp)],
+    "sx_ipc_close": [c_vp],
+    "sx_allreduce_oneshot": [C.POINTER(OneshotArgs), c_vp],
     "sx_attention_small": [C.POINTER(AttnSmallArgs), c_vp],
     "sx_attn_decode": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_i32, c_vp],
     "sx_rope_kv_append": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp],

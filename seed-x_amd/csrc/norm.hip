@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void layernorm_block_kernel(const void* x, voi
   }
 }
 
-static int g_gn_stat_blocks = 512;   // tuning hook (sx_norm_tune): target block count of the GroupNorm statistics pass
+static int g_gn_stat_blocks = 0;   // tuning hook (sx_norm_tune): block count of the GroupNorm statistics pass, 0 = by size
 
 // ---- GroupNorm over NHWC fp32 -----------------------------------------------------------------
 constexpr int GN_MAX_SLOTS2 = 6;  // C/2 pairs per row / 256 threads  (C <= 3072)
@@ -420,7 +420,14 @@ static int groupnorm_impl(const float* x, const float* x2, int C1, void* y, void
     SX_HIP_LAUNCH_CHECK();
     // stats: ~512 blocks in total — every block ends with 2*groups fp64 atomics on the same B*groups*2 words, so the
     // block count (not the byte count) bounds this kernel once the atomics serialise in L2
-    int rows_stats = (HW * B + g_gn_stat_blocks - 1) / g_gn_stat_blocks;
+    // block count: ~256 KB of fp32 input per block, 512..2048 blocks (tools/lab/gn_lab, profiles/r3_gn_lab.log: 512 blocks were
+    // right for the 32x32 / 64x64 levels, 3.4 TB/s instead of 6.0 at 128x128 x 320 and 1.7 instead of 3.6 on the VAE's 1024^2 x 128)
+    long nblk = g_gn_stat_blocks;
+    if (nblk <= 0) {
+      nblk = ((long)B * HW * C * 4) >> 18;
+      nblk = nblk < 512 ? 512 : (nblk > 2048 ? 2048 : nblk);
+    }
+    int rows_stats = (int)(((long)HW * B + nblk - 1) / nblk);
     if (rows_stats < 8) rows_stats = 8;
     const dim3 grid_s((HW + rows_stats - 1) / rows_stats, B);
     if (x2)
@@ -442,7 +449,7 @@ static int groupnorm_impl(const float* x, const float* x2, int C1, void* y, void
 }
 
 extern "C" int sx_norm_tune(int key, int value) {   // tuning hook: key 0 = block count of the GroupNorm statistics pass
-  if (key == 0 && value >= 64 && value <= 65536) { g_gn_stat_blocks = value; return SX_OK; }
+  if (key == 0 && (value == 0 || (value >= 64 && value <= 65536))) { g_gn_stat_blocks = value; return SX_OK; }
   SX_FAIL("sx_norm_tune: unknown key %d / value %d", key, value);
 }
 

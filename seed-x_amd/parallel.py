@@ -11,7 +11,8 @@ spread over several GPUs of a node:
     [G, H·W, 4] eps per step (256 KB at 1024 px) in front of the replicated CFG + Euler update.
 
 `Comm` is the only thing the model code sees. `TorchDistComm` maps it to torch.distributed (backend "nccl" = RCCL over
-xGMI on the GPU box, "gloo" in the CPU tests). `ThreadComm` runs `world` virtual ranks as threads of ONE process on ONE
+xGMI on the GPU box, "gloo" in the CPU tests); `IpcComm` runs the small decode-step collectives as one graph-capturable
+kernel launch over hipIpc-mapped peer buffers (csrc/comm.hip). `ThreadComm` runs `world` virtual ranks as threads of ONE process on ONE
 GPU — the single-GPU box the kernels are validated on cannot host a real multi-rank RCCL group, and the sharding
 arithmetic (which rows / columns / heads each rank owns, where the reductions sit) is what has to be proven.
 """
@@ -90,6 +91,111 @@ class TorchDistComm(Comm):
 
     def barrier(self):
         self._dist.barrier(group=self.group)
+
+
+class IpcComm(Comm):
+    """One process per GPU; all-reduce / all-gather of small fp32 payloads as ONE kernel launch per rank over peer-mapped
+    staging buffers (csrc/comm.hip: hipIpcMemHandle, epoch flags, rank-ordered reduction → the same bits on every rank, and
+    the same bits as ThreadComm's `parts[0] + parts[1] + …`). Graph-capturable: the kernel carries its epoch in device memory,
+    so the tensor-parallel decode step can be captured and replayed with its 80 all-reduces inside.
+
+    `bootstrap` is any torch.distributed group (gloo is enough): it only carries the 64-byte IPC handles at construction
+    and serves payloads above `cap_floats` (RCCL's ring is the right tool there). Peers may be other GPUs of the node
+    (xGMI peer access) or — how the 1-GPU test pool exercises the protocol — other processes on the SAME GPU."""
+    graph_safe = True
+
+    CHUNK = 4096                               # floats per workgroup (SX_ONESHOT_CHUNK in include/seedx_hip.h)
+
+    def __init__(self, bootstrap=None, cap_floats=131072, device=None, max_spin=0):
+        import ctypes as C
+        import torch.distributed as dist
+        from . import _lib
+        self._dist, self.group = dist, bootstrap
+        self.rank, self.world = dist.get_rank(bootstrap), dist.get_world_size(bootstrap)
+        self.cap, self.max_spin = -(-int(cap_floats) // self.CHUNK) * self.CHUNK, int(max_spin)
+        nchunk = self.cap // self.CHUNK
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self._lib = lib = _lib.load()
+        with torch.cuda.device(self.device):
+            own = []
+            for nbytes in (2 * self.cap * 4, nchunk * self.world * 4):                # staging (2 slots), flags [chunk][world]
+                p = C.c_void_p()
+                _lib.check(lib.sx_comm_alloc(C.byref(p), nbytes), "sx_comm_alloc")
+                own.append(p.value)
+            self._own = own
+            handles = []
+            for p in own:
+                h = C.create_string_buffer(64)
+                _lib.check(lib.sx_ipc_export(p, h), "sx_ipc_export")
+                handles.append(h.raw)
+            gathered = [None] * self.world
+            dist.all_gather_object(gathered, handles, group=bootstrap)
+            self._opened = []
+            stage_ptrs, flag_ptrs = [], []
+            for r in range(self.world):
+                if r == self.rank:
+                    stage_ptrs.append(own[0]); flag_ptrs.append(own[1])
+                    continue
+                ptrs = []
+                for h in gathered[r]:
+                    q = C.c_void_p()
+                    _lib.check(lib.sx_ipc_open(h, C.byref(q)), "sx_ipc_open")
+                    ptrs.append(q.value)
+                    self._opened.append(q.value)
+                stage_ptrs.append(ptrs[0]); flag_ptrs.append(ptrs[1])
+            self._stage = torch.tensor(stage_ptrs, dtype=torch.int64, device=self.device)
+            self._flags = torch.tensor(flag_ptrs, dtype=torch.int64, device=self.device)
+            self._epoch = torch.zeros(nchunk, dtype=torch.int32, device=self.device)
+            self._status = torch.zeros(1, dtype=torch.int32, device=self.device)
+            torch.cuda.synchronize()
+        dist.barrier(group=bootstrap)          # every rank has opened every handle before the first collective
+
+    def _launch(self, t, gather_out=None):
+        import ctypes as C
+        from . import _lib
+        a = _lib.OneshotArgs()
+        a.data, a.gather_out = t.data_ptr(), (gather_out.data_ptr() if gather_out is not None else None)
+        a.stage, a.flags = self._stage.data_ptr(), self._flags.data_ptr()
+        a.epoch, a.status = self._epoch.data_ptr(), self._status.data_ptr()
+        a.n, a.cap, a.rank, a.world, a.max_spin, a.chunk = t.numel(), self.cap, self.rank, self.world, self.max_spin, self.CHUNK
+        _lib.check(self._lib.sx_allreduce_oneshot(C.byref(a), torch.cuda.current_stream().cuda_stream), "sx_allreduce_oneshot")
+
+    def _fits(self, t):
+        return t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and 0 < t.numel() <= self.cap
+
+    def all_reduce(self, t):
+        if self._fits(t):
+            self._launch(t)
+        else:                                  # large / non-fp32 payloads: the bootstrap group's ring
+            self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self.group)
+        return t
+
+    def all_gather(self, t):
+        t = t.contiguous()
+        out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        if self._fits(t):
+            self._launch(t, gather_out=out)
+        else:
+            parts = [torch.empty_like(t) for _ in range(self.world)]
+            self._dist.all_gather(parts, t, group=self.group)
+            out = torch.stack(parts, dim=0)
+        return out
+
+    def check(self):
+        """Raises if a collective gave up waiting for a peer (host sync: call outside the hot loop)."""
+        st = int(self._status.item())
+        if st:
+            raise RuntimeError(f"IpcComm rank {self.rank}: a peer did not arrive in epoch {st} (bounded poll expired)")
+
+    def barrier(self):
+        self._dist.barrier(group=self.group)
+
+    def close(self):
+        for p in getattr(self, "_opened", []):
+            self._lib.sx_ipc_close(p)
+        for p in getattr(self, "_own", []):
+            self._lib.sx_comm_free(p)
+        self._opened, self._own = [], []
 
 
 class _ThreadShared:
