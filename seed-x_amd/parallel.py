@@ -68,7 +68,7 @@ class TorchDistComm(Comm):
     def all_gather(self, t):
         out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
         if t.is_cuda:
-            self._dist.all_gather_into_tensor(out, t.contiguous(), group=self.group)
+            self._dist.all_gather_into_tensor(out.view(-1), t.contiguous().view(-1), group=self.group)   # flat: any backend
         else:                                          # gloo: list form
             parts = [torch.empty_like(t) for _ in range(self.world)]
             self._dist.all_gather(parts, t.contiguous(), group=self.group)
@@ -81,7 +81,7 @@ class TorchDistComm(Comm):
         if not t.is_cuda:
             return _Done(self.all_gather(t))
         out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
-        work = self._dist.all_gather_into_tensor(out, t.contiguous(), group=self.group, async_op=True)
+        work = self._dist.all_gather_into_tensor(out.view(-1), t.contiguous().view(-1), group=self.group, async_op=True)
 
         class _H:
             def wait(_s):
