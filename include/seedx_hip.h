@@ -30,6 +30,10 @@ extern "C" {
 #define SX_BF16 1
 #define SX_F32 2
 #define SX_BF16X3 3 /* sx_groupnorm* outputs only: bf16 planes [hi | hi | lo] per row, 3*C columns (see sx_split_bf16) */
+/* OR-ed into a 16-bit OUTPUT dtype of the decode-step producers (sx_layernorm with rows <= 16, sx_attn_decode_b, sx_gemv):
+ * the [rows <= 16][cols] result is written as MFMA operand tiles [cols/32][16][32] — what sx_gemv reads with x_layout = 1
+ * (tile t = columns 32t .. 32t+31 of all 16 rows, 1 KB contiguous; rows >= `rows` of a tile are not written). */
+#define SX_TILED16 0x100
 
 /* epilogue activations */
 #define SX_ACT_NONE 0
@@ -105,11 +109,22 @@ typedef struct sx_gemv_args {
   int32_t dtype, out_dtype, act, glu;
   int32_t w_layout;    /* 0: W row-major [N][K]. 1: decode tiles [N/16][K/32][16][32] (each 16-row x 32-k MFMA operand tile
                         * is 1 KB contiguous, tiles of a row group follow each other along K): MFMA path only (M >= 2) */
-  int32_t reserved;
+  int32_t x_layout;    /* 0: x row-major [M][K]. 1: operand tiles [K/32][16][32] (tile t holds x[0..15][32t .. 32t+31], rows >= M
+                        * are padding with any finite content; 16 * K elements in all): MFMA path only */
+  void* workspace;     /* optional, MFMA path: device scratch for split-K over workgroups (shapes whose N / 16 row groups do not
+                        * fill the chip). Layout: 16 KB of arrival counters, then the partial sums. Must be ZERO when first used
+                        * and is left with its counters at zero; bytes >= 16384 + 8 * 16 * N * 4 allows every split factor
+                        * (smaller: no split). One launch at a time per
+                        * workspace (launches on one stream are fine). NULL: never split. Results are deterministic either way
+                        * (partials are added in split order by the last workgroup to arrive). */
+  uint64_t workspace_bytes;
 } sx_gemv_args;
 int sx_gemv(const sx_gemv_args* args, void* stream);
 /* test hook: 1 = always take the VALU path (lets the tests compare both), 0 = automatic */
 int sx_gemv_force_valu(int on);
+/* tuning hook (tools/lab/gemv_lab): key 2 = split-K factor of the MFMA skinny GEMM when a workspace is given:
+ * 0 automatic, -1 / 1 never, 2 / 4 / 8 forced */
+int sx_gemv_tune(int key, int value);
 
 /* ------------------------------------------------------------------------------------------------
  * Normalisations (row reductions with wave shuffles, fp32 statistics)

@@ -10,6 +10,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libseedx_hip.so")
 
 SX_F16, SX_BF16, SX_F32 = 0, 1, 2
 SX_BF16X3 = 3          # sx_groupnorm* output only: bf16 planes [hi | hi | lo] per row
+SX_TILED16 = 0x100     # OR-ed into a 16-bit out dtype: decode operand tiles [cols/32][16][32] (include/seedx_hip.h)
 SX_ACT_NONE, SX_ACT_GELU, SX_ACT_SILU = 0, 1, 2
 SX_A_LINEAR, SX_A_CONV3X3 = 0, 1
 
@@ -29,7 +30,7 @@ class GemvArgs(C.Structure):
     _fields_ = [("x", c_vp), ("W", c_vp), ("y", c_vp), ("residual", c_vp),
                 ("M", c_i32), ("N", c_i32), ("K", c_i32),
                 ("dtype", c_i32), ("out_dtype", c_i32), ("act", c_i32), ("glu", c_i32),
-                ("w_layout", c_i32), ("reserved", c_i32)]
+                ("w_layout", c_i32), ("x_layout", c_i32), ("workspace", c_vp), ("workspace_bytes", C.c_uint64)]
 
 
 class OneshotArgs(C.Structure):
@@ -75,6 +76,7 @@ SIGNATURES = {
     "sx_attention": [C.POINTER(AttnArgs), c_vp],
     "sx_attention_variant": [c_i32],
     "sx_norm_tune": [c_i32, c_i32],
+    "sx_gemv_tune": [c_i32, c_i32],
     "sx_comm_alloc": [C.POINTER(c_vp), C.c_uint64],
     "sx_comm_free": [c_vp],
     "sx_ipc_export": [c_vp, C.c_char_p],

@@ -14,6 +14,10 @@ struct GemvP {
   const float* residual;
   int M, N, K, out_dtype, act, glu;
   int packed;   // W is in the decode layout [N/16][K/32][16 rows][32 k] (one MFMA operand tile = 1 KB contiguous)
+  int y_tiled;  // y is written as operand tiles [n_out/32][16][32] (16-bit outputs)
+  int x_tiled;  // x is in operand tiles [K/32][16 rows][32 k] (one 1-KB tile per MFMA B operand; rows >= M are padding)
+  unsigned* ws_cnt;   // split-K: arrival counters [N/16] (zero between launches)
+  float* ws_part;     //          partial sums [S][16][N]
 };
 
 template <typename TT, int MR>
@@ -97,18 +101,27 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvP p) {
 // non-temporal loads per lane; each load instruction covers one 64-B half line of 16 rows: lane group g = lane >> 4 reads
 // bytes [16g, 16g + 16) of it, which is exactly the MFMA's k-slot layout, no shuffle). 4 k-steps are in flight per wave
 // (8-16 KB). Partial sums meet in LDS; wave 0 runs the fused epilogue (act / GLU / fp32 residual / store).
-template <typename TT, int R, int NWV>
+template <typename TT, int R, int NWV, int U>
 __global__ __launch_bounds__(NWV * 64) void gemm_skinny_kernel(const GemvP p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   typedef typename TT::vec8 vec8;
   __shared__ float red[NWV][R][64][4];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // the wave index as a SCALAR: everything derived from it (k range, round counts) then lives in SGPRs and the guards below
+  // are scalar branches. With a VGPR-derived count the compiler predicates the guarded MFMAs through EXEC instead — and
+  // MFMA ignores EXEC: the skipped k-steps' (never loaded) registers were multiplied in (found by tools/lab/gemv_lab).
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = lane & 15, g = lane >> 4;
   const int n0 = blockIdx.x * 16 * R;
   const int nks = p.K >> 6;
-  const int ks0 = wave * nks / NWV, ks1 = (wave + 1) * nks / NWV;
+  const int S = gridDim.y;                                           // split-K workgroups per row group (1 = none)
+  const int nsl = NWV * S, sl = blockIdx.y * NWV + wave;             // k slices: split-K workgroups x waves
+  const int ks0 = sl * nks / nsl, ks1 = (sl + 1) * nks / nsl;
   const bool mvalid = r < p.M;
-  const unsigned short* xp = p.x + (size_t)(mvalid ? r : 0) * p.K + 8 * g;
+  // row-major x: a load instruction touches 16 rows 2K bytes apart — for K = 5120 that stride is a multiple of 16 cache
+  // lines, so all 16 rows (and every wave on the chip, in step) hit the same L2 channel. Tiled x: the same instruction reads
+  // one contiguous 1-KB tile, consecutive k-steps are consecutive tiles.
+  const unsigned short* xp = p.x_tiled ? p.x + r * 32 + 8 * g : p.x + (size_t)(mvalid ? r : 0) * p.K + 8 * g;
+  const size_t xstep = p.x_tiled ? 1024 : 64, xhalf = p.x_tiled ? 512 : 32;
   // row-major W: a load instruction covers one 64-B half line of 16 rows (row stride 2K bytes). Decode layout: the same
   // instruction covers one contiguous 1-KB operand tile, a wave's k range is one contiguous stream.
   const unsigned short* wp[R];
@@ -120,42 +133,74 @@ __global__ __launch_bounds__(NWV * 64) void gemm_skinny_kernel(const GemvP p) {
   f32x4_t acc[R];
 #pragma unroll
   for (int q = 0; q < R; ++q) acc[q] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  const u32x4_t zero = {0u, 0u, 0u, 0u};
-  constexpr int U = 4;
-  int ks = ks0;
-  for (; ks + U <= ks1; ks += U) {
-    u32x4_t wa[U][R], wb[U][R], xa[U], xb[U];
+  // Rounds of U k-steps through TWO register sets: round i+1's loads are issued before round i is consumed, so 1-2 rounds
+  // (U..2U KB per row group and wave) are in flight at every moment. The pipelined loop has no branch inside (the waitcnt
+  // pass then emits exact vmcnt(N) waits; with a guard inside it falls back to vmcnt(0) before the first MFMA — measured:
+  // ~25 GB/s per CU, the latency-bound rate of one round in flight). Last full rounds and the < U remainder are peeled.
+  struct Frag { u32x4_t wa[U][R], wb[U][R], xa[U], xb[U]; };
+  auto load_round = [&](Frag& f, int ks, int cnt) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const size_t k = (size_t)(ks + u) * 64;
+      if (u < cnt) {
+        const size_t k = (size_t)(ks + u) * xstep;
 #pragma unroll
-      for (int q = 0; q < R; ++q) {
-        wa[u][q] = __builtin_nontemporal_load((const u32x4_t*)(wp[q] + (size_t)(ks + u) * kstep));
-        wb[u][q] = __builtin_nontemporal_load((const u32x4_t*)(wp[q] + (size_t)(ks + u) * kstep + khalf));
+        for (int q = 0; q < R; ++q) {
+          f.wa[u][q] = __builtin_nontemporal_load((const u32x4_t*)(wp[q] + (size_t)(ks + u) * kstep));
+          f.wb[u][q] = __builtin_nontemporal_load((const u32x4_t*)(wp[q] + (size_t)(ks + u) * kstep + khalf));
+        }
+        f.xa[u] = *(const u32x4_t*)(xp + k);
+        f.xb[u] = *(const u32x4_t*)(xp + k + xhalf);
       }
-      xa[u] = *(const u32x4_t*)(xp + k);
-      xb[u] = *(const u32x4_t*)(xp + k + 32);
     }
+  };
+  auto consume = [&](const Frag& f, int cnt) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const vec8 a = __builtin_bit_cast(vec8, mvalid ? xa[u] : zero), b = __builtin_bit_cast(vec8, mvalid ? xb[u] : zero);
+      if (u < cnt) {
+        // lanes of rows >= M carry row 0's x: their output columns (m >= M) are never stored, and an MFMA output column depends
+        // on its own B column only — no select on the loaded registers (a VALU op on them at the top of the round makes the
+        // waitcnt pass drain every load in flight)
+        const vec8 a = __builtin_bit_cast(vec8, f.xa[u]), b = __builtin_bit_cast(vec8, f.xb[u]);
 #pragma unroll
-      for (int q = 0; q < R; ++q) {
-        acc[q] = TT::mfma16(__builtin_bit_cast(vec8, wa[u][q]), a, acc[q]);
-        acc[q] = TT::mfma16(__builtin_bit_cast(vec8, wb[u][q]), b, acc[q]);
+        for (int q = 0; q < R; ++q) {
+          acc[q] = TT::mfma16(__builtin_bit_cast(vec8, f.wa[u][q]), a, acc[q]);
+          acc[q] = TT::mfma16(__builtin_bit_cast(vec8, f.wb[u][q]), b, acc[q]);
+        }
       }
     }
-  }
-  for (; ks < ks1; ++ks) {
-    const size_t k = (size_t)ks * 64;
-    const u32x4_t xa = *(const u32x4_t*)(xp + k), xb = *(const u32x4_t*)(xp + k + 32);
-    const vec8 a = __builtin_bit_cast(vec8, mvalid ? xa : zero), b = __builtin_bit_cast(vec8, mvalid ? xb : zero);
-#pragma unroll
-    for (int q = 0; q < R; ++q) {
-      const u32x4_t wa = __builtin_nontemporal_load((const u32x4_t*)(wp[q] + (size_t)ks * kstep));
-      const u32x4_t wb = __builtin_nontemporal_load((const u32x4_t*)(wp[q] + (size_t)ks * kstep + khalf));
-      acc[q] = TT::mfma16(__builtin_bit_cast(vec8, wa), a, acc[q]);
-      acc[q] = TT::mfma16(__builtin_bit_cast(vec8, wb), b, acc[q]);
+  };
+  {
+    Frag A, B;
+    const int full = (ks1 - ks0) / U, rem = (ks1 - ks0) % U;
+    int i = 0;
+    if (full > 0) {
+      load_round(A, ks0, U);
+      for (; i + 2 < full; i += 2) {
+        // sched_barrier: the machine scheduler otherwise hoists the next round's loads above this round's MFMAs (renaming
+        // the registers), which turns the loop back into "issue everything, then wait for everything"
+        load_round(B, ks0 + (i + 1) * U, U);
+        __builtin_amdgcn_sched_barrier(0);
+        consume(A, U);
+        __builtin_amdgcn_sched_barrier(0);
+        load_round(A, ks0 + (i + 2) * U, U);
+        __builtin_amdgcn_sched_barrier(0);
+        consume(B, U);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (i + 2 == full) {
+        load_round(B, ks0 + (i + 1) * U, U);
+        consume(A, U);
+        if (rem) load_round(A, ks0 + full * U, rem);
+        consume(B, U);
+      } else {
+        if (rem) load_round(B, ks0 + full * U, rem);
+        consume(A, U);
+        if (rem) { consume(B, rem); }
+      }
+      if (i + 2 == full && rem) consume(A, rem);
+    } else if (rem) {
+      load_round(A, ks0, rem);
+      consume(A, rem);
     }
   }
 #pragma unroll
@@ -175,6 +220,37 @@ __global__ __launch_bounds__(NWV * 64) void gemm_skinny_kernel(const GemvP p) {
       for (int w = 0; w < NWV; ++w) t += red[w][q][lane][e];
       v[q][e] = t;
     }
+  if (S > 1) {
+    // split-K: every workgroup publishes its partial [16][16R] block; the LAST one to arrive (per row group) adds the S partials
+    // in split order — the result does not depend on which workgroup that is — and runs the epilogue. The counter is left at 0.
+#pragma unroll
+    for (int q = 0; q < R; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        __hip_atomic_store(p.ws_part + ((size_t)blockIdx.y * 16 + r) * p.N + n0 + q * 16 + 4 * g + e, v[q][e], __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    // No cache-wide fence (an agent-scope release / acquire writes back and invalidates the whole per-XCD L2 — measured 4x
+    // slower kernels): the partials themselves move as agent-scope (sc1) atomics, which are performed at the device's
+    // coherence point, so ordering them against the counter only needs "my stores are acknowledged" before the count and
+    // "count seen" before the loads.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned old = 0;
+    if (lane == 0) old = __hip_atomic_fetch_add(p.ws_cnt + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    old = __shfl(old, 0);
+    if (old != (unsigned)(S - 1)) return;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int q = 0; q < R; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float t = 0.f;
+        for (int sidx = 0; sidx < S; ++sidx)
+          t += __hip_atomic_load(p.ws_part + ((size_t)sidx * 16 + r) * p.N + n0 + q * 16 + 4 * g + e, __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_AGENT);
+        v[q][e] = t;
+      }
+    if (lane == 0) __hip_atomic_store(p.ws_cnt + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   if (!mvalid) return;
   const int ncols = p.glu ? p.N / 2 : p.N;
 #pragma unroll
@@ -193,7 +269,12 @@ __global__ __launch_bounds__(NWV * 64) void gemm_skinny_kernel(const GemvP p) {
     }
     const size_t off = (size_t)r * ncols + col;
     if (p.residual) o += *(const f32x4_t*)(p.residual + off);
-    if (p.out_dtype == SX_F32) {
+    if (p.y_tiled) {      // 16-bit operand tiles [ncols/32][16][32] for the next skinny GEMM (x_layout = 1)
+      u32x2_t w2;
+      if (p.out_dtype == SX_BF16) { w2[0] = pack2<BF16>(o[0], o[1]); w2[1] = pack2<BF16>(o[2], o[3]); }
+      else { w2[0] = pack2<F16>(o[0], o[1]); w2[1] = pack2<F16>(o[2], o[3]); }
+      *(u32x2_t*)((unsigned short*)p.y + (size_t)(col >> 5) * 512 + (size_t)r * 32 + (col & 31)) = w2;
+    } else if (p.out_dtype == SX_F32) {
       *(f32x4_t*)((float*)p.y + off) = o;
     } else {
       u32x2_t w2;
@@ -301,11 +382,10 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const unsigned short* 
 }
 
 template <typename TT>
-__global__ void attn_decode_combine_kernel(const float* scratch, unsigned short* out, int D, int nsplit) {
+__global__ void attn_decode_combine_kernel(const float* scratch, unsigned short* out, int D, int nsplit, int tiled) {
   const int h = blockIdx.x, d = threadIdx.x, g = blockIdx.y, H = gridDim.x;
   if (d >= D) return;
   scratch += (size_t)g * H * nsplit * (D + 2);
-  out += (size_t)g * H * D;
   const float* base = scratch + (size_t)h * nsplit * (D + 2);
   float mg = -INFINITY;
   for (int s = 0; s < nsplit; ++s) mg = fmaxf(mg, base[(size_t)s * (D + 2) + D]);
@@ -316,7 +396,9 @@ __global__ void attn_decode_combine_kernel(const float* scratch, unsigned short*
     acc += w * base[(size_t)s * (D + 2) + d];
     l += w * base[(size_t)s * (D + 2) + D + 1];
   }
-  out[(size_t)h * D + d] = TT::from_f32(l > 0.f ? acc / l : 0.f);
+  const int col = h * D + d;                     // of row g in [G][H*D]; SX_TILED16: tile col/32, row g, column col%32
+  const size_t o = tiled ? (size_t)(col >> 5) * 512 + (size_t)g * 32 + (col & 31) : (size_t)g * H * D + col;
+  out[o] = TT::from_f32(l > 0.f ? acc / l : 0.f);
 }
 
 // ---- RoPE + KV append ----------------------------------------------------------------------------------------------
@@ -449,6 +531,12 @@ inline dim3 gs_grid(int64_t n) {
 using namespace sxk_decode;
 
 #define ST ((hipStream_t)stream)
+static int g_skinny_var[3] = {0, 0, 0};  // tuning hook (sx_gemv_tune): [2] = split-K factor (0 auto, -1 never, 2 / 4 / 8 forced)
+extern "C" int sx_gemv_tune(int key, int value) {
+  SX_CHECK(key == 2 && (value == -1 || value == 0 || value == 1 || value == 2 || value == 4 || value == 8), "sx_gemv_tune: key %d value %d", key, value);
+  g_skinny_var[key] = value;
+  return SX_OK;
+}
 static int g_force_valu_gemv = 0;   // test hook (sx_gemv_force_valu): compare the two GEMV paths
 extern "C" int sx_gemv_force_valu(int on) { g_force_valu_gemv = on; return SX_OK; }   // 1 = VALU only, 2 = MFMA whenever legal
 
@@ -460,20 +548,42 @@ extern "C" int sx_gemv(const sx_gemv_args* a, void* stream) {
   SX_CHECK(!a->glu || a->N % 32 == 0, "sx_gemv: glu needs N %% 32 == 0");
   GemvP p;
   p.x = (const unsigned short*)a->x; p.W = (const unsigned short*)a->W; p.y = a->y; p.residual = a->residual;
-  p.M = a->M; p.N = a->N; p.K = a->K; p.out_dtype = a->out_dtype; p.act = a->act; p.glu = a->glu;
+  p.M = a->M; p.N = a->N; p.K = a->K; p.out_dtype = a->out_dtype & 0xff; p.act = a->act; p.glu = a->glu;
+  p.y_tiled = (a->out_dtype & SX_TILED16) ? 1 : 0;
+  SX_CHECK(!p.y_tiled || ((p.out_dtype == SX_F16 || p.out_dtype == SX_BF16) && (a->glu ? a->N / 2 : a->N) % 32 == 0),
+           "sx_gemv: SX_TILED16 needs a 16-bit output with n_out %% 32 == 0");
   p.packed = a->w_layout;
+  p.ws_cnt = nullptr; p.ws_part = nullptr;
+  p.x_tiled = a->x_layout;
+  SX_CHECK(a->x_layout == 0 || a->x_layout == 1, "sx_gemv: x_layout must be 0 (row-major) or 1 (operand tiles)");
   SX_CHECK(a->w_layout == 0 || a->w_layout == 1, "sx_gemv: w_layout must be 0 (row-major) or 1 (decode tiles)");
   // MI355X (tools/bench_gemv.py, 13B shapes): VALU path 6.5 / 4.7 / 3.0 TB/s at M = 1 / 4 / 8, MFMA path 4.0-4.4 TB/s at any M
   const bool mfma_ok = a->M >= 2 && a->K % 64 == 0 && a->K >= 256 && a->N % 32 == 0;
   SX_CHECK(!a->w_layout || (mfma_ok && a->K % 64 == 0), "sx_gemv: the decode-tile layout needs M >= 2, K %% 64 == 0, K >= 256, N %% 32 == 0");
   // the decode-tile layout only exists for the MFMA kernel: it overrides the VALU test hook
-  if (mfma_ok && (a->w_layout || (g_force_valu_gemv != 1 && (a->M >= 5 || g_force_valu_gemv == 2)))) {
+  SX_CHECK(!p.y_tiled || mfma_ok, "sx_gemv: a tiled output needs the MFMA path (M >= 2, K %% 64 == 0, K >= 256, N %% 32 == 0)");
+  SX_CHECK(!a->x_layout || mfma_ok, "sx_gemv: tiled x needs the MFMA path (M >= 2, K %% 64 == 0, K >= 256, N %% 32 == 0)");
+  if (mfma_ok && (a->w_layout || a->x_layout || p.y_tiled || (g_force_valu_gemv != 1 && (a->M >= 5 || g_force_valu_gemv == 2)))) {
     // MFMA skinny GEMM: R = 2 row groups per wave for GLU (one packed group) or when that still gives >= 256 blocks
     const bool r2 = a->glu || a->N / 32 >= 256;
-    const dim3 grid(r2 ? a->N / 32 : a->N / 16), block(256);
-#define SX_SK_GO(TT)                                                                        \
-    if (r2) hipLaunchKernelGGL((gemm_skinny_kernel<TT, 2, 4>), grid, block, 0, ST, p);      \
-    else hipLaunchKernelGGL((gemm_skinny_kernel<TT, 1, 4>), grid, block, 0, ST, p);
+    const int gx = r2 ? a->N / 32 : a->N / 16;
+    // split-K over workgroups when the row groups alone do not fill the chip (N = 5120: 320 workgroups on 256 CUs, the CUs
+    // with two of them set the time) AND the kernel is long enough to pay for the second pass (publish, count, re-read: ~4 us
+    // at the kernel's tail): tools/lab/gemv_lab — down 5120x13824 36.8 -> 33.0 us with S = 4, o 5120x5120 15.4 -> 17.6 (never)
+    int S = 1;
+    if (a->workspace) {
+      if (g_skinny_var[2] > 0) S = g_skinny_var[2];
+      else if (g_skinny_var[2] == 0 && a->K >= 8192) while (S < 8 && gx * S < 1024 && (a->K / 64) / (2 * S * 4) >= 4) S *= 2;
+      const uint64_t cnt_bytes = 16384;    // fixed, so launches of different N can share one workspace (their partial regions
+                                           // may overlap — launches are serial — but never reach the counters)
+      if (S > 1 && (gx > 4096 || cnt_bytes + (uint64_t)S * 16 * a->N * 4 > a->workspace_bytes)) S = 1;   // too small: no split
+      p.ws_cnt = (unsigned*)a->workspace;
+      p.ws_part = (float*)((char*)a->workspace + cnt_bytes);
+    }
+    const dim3 grid(gx, S);
+#define SX_SK_GO(TT)                                                                                   \
+    if (r2) hipLaunchKernelGGL((gemm_skinny_kernel<TT, 2, 4, 4>), grid, dim3(256), 0, ST, p);           \
+    else hipLaunchKernelGGL((gemm_skinny_kernel<TT, 1, 4, 4>), grid, dim3(256), 0, ST, p);
     if (a->dtype == SX_BF16) { SX_SK_GO(BF16) } else { SX_SK_GO(F16) }
 #undef SX_SK_GO
     SX_HIP_LAUNCH_CHECK();
@@ -503,18 +613,21 @@ extern "C" int sx_attn_decode_b(const void* q, const void* kcache, const void* v
   SX_CHECK(q && kcache && vcache && out && scratch && ctx_len_dev, "sx_attn_decode: null pointer");
   SX_CHECK(D % 8 == 0 && D <= 128, "sx_attn_decode: head_dim %d", D);
   SX_CHECK(nsplit >= 1 && nsplit <= 64 && G >= 1, "sx_attn_decode: nsplit/G");
+  const int tiled = (dtype & SX_TILED16) ? 1 : 0;   // the OUTPUT as operand tiles [H*D/32][16][32] (q and the caches are as always)
+  dtype &= 0xff;
+  SX_CHECK(!tiled || (G <= 16 && (H * D) % 32 == 0), "sx_attn_decode: SX_TILED16 needs G <= 16 and H*D %% 32 == 0");
   if (dtype == SX_BF16) {
     hipLaunchKernelGGL(attn_decode_kernel<BF16>, dim3(H, nsplit, G), dim3(256), 0, ST, (const unsigned short*)q,
                        (const unsigned short*)kcache, (const unsigned short*)vcache, scratch, ctx_len_dev, D, Tmax,
                        nsplit, scale, (long long)cache_seq_stride);
     hipLaunchKernelGGL(attn_decode_combine_kernel<BF16>, dim3(H, G), dim3(128), 0, ST, scratch, (unsigned short*)out, D,
-                       nsplit);
+                       nsplit, tiled);
   } else {
     hipLaunchKernelGGL(attn_decode_kernel<F16>, dim3(H, nsplit, G), dim3(256), 0, ST, (const unsigned short*)q,
                        (const unsigned short*)kcache, (const unsigned short*)vcache, scratch, ctx_len_dev, D, Tmax,
                        nsplit, scale, (long long)cache_seq_stride);
     hipLaunchKernelGGL(attn_decode_combine_kernel<F16>, dim3(H, G), dim3(128), 0, ST, scratch, (unsigned short*)out, D,
-                       nsplit);
+                       nsplit, tiled);
   }
   SX_HIP_LAUNCH_CHECK();
   return SX_OK;

@@ -121,7 +121,11 @@ __global__ __launch_bounds__(256) void layernorm_block_kernel(const void* x, voi
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
     const int i = tid + 256 * k;
-    if (i < n4) store4(y, out_dt, base4 + i, (v[k] - mean) * rstd * g[k] + b[k]);
+    if (i < n4) {
+      // SX_TILED16: element (row, col) lives at tile col/32, row `row`, column col%32 of [cols/32][16][32]
+      const size_t o4 = (out_dt & SX_TILED16) ? ((size_t)(i >> 3) * 512 + (size_t)row * 32 + (size_t)(i & 7) * 4) >> 2 : base4 + i;
+      store4(y, out_dt & 0xff, o4, (v[k] - mean) * rstd * g[k] + b[k]);
+    }
   }
 }
 
@@ -353,7 +357,10 @@ extern "C" int sx_layernorm(const void* x, int in_dtype, void* y, int out_dtype,
                             const float* beta, int rows, int cols, float eps, int rms, void* stream) {
   SX_CHECK(x && y && gamma, "sx_layernorm: null pointer");
   SX_CHECK(rows > 0 && cols > 0 && cols % 4 == 0, "sx_layernorm: rows=%d cols=%d (cols %% 4 must be 0)", rows, cols);
-  SX_CHECK(out_dtype >= SX_F16 && out_dtype <= SX_F32, "sx_layernorm: bad out dtype");
+  const bool tiled = (out_dtype & SX_TILED16) != 0;
+  SX_CHECK(!tiled || (rows <= 16 && cols % 32 == 0 && ((out_dtype & 0xff) == SX_F16 || (out_dtype & 0xff) == SX_BF16)),
+           "sx_layernorm: SX_TILED16 needs rows <= 16, cols %% 32 == 0 and a 16-bit output (rows=%d cols=%d)", rows, cols);
+  SX_CHECK((out_dtype & 0xff) >= SX_F16 && (out_dtype & 0xff) <= SX_F32 && (out_dtype & ~0x1ff) == 0, "sx_layernorm: bad out dtype");
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((rows + 3) / 4), block(256);
   const int n4 = cols / 4;

@@ -167,6 +167,11 @@ class LlamaForCausalLM:
             lw = P["layers"][-1]
             for k in ("wqkv", "wo", "wgu", "wd"):
                 lw[k + "_t"] = tiles(lw[k])
+        # every decode GEMV has the decode-tile weight copy → its 16-bit inputs travel as operand tiles too (_layers_single)
+        P["decode_tiled"] = all(lw[k + "_t"] is not None for lw in P["layers"] for k in ("wqkv", "wo", "wgu", "wd")) \
+            and (self.nh_l * self.hd) % 32 == 0
+        # split-K scratch of the skinny GEMM: counters + 8 partial [16, H] blocks (include/seedx_hip.h: sx_gemv_args.workspace)
+        P["gemv_ws"] = torch.zeros(16384 + 8 * 16 * self.H * 4, dtype=torch.uint8, device=dev) if P["decode_tiled"] else None
         inv = 1.0 / (self.config.rope_base ** (torch.arange(0, self.hd, 2).float() / self.hd))
         fr = torch.outer(torch.arange(self.Tmax).float(), inv)           # [Tmax, hd/2] fp32 (:97-113)
         P["cos"], P["sin"] = fr.cos().to(dev).contiguous(), fr.sin().to(dev).contiguous()
@@ -255,18 +260,22 @@ class LlamaForCausalLM:
         comm, lead = self.comm, self.comm.rank == 0
         eps = self.config.rms_norm_eps
         scale = 1.0 / math.sqrt(hd)
+        # G >= 5 sequences run the MFMA skinny GEMM: its 16-bit inputs then travel as operand tiles (ops.Tiled16) from the
+        # kernel that produces them (norm, attention combine, GLU epilogue) — one contiguous 1-KB load per operand instead of
+        # 16 rows that all sit on the same L2 channel — and the down projection may split K over workgroups (workspace)
+        tl, ws = P["decode_tiled"] and G >= 5, P["gemv_ws"]
         for li, lw in enumerate(P["layers"]):
-            h = ops.rmsnorm(x, lw["ln1"], eps, dt)
+            h = ops.rmsnorm(x, lw["ln1"], eps, dt, tiled=tl)
             qkv = ops.gemv(h, lw["wqkv"], w_tiles=lw["wqkv_t"])                       # [G, 3H]
             ops.rope_kv_append_b(qkv, P["kc"][li], P["vc"][li], P["cos"], P["sin"], P["pos"], G, 1, nh, hd)
             q = qkv[:, :H] if G == 1 else qkv[:, :H].contiguous()                    # [G, H] (plumbing copy for G > 1)
-            att = ops.attn_decode_b(q.view(G, nh, hd), P["kc"][li], P["vc"][li], P["ctx"], scale)
+            att = ops.attn_decode_b(q.view(G, nh, hd), P["kc"][li], P["vc"][li], P["ctx"], scale, out_tiled=tl)
             x = comm.all_reduce(ops.gemv(att, lw["wo"], residual=x if lead else None, out_dtype=torch.float32,
-                                         w_tiles=lw["wo_t"]))
-            h = ops.rmsnorm(x, lw["ln2"], eps, dt)
-            g = ops.gemv(h, lw["wgu"], act="silu", glu=True, w_tiles=lw["wgu_t"])
+                                         w_tiles=lw["wo_t"], workspace=ws))
+            h = ops.rmsnorm(x, lw["ln2"], eps, dt, tiled=tl)
+            g = ops.gemv(h, lw["wgu"], act="silu", glu=True, w_tiles=lw["wgu_t"], y_tiled=tl)
             x = comm.all_reduce(ops.gemv(g, lw["wd"], residual=x if lead else None, out_dtype=torch.float32,
-                                         w_tiles=lw["wd_t"]))
+                                         w_tiles=lw["wd_t"], workspace=ws))
         ops.add_i32(P["pos"], 1)
         ops.add_i32(P["ctx"], 1)
         return x

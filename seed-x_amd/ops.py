@@ -138,27 +138,62 @@ def pack_decode_tiles(w):
     return w.view(N // 16, 16, K // 32, 32).permute(0, 2, 1, 3).contiguous().view(N, K)
 
 
-def gemv(x, w, residual=None, act=None, glu=False, out_dtype=None, w_tiles=None):
-    """w_tiles: the same weight in the decode layout (pack_decode_tiles); used instead of w when the MFMA path runs."""
+class Tiled16:
+    """A [rows <= 16, cols] 16-bit activation of the decode step held as MFMA operand tiles [cols/32][16][32] (SX_TILED16 in
+    include/seedx_hip.h): what the skinny GEMM reads with one contiguous 1-KB load per operand. Rows >= `rows` are padding."""
+    __slots__ = ("t", "rows", "cols")
+
+    def __init__(self, rows, cols, dtype, device):
+        assert rows <= 16 and cols % 32 == 0
+        self.t, self.rows, self.cols = torch.empty((cols // 32, 16, 32), dtype=dtype, device=device), rows, cols
+
+    @property
+    def dtype(self):
+        return self.t.dtype
+
+    def dense(self):
+        """[rows, cols] row-major copy (tests)."""
+        return self.t.permute(1, 0, 2).reshape(16, self.cols)[:self.rows].contiguous()
+
+
+def gemv(x, w, residual=None, act=None, glu=False, out_dtype=None, w_tiles=None, y_tiled=False, workspace=None):
+    """w_tiles: the same weight in the decode layout (pack_decode_tiles); used instead of w when the MFMA path runs.
+    x may be a Tiled16 (then w_tiles is required); y_tiled returns the 16-bit result as a Tiled16 for the next gemv.
+    workspace: zero-initialised uint8 scratch enabling split-K over workgroups for shapes that need it (sx_gemv_args.workspace)."""
     lib = _lib.load()
-    assert x.dim() == 2 and x.is_contiguous() and w.is_contiguous() and x.dtype == w.dtype
-    M, K = x.shape
+    xt = isinstance(x, Tiled16)
+    if xt:
+        M, K = x.rows, x.cols
+        assert w_tiles is not None and x.dtype == w.dtype
+    else:
+        assert x.dim() == 2 and x.is_contiguous() and w.is_contiguous() and x.dtype == w.dtype
+        M, K = x.shape
     N = w.shape[0]
     n_out = N // 2 if glu else N
     out_dtype = out_dtype or x.dtype
-    y = torch.empty((M, n_out), dtype=out_dtype, device=x.device)
+    dev = x.t.device if xt else x.device
+    if y_tiled:
+        yt = Tiled16(M, n_out, out_dtype, dev)
+        y = yt.t
+    else:
+        y = torch.empty((M, n_out), dtype=out_dtype, device=dev)
     args = GemvArgs()
-    args.x, args.W, args.y = x.data_ptr(), w.data_ptr(), y.data_ptr()
+    args.x, args.W, args.y = (x.t if xt else x).data_ptr(), w.data_ptr(), y.data_ptr()
+    args.x_layout = 1 if xt else 0
+    if workspace is not None:
+        args.workspace, args.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
     if residual is not None:
         assert residual.dtype == torch.float32 and residual.is_contiguous() and residual.shape == (M, n_out)
         args.residual = residual.data_ptr()
     args.M, args.N, args.K = M, N, K
     args.dtype, args.out_dtype, args.act, args.glu = _DT[x.dtype], _DT[out_dtype], ACT[act], 1 if glu else 0
-    if w_tiles is not None and M >= 5 and K % 64 == 0 and K >= 256 and N % 32 == 0:
+    if y_tiled:
+        args.out_dtype |= _lib.SX_TILED16
+    if w_tiles is not None and (xt or y_tiled or M >= 5) and K % 64 == 0 and K >= 256 and N % 32 == 0:
         assert w_tiles.shape == w.shape and w_tiles.dtype == w.dtype and w_tiles.is_contiguous()
         args.W, args.w_layout = w_tiles.data_ptr(), 1
     check(lib.sx_gemv(C.byref(args), _stream()), "sx_gemv")
-    return y
+    return yt if y_tiled else y
 
 
 def linear(x, w, **kw):
@@ -179,19 +214,24 @@ def linear(x, w, **kw):
 # ---------------------------------------------------------------------------------------------------------
 # Norms
 # ---------------------------------------------------------------------------------------------------------
-def layernorm(x, gamma, beta, eps, out_dtype, rms=False):
+def layernorm(x, gamma, beta, eps, out_dtype, rms=False, tiled=False):
+    """tiled (rows <= 16, 16-bit out): the result as a Tiled16 — the decode step's norms feed skinny GEMMs only."""
     lib = _lib.load()
     assert x.is_contiguous()
     cols = x.shape[-1]
     rows = x.numel() // cols
-    y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
-    check(lib.sx_layernorm(_p(x), _DT[x.dtype], _p(y), _DT[out_dtype], _p(_f32c(gamma)), _p(_f32c(beta)), rows, cols,
+    if tiled:
+        yt = Tiled16(rows, cols, out_dtype, x.device)
+        y, code = yt.t, _DT[out_dtype] | _lib.SX_TILED16
+    else:
+        y, code = torch.empty(x.shape, dtype=out_dtype, device=x.device), _DT[out_dtype]
+    check(lib.sx_layernorm(_p(x), _DT[x.dtype], _p(y), code, _p(_f32c(gamma)), _p(_f32c(beta)), rows, cols,
                            float(eps), 1 if rms else 0, _stream()), "sx_layernorm")
-    return y
+    return yt if tiled else y
 
 
-def rmsnorm(x, gamma, eps, out_dtype):
-    return layernorm(x, gamma, None, eps, out_dtype, rms=True)
+def rmsnorm(x, gamma, eps, out_dtype, tiled=False):
+    return layernorm(x, gamma, None, eps, out_dtype, rms=True, tiled=tiled)
 
 
 def groupnorm(x, gamma, beta, groups, eps, silu, out_dtype, want_raw=False, x2=None, comm=None, hw_total=None, planes=False):
@@ -459,15 +499,20 @@ def rope_kv_append_b(qkv, kcache, vcache, cos_tab, sin_tab, pos_dev, G, T, H, D)
                                   kcache.shape[2], kcache.stride(0), _DT[qkv.dtype], _stream()), "sx_rope_kv_append_b")
 
 
-def attn_decode_b(q, kcache, vcache, ctx_dev, scale, nsplit=8):
-    """q [G, H, D]; caches [G, H, Tmax, D]; ctx_dev int32 [G]. Returns [G, H*D]."""
+def attn_decode_b(q, kcache, vcache, ctx_dev, scale, nsplit=8, out_tiled=False):
+    """q [G, H, D]; caches [G, H, Tmax, D]; ctx_dev int32 [G]. Returns [G, H*D] (out_tiled: as a Tiled16 for the o-projection)."""
     lib = _lib.load()
     G, H, D = q.shape
-    out = torch.empty((G, H * D), dtype=q.dtype, device=q.device)
+    code = _DT[q.dtype]
+    if out_tiled:
+        ot = Tiled16(G, H * D, q.dtype, q.device)
+        out, code = ot.t, code | _lib.SX_TILED16
+    else:
+        out = torch.empty((G, H * D), dtype=q.dtype, device=q.device)
     scratch = torch.empty((G, H, nsplit, D + 2), dtype=torch.float32, device=q.device)
     check(lib.sx_attn_decode_b(_p(q), _p(kcache), _p(vcache), _p(out), _p(scratch), _p(ctx_dev), G, H, D, kcache.shape[2],
-                               kcache.stride(0), nsplit, float(scale), _DT[q.dtype], _stream()), "sx_attn_decode_b")
-    return out
+                               kcache.stride(0), nsplit, float(scale), code, _stream()), "sx_attn_decode_b")
+    return ot if out_tiled else out
 
 
 def greedy_next_b(logits, vocab, img_ids_dev, cur_dev, out_ids, step_dev):

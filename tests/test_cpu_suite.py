@@ -191,7 +191,7 @@ def test_ctypes_struct_layout_matches_header():
     from seedx_amd import _lib
     src = open(os.path.join(ROOT, "include", "seedx_hip.h")).read()
     for cname, cls in (("sx_gemm_args", _lib.GemmArgs), ("sx_gemv_args", _lib.GemvArgs), ("sx_attn_args", _lib.AttnArgs),
-                       ("sx_attn_small_args", _lib.AttnSmallArgs)):
+                       ("sx_attn_small_args", _lib.AttnSmallArgs), ("sx_oneshot_args", _lib.OneshotArgs)):
         body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), src, flags=re.S).group(1)
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
         names = []
@@ -199,7 +199,7 @@ def test_ctypes_struct_layout_matches_header():
             decl = decl.strip()
             if not decl:
                 continue
-            decl = re.sub(r"^(const\s+)?(void|float|int32_t|int64_t)\s*\*?", "", decl)
+            decl = re.sub(r"^(const\s+)?(void|float|int32_t|int64_t|uint32_t|uint64_t)\s*\*?", "", decl)
             names += [n.strip().lstrip("*") for n in decl.split(",")]
         assert names == [f[0] for f in cls._fields_], (cname, names)
 

@@ -342,6 +342,66 @@ def test_gemv_decode_tile_layout(dev, dtype, M, N, K):
     assert torch.equal(ops.gemv(x[:2].contiguous(), w), ops.gemv(x[:2].contiguous(), w, w_tiles=t))
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,K", [(5, 512, 320), (16, 5120, 5120), (16, 5120, 13824), (9, 1024, 8192 + 64), (16, 2048, 704)])
+def test_gemv_tiled_activations_and_split_k(dev, dtype, M, N, K):
+    """Decode-step activations as operand tiles (ops.Tiled16 / SX_TILED16): the three producers (RMSNorm, skinny-GEMM epilogue
+    incl. GLU, decode-attention combine is covered in test_attn_decode_b_tiled) must place element (m, k) at tile k // 32, row m,
+    column k % 32, and the skinny GEMM must give the SAME BITS from a tiled x as from the row-major x. Split-K over workgroups
+    (workspace given, K >= 8192): deterministic (20 launches), equal to the unsplit result up to fp32 re-association, counters
+    left at zero. K / 64 not divisible by the 4 waves x 4 k-steps exercises the peeled partial rounds — the guards there must
+    be scalar branches: MFMA ignores EXEC (a VGPR-derived guard multiplied never-loaded registers in)."""
+    from seedx_amd import ops
+    x32 = rnd((M, K), torch.float32, dev, seed=51)
+    gamma = rnd((K,), torch.float32, dev, seed=52)
+    w = rnd((N, K), dtype, dev, 0.05, seed=53)
+    t = ops.pack_decode_tiles(w)
+    res = rnd((M, N), torch.float32, dev, seed=54)
+    # producer 1: RMSNorm
+    if K <= 6144:                      # the norm kernel's register-resident limit
+        h = ops.rmsnorm(x32, gamma, 1e-5, dtype)
+        ht = ops.rmsnorm(x32, gamma, 1e-5, dtype, tiled=True)
+        assert ht.t.shape == (K // 32, 16, 32) and torch.equal(ht.dense(), h)
+        assert torch.equal(ht.t[3, M - 1], h[M - 1, 96:128])
+    else:                              # tile by hand (what the GLU epilogue produces for the down projection)
+        h = x32.to(dtype)
+        ht = ops.Tiled16(M, K, dtype, dev)
+        ht.t.fill_(float("nan"))       # padding rows may hold anything
+        ht.t[:, :M] = h.view(M, K // 32, 32).permute(1, 0, 2)
+    # consumer: same bits from tiled and row-major x
+    a = ops.gemv(h, w, residual=res, out_dtype=torch.float32, w_tiles=t)
+    b = ops.gemv(ht, w, residual=res, out_dtype=torch.float32, w_tiles=t)
+    assert torch.equal(a, b)
+    assert relerr(a, h.float() @ w.float().t() + res) < 5e-5
+    # producer 2: skinny-GEMM epilogue, plain and GLU
+    y, yt = ops.gemv(ht, w, w_tiles=t), ops.gemv(ht, w, w_tiles=t, y_tiled=True)
+    assert yt.t.shape == (N // 32, 16, 32) and torch.equal(yt.dense(), y)
+    g, gt = ops.gemv(ht, w, act="silu", glu=True, w_tiles=t), ops.gemv(ht, w, act="silu", glu=True, w_tiles=t, y_tiled=True)
+    if (N // 2) % 32 == 0:
+        assert torch.equal(gt.dense(), g)
+    # split-K
+    ws = torch.zeros(16384 + 8 * 16 * N * 4, dtype=torch.uint8, device=dev)
+    c = ops.gemv(ht, w, residual=res, out_dtype=torch.float32, w_tiles=t, workspace=ws)
+    for _ in range(20):
+        assert torch.equal(c, ops.gemv(ht, w, residual=res, out_dtype=torch.float32, w_tiles=t, workspace=ws))
+    assert relerr(c, a) < 2e-6
+    assert int(ws[:16384].view(torch.int32).abs().sum()) == 0, "arrival counters must be left at zero"
+    if K >= 8192 and N // 16 < 512:
+        assert int(ws[16384:].view(torch.int32).abs().sum()) != 0, "this shape was expected to split K"
+
+
+def test_attn_decode_b_tiled(dev):
+    from seedx_amd import ops
+    G, H, D, T = 7, 8, 128, 96
+    dt = torch.bfloat16
+    q = rnd((G, H, D), dt, dev, seed=61)
+    kc, vc = rnd((G, H, T, D), dt, dev, seed=62), rnd((G, H, T, D), dt, dev, seed=63)
+    ctx = torch.tensor([1, 5, 96, 40, 17, 64, 33], dtype=torch.int32, device=dev)
+    a = ops.attn_decode_b(q, kc, vc, ctx, 0.088)
+    b = ops.attn_decode_b(q, kc, vc, ctx, 0.088, out_tiled=True)
+    assert b.t.shape == (H * D // 32, 16, 32) and torch.equal(b.dense(), a)
+
+
 @pytest.mark.parametrize("ctx", [1, 17, 166, 1000])
 def test_attn_decode(dev, ctx):
     from seedx_amd import ops

@@ -3,7 +3,7 @@
 set -e
 HERE="$(cd "$(dirname "$0")" && pwd)"
 LIB="$HERE/../../seed-x_amd/lib"
-for t in gemm_lab attn_lab gn_lab; do
+for t in gemm_lab attn_lab gn_lab gemv_lab; do
   g++ -O2 -std=c++17 -Wno-unused-result -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -o "$HERE/$t" "$HERE/$t.cpp" \
       -L"$LIB" -lseedx_hip -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,'$ORIGIN/../../seed-x_amd/lib' -Wl,-rpath,/opt/rocm/lib
 done
