@@ -244,9 +244,11 @@ int sx_greedy_next(float* logits, int vocab, const int32_t* img_ids_dev, int n_i
 int sx_rope_kv_append_b(void* qkv, void* kcache, void* vcache, const float* cos_tab, const float* sin_tab,
                         const int32_t* pos0_dev, int G, int T, int H, int D, int Tmax, int64_t cache_seq_stride, int dtype,
                         void* stream);
+/* q_seq_stride: elements between the q rows of consecutive sequences (0 = H * D, contiguous) — 3 * H * D reads q straight out of
+ * the fused [G][3 * H * D] qkv projection. dtype may carry SX_TILED16 (the output as operand tiles for the o-projection). */
 int sx_attn_decode_b(const void* q, const void* kcache, const void* vcache, void* out, float* scratch,
                      const int32_t* ctx_len_dev, int G, int H, int D, int Tmax, int64_t cache_seq_stride, int nsplit,
-                     float scale, int dtype, void* stream);
+                     float scale, int dtype, int64_t q_seq_stride, void* stream);
 int sx_greedy_next_b(float* logits, int ld_logits, int vocab, const int32_t* img_ids_dev, int n_img,
                      const int32_t* prev_id_dev, int32_t* next_id_dev, int32_t* out_ids, int ld_out,
                      const int32_t* step_dev, int G, void* stream);

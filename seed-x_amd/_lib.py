@@ -87,7 +87,7 @@ SIGNATURES = {
     "sx_attn_decode": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_i32, c_vp],
     "sx_rope_kv_append": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp],
     "sx_rope_kv_append_b": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64, c_i32, c_vp],
-    "sx_attn_decode_b": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i64, c_i32, c_f32, c_i32, c_vp],
+    "sx_attn_decode_b": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i64, c_i32, c_f32, c_i32, c_i64, c_vp],
     "sx_greedy_next_b": [c_vp, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_vp],
     "sx_scatter_rows_step": [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp],
     "sx_add_i32_n": [c_vp, c_i32, c_i32, c_vp],

@@ -135,8 +135,10 @@ __global__ __launch_bounds__(NWV * 64) void gemm_skinny_kernel(const GemvP p) {
   for (int q = 0; q < R; ++q) acc[q] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   // Rounds of U k-steps through TWO register sets: round i+1's loads are issued before round i is consumed, so 1-2 rounds
   // (U..2U KB per row group and wave) are in flight at every moment. The pipelined loop has no branch inside (the waitcnt
-  // pass then emits exact vmcnt(N) waits; with a guard inside it falls back to vmcnt(0) before the first MFMA — measured:
-  // ~25 GB/s per CU, the latency-bound rate of one round in flight). Last full rounds and the < U remainder are peeled.
+  // pass then emits exact vmcnt(N) waits; with a guard inside it falls back to vmcnt(0) before the first MFMA). Last full
+  // rounds and the < U remainder are peeled. Measured (tools/lab/gemv_lab, profiles/r3_ab_experiments.md §6): the deeper
+  // flight alone changes nothing (+-1 %) — the wide shapes already stream at 6.5-6.9 TB/s net of the 3-4 us launch cost;
+  // what moved the numbers was the x layout (L2 channel conflicts) and, for K = 13824, split-K.
   struct Frag { u32x4_t wa[U][R], wb[U][R], xa[U], xb[U]; };
   auto load_round = [&](Frag& f, int ks, int cnt) {
 #pragma unroll
@@ -291,11 +293,11 @@ template <typename TT>
 __global__ __launch_bounds__(256) void attn_decode_kernel(const unsigned short* q, const unsigned short* kc,
                                                           const unsigned short* vc, float* scratch,
                                                           const int* ctx_len_dev, int D, int Tmax, int nsplit,
-                                                          float scale, long long seq_stride) {
+                                                          float scale, long long seq_stride, long long q_stride) {
   __shared__ float red[16][132];  // 16 lane-groups x (D<=128 outputs + m + l)
   const int h = blockIdx.x, sp = blockIdx.y, g = blockIdx.z, H = gridDim.x;
   const int ctx = ctx_len_dev[g];
-  q += (size_t)g * H * D;
+  q += (size_t)g * q_stride;
   kc += (size_t)g * seq_stride;
   vc += (size_t)g * seq_stride;
   scratch += (size_t)g * H * nsplit * (D + 2);
@@ -609,8 +611,9 @@ extern "C" int sx_gemv(const sx_gemv_args* a, void* stream) {
 
 extern "C" int sx_attn_decode_b(const void* q, const void* kcache, const void* vcache, void* out, float* scratch,
                                 const int32_t* ctx_len_dev, int G, int H, int D, int Tmax, int64_t cache_seq_stride,
-                                int nsplit, float scale, int dtype, void* stream) {
+                                int nsplit, float scale, int dtype, int64_t q_seq_stride, void* stream) {
   SX_CHECK(q && kcache && vcache && out && scratch && ctx_len_dev, "sx_attn_decode: null pointer");
+  SX_CHECK(q_seq_stride == 0 || (q_seq_stride >= (int64_t)H * D && q_seq_stride % 8 == 0), "sx_attn_decode: q_seq_stride");
   SX_CHECK(D % 8 == 0 && D <= 128, "sx_attn_decode: head_dim %d", D);
   SX_CHECK(nsplit >= 1 && nsplit <= 64 && G >= 1, "sx_attn_decode: nsplit/G");
   const int tiled = (dtype & SX_TILED16) ? 1 : 0;   // the OUTPUT as operand tiles [H*D/32][16][32] (q and the caches are as always)
@@ -619,13 +622,13 @@ extern "C" int sx_attn_decode_b(const void* q, const void* kcache, const void* v
   if (dtype == SX_BF16) {
     hipLaunchKernelGGL(attn_decode_kernel<BF16>, dim3(H, nsplit, G), dim3(256), 0, ST, (const unsigned short*)q,
                        (const unsigned short*)kcache, (const unsigned short*)vcache, scratch, ctx_len_dev, D, Tmax,
-                       nsplit, scale, (long long)cache_seq_stride);
+                       nsplit, scale, (long long)cache_seq_stride, (long long)(q_seq_stride ? q_seq_stride : (int64_t)H * D));
     hipLaunchKernelGGL(attn_decode_combine_kernel<BF16>, dim3(H, G), dim3(128), 0, ST, scratch, (unsigned short*)out, D,
                        nsplit, tiled);
   } else {
     hipLaunchKernelGGL(attn_decode_kernel<F16>, dim3(H, nsplit, G), dim3(256), 0, ST, (const unsigned short*)q,
                        (const unsigned short*)kcache, (const unsigned short*)vcache, scratch, ctx_len_dev, D, Tmax,
-                       nsplit, scale, (long long)cache_seq_stride);
+                       nsplit, scale, (long long)cache_seq_stride, (long long)(q_seq_stride ? q_seq_stride : (int64_t)H * D));
     hipLaunchKernelGGL(attn_decode_combine_kernel<F16>, dim3(H, G), dim3(128), 0, ST, scratch, (unsigned short*)out, D,
                        nsplit, tiled);
   }
@@ -635,7 +638,7 @@ extern "C" int sx_attn_decode_b(const void* q, const void* kcache, const void* v
 extern "C" int sx_attn_decode(const void* q, const void* kcache, const void* vcache, void* out, float* scratch,
                               const int32_t* ctx_len_dev, int H, int D, int Tmax, int nsplit, float scale, int dtype,
                               void* stream) {
-  return sx_attn_decode_b(q, kcache, vcache, out, scratch, ctx_len_dev, 1, H, D, Tmax, 0, nsplit, scale, dtype, stream);
+  return sx_attn_decode_b(q, kcache, vcache, out, scratch, ctx_len_dev, 1, H, D, Tmax, 0, nsplit, scale, dtype, 0, stream);
 }
 
 extern "C" int sx_rope_kv_append_b(void* qkv, void* kcache, void* vcache, const float* cos_tab, const float* sin_tab,

@@ -268,8 +268,8 @@ class LlamaForCausalLM:
             h = ops.rmsnorm(x, lw["ln1"], eps, dt, tiled=tl)
             qkv = ops.gemv(h, lw["wqkv"], w_tiles=lw["wqkv_t"])                       # [G, 3H]
             ops.rope_kv_append_b(qkv, P["kc"][li], P["vc"][li], P["cos"], P["sin"], P["pos"], G, 1, nh, hd)
-            q = qkv[:, :H] if G == 1 else qkv[:, :H].contiguous()                    # [G, H] (plumbing copy for G > 1)
-            att = ops.attn_decode_b(q.view(G, nh, hd), P["kc"][li], P["vc"][li], P["ctx"], scale, out_tiled=tl)
+            q = qkv[:, :H].unflatten(1, (nh, hd))                                    # strided view into qkv: no copy
+            att = ops.attn_decode_b(q, P["kc"][li], P["vc"][li], P["ctx"], scale, out_tiled=tl)
             x = comm.all_reduce(ops.gemv(att, lw["wo"], residual=x if lead else None, out_dtype=torch.float32,
                                          w_tiles=lw["wo_t"], workspace=ws))
             h = ops.rmsnorm(x, lw["ln2"], eps, dt, tiled=tl)

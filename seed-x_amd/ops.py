@@ -500,9 +500,11 @@ def rope_kv_append_b(qkv, kcache, vcache, cos_tab, sin_tab, pos_dev, G, T, H, D)
 
 
 def attn_decode_b(q, kcache, vcache, ctx_dev, scale, nsplit=8, out_tiled=False):
-    """q [G, H, D]; caches [G, H, Tmax, D]; ctx_dev int32 [G]. Returns [G, H*D] (out_tiled: as a Tiled16 for the o-projection)."""
+    """q [G, H, D] (rows may be strided views into the fused qkv projection); caches [G, H, Tmax, D]; ctx_dev int32 [G].
+    Returns [G, H*D] (out_tiled: as a Tiled16 for the o-projection)."""
     lib = _lib.load()
     G, H, D = q.shape
+    assert q.stride(2) == 1 and q.stride(1) == D and q.stride(0) % 8 == 0
     code = _DT[q.dtype]
     if out_tiled:
         ot = Tiled16(G, H * D, q.dtype, q.device)
@@ -511,7 +513,7 @@ def attn_decode_b(q, kcache, vcache, ctx_dev, scale, nsplit=8, out_tiled=False):
         out = torch.empty((G, H * D), dtype=q.dtype, device=q.device)
     scratch = torch.empty((G, H, nsplit, D + 2), dtype=torch.float32, device=q.device)
     check(lib.sx_attn_decode_b(_p(q), _p(kcache), _p(vcache), _p(out), _p(scratch), _p(ctx_dev), G, H, D, kcache.shape[2],
-                               kcache.stride(0), nsplit, float(scale), code, _stream()), "sx_attn_decode_b")
+                               kcache.stride(0), nsplit, float(scale), code, q.stride(0), _stream()), "sx_attn_decode_b")
     return ot if out_tiled else out
 
 
