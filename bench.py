@@ -398,7 +398,7 @@ def measure_roofline(w):
     Returns (roofline of the dominant kernel family, per-phase dict)."""
     from seedx_amd import _lib, ops
     lib = _lib.load()
-    real = {n: getattr(lib, n) for n in ("sx_gemm", "sx_gemv", "sx_attention")}
+    real = {n: getattr(lib, n) for n in ("sx_gemm", "sx_gemv", "sx_attention", "sx_attn_decode_b")}
     rec = []                       # (family, phase, flops, bytes, start, end)
     executed = {}                  # phase -> MFMA FLOPs actually issued (plane-carrying launches counted with their tripled K)
     stack = ["other"]
@@ -432,6 +432,13 @@ def measure_roofline(w):
         fl = 4.0 * a.B * a.H * a.Sq * a.Skv * a.D * (0.5 if a.causal else 1.0)
         byt = 2.0 * a.B * a.H * a.D * (2 * a.Sq + 2 * a.Skv)
         return timed("attention", fl, byt, real["sx_attention"], args_ref, stream)
+
+    def h_attn_decode(*args):
+        # split-KV decode attention: K and V of every visible key are read once (ctx lives on the device: read it back — this is
+        # the instrumented eager pass, not the timed one)
+        G, H, D = args[6], args[7], args[8]
+        keys = float(w.agent.llm._P["ctx"][:G].sum().item())
+        return timed("attn_decode", 4.0 * keys * H * D, 2.0 * 2.0 * keys * H * D, real["sx_attn_decode_b"], *args)
 
     def phase_wrap(obj, name, phase):
         cls = type(obj)
@@ -470,6 +477,8 @@ def measure_roofline(w):
             patched.append(phase_wrap(loop, "run", "unet"))
             patched.append(phase_wrap(w.adapter, "_finish", "vae"))
         lib.sx_gemm, lib.sx_gemv, lib.sx_attention = h_gemm, h_gemv, h_attn
+        if agent is not None:
+            lib.sx_attn_decode_b = h_attn_decode
         w.step(1)
         torch.cuda.synchronize()
     finally:
@@ -504,10 +513,15 @@ def measure_roofline(w):
             # ALGORITHMIC FLOPs, this is what the matrix pipe actually executes
             d["executed_mfma_tflop"] = ex / 1e12
             d["executed_mfma_frac"] = ex / wall / 1e12 / PEAK_TFLOPS_16BIT
-        if ph == "decode":         # weight streaming: every skinny-GEMM launch reads its weight matrix once
-            d.update({"bound": "hbm", "achieved": byt_gemv / wall / 1e9, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                      "frac": byt_gemv / wall / 1e9 / PEAK_HBM_GBPS,
-                      "gemv_kernel_gbps": byt_gemv / t_fam["gemv"] / 1e9 if t_fam["gemv"] > 0 else None})
+        if ph == "decode":         # weight streaming: every skinny-GEMM launch reads its weight matrix once, decode attention the KV cache
+            byt_kv = sum(r_[3] for r_ in inside if r_[0] == "attn_decode")
+            t_kv = sum(r_[4].elapsed_time(r_[5]) for r_ in inside if r_[0] == "attn_decode") * 1e-3
+            d.update({"bound": "hbm", "achieved": (byt_gemv + byt_kv) / wall / 1e9, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                      "frac": (byt_gemv + byt_kv) / wall / 1e9 / PEAK_HBM_GBPS,
+                      "weight_bytes": byt_gemv, "kv_bytes": byt_kv,
+                      "gemv_kernel_gbps": byt_gemv / t_fam["gemv"] / 1e9 if t_fam["gemv"] > 0 else None,
+                      "attn_decode_kernel_gbps": byt_kv / t_kv / 1e9 if t_kv > 0 else None,
+                      "kernel_time_share_attn_decode": t_kv / wall if wall > 0 else 0.0})
         else:
             d.update({"bound": "mfma", "achieved": d["tflops"], "peak": PEAK_TFLOPS_16BIT, "unit": "TFLOP/s", "frac": d["mfma_frac"]})
         phases[ph] = d
