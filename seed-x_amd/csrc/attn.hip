@@ -234,8 +234,13 @@ __global__ __launch_bounds__(256, (DP <= 64 ? 4 : 1)) void attn_kernel(const Att
         unsigned w[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const float p0 = __builtin_amdgcn_exp2f(fmaf(s[jb][8 * s2 + 2 * j], c, mc));
-          const float p1 = __builtin_amdgcn_exp2f(fmaf(s[jb][8 * s2 + 2 * j + 1], c, mc));
+          // the two scores of a packed pair sit in an aligned register pair: one v_pk_fma_f32 scales and shifts both (same
+          // IEEE fma per element, half the VALU issue slots)
+          typedef float f2_t __attribute__((ext_vector_type(2)));
+          const f2_t sv = {s[jb][8 * s2 + 2 * j], s[jb][8 * s2 + 2 * j + 1]};
+          const f2_t e = __builtin_elementwise_fma(sv, (f2_t){c, c}, (f2_t){mc, mc});
+          const float p0 = __builtin_amdgcn_exp2f(e[0]);
+          const float p1 = __builtin_amdgcn_exp2f(e[1]);
           w[j] = pack2<TT>(p0, p1);
           psum = TT::pair_sum(w[j], psum);          // sums the ROUNDED probabilities, i.e. exactly what P·V multiplies
         }
