@@ -525,6 +525,35 @@ def measure_roofline(w):
         else:
             d.update({"bound": "mfma", "achieved": d["tflops"], "peak": PEAK_TFLOPS_16BIT, "unit": "TFLOP/s", "frac": d["mfma_frac"]})
         phases[ph] = d
+    if agent is not None and "decode" in phases and phases["decode"]["calls"] > 0:
+        # the timed step REPLAYS the decode token step as a HIP graph; the eager pass above pays ~360 launches per token. Time
+        # 32 graph replays at the position the step ended on (bytes per token from the eager pass: weights + visible KV).
+        llm = agent.llm
+        G = llm.G
+        ids = torch.full((G, 40), -1, dtype=torch.int32, device=llm.device)
+        hid = torch.zeros((G, 40, llm.config.hidden_size), device=llm.device)
+        img_ids = torch.arange(llm.V - 200, llm.V - 134, dtype=torch.int32, device=llm.device)
+        snap = {k: llm._P[k].clone() for k in ("pos", "ctx", "step", "cur")}
+        llm._P["step"].zero_()
+        llm._P["cur"].fill_(5)
+        for _ in range(3):
+            llm.decode_step(img_ids, ids, hid, use_graph=True)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(32):
+            llm.decode_step(img_ids, ids, hid, use_graph=True)
+        e1.record()
+        torch.cuda.synchronize()
+        for k, v in snap.items():
+            llm._P[k].copy_(v)
+        llm._graph = None
+        ms_tok = e0.elapsed_time(e1) / 32
+        dd = phases["decode"]
+        byt_tok = (dd["weight_bytes"] + dd["kv_bytes"]) / dd["calls"]
+        dd["graph_replay"] = {"ms_per_token": ms_tok, "bytes_per_token": byt_tok, "achieved": byt_tok / ms_tok / 1e6, "unit": "GB/s",
+                              "frac": byt_tok / ms_tok / 1e6 / PEAK_HBM_GBPS,
+                              "note": "32 HIP-graph replays of the token step for all sequences, as in the timed step; the eager figures "
+                                      "above include ~360 host launches per token"}
     if "attention" in fam and fam["attention"]["s"] > 0:
         d = fam["attention"]
         phases["attention_kernels"] = {"bound": "mfma", "achieved": d["flop"] / d["s"] / 1e12, "peak": PEAK_TFLOPS_16BIT, "unit": "TFLOP/s",
@@ -545,12 +574,17 @@ def measure_roofline(w):
     # traffic: bytes per launch from rocprofv3 --pmc passes of THIS command (tools/bench_pmc_traffic.py; eager launches).
     # Only quoted when the stored profile was taken with the GEMM sources as they are now, at this batch size / config.
     traffic, tnote = None, "no PMC profile taken with the current GEMM kernels at this batch size / config"
-    try:
-        prof = json.load(open(os.path.join(ROOT, "profiles", "r3_bench_pmc_traffic.json")))
-        if prof.get("batch_per_gpu") == BATCH and w.a.config == 0 and prof.get("kernel_source_sha") == _kernel_source_sha():
-            traffic, tnote = prof["traffic_bytes_per_launch"], prof["method"]
-    except (OSError, ValueError, KeyError):
-        pass
+    for name in ("r3_bench_pmc_traffic.json", "r3_unet_pmc_traffic.json"):
+        try:
+            prof = json.load(open(os.path.join(ROOT, "profiles", name)))
+            if prof.get("batch_per_gpu") == BATCH and w.a.config == 0 and prof.get("kernel_source_sha") == _kernel_source_sha():
+                traffic, tnote = prof["traffic_bytes_per_launch"], prof["method"]
+                if prof.get("scope") == "unet_only":
+                    tnote += ("; scope: the UNet's sx_gemm launches only (2 eager CFG steps, tools/r3_pmc_unet.sh) — rocprofv3 crashes "
+                              "with these counters on the composite bench command; the UNet holds 96 % of the step's GEMM time")
+                break
+        except (OSError, ValueError, KeyError):
+            pass
     roof = {"bound": "mfma", "achieved": fl / tot_s / 1e12, "peak": PEAK_TFLOPS_16BIT, "unit": "TFLOP/s",
             "frac": fl / tot_s / 1e12 / PEAK_TFLOPS_16BIT, "traffic": traffic, "traffic_unit": "bytes/launch",
             "traffic_source": tnote, "algorithmic_bytes_per_launch": alg_bytes / n,

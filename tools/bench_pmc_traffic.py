@@ -46,6 +46,7 @@ def main():
     print(json.dumps({"kernel": "sxk_gemm::gemm_pp_kernel<*> + gemm_kernel<*>", "kernels": sys.argv[4] if len(sys.argv) > 4 else "r1",
                       "kernel_source_sha": kernel_source_sha(),
                       "batch_per_gpu": int(sys.argv[3]), "launches": nf,
+                      "scope": sys.argv[5] if len(sys.argv) > 5 else "bench_step",
                       "fetch_bytes_per_launch": fb / nf, "write_bytes_per_launch": wb / nf,
                       "traffic_bytes_per_launch": (fb + wb) / nf,
                       "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over one eager bench step; "
