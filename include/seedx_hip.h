@@ -249,6 +249,25 @@ int sx_rope_kv_append_b(void* qkv, void* kcache, void* vcache, const float* cos_
 int sx_attn_decode_b(const void* q, const void* kcache, const void* vcache, void* out, float* scratch,
                      const int32_t* ctx_len_dev, int G, int H, int D, int Tmax, int64_t cache_seq_stride, int nsplit,
                      float scale, int dtype, int64_t q_seq_stride, void* stream);
+/* One launch per layer for the lock-step decode step: RoPE of the new token's q and k, K / V append at pos[g], split-KV attention
+ * over the pos[g] + 1 visible keys and the combine of the splits. Replaces sx_rope_kv_append_b (T = 1) + sx_attn_decode_b with
+ * bit-identical output and cache contents (modeling_llama_xformer.py:204-239 at q_len == 1). q is NOT rotated in place. */
+typedef struct sx_attn_decode_args {
+  const void* qkv;          /* [G][3*H*D] 16-bit rows q | k | v of the new token (output of the fused qkv projection)      */
+  void* kcache;             /* [G][H][Tmax][D], sequences cache_seq_stride elements apart                                   */
+  void* vcache;
+  void* out;                /* [G][H*D] 16-bit, or operand tiles with dtype | SX_TILED16                                    */
+  float* scratch;           /* [G][H][nsplit][D + 2] fp32                                                                   */
+  void* counters;           /* uint32 [G*H]: zero when first used, left at zero                                             */
+  const float* cos_tab;     /* [Tmax][D/2] fp32                                                                             */
+  const float* sin_tab;
+  const int32_t* pos_dev;   /* [G] position of the new token; positions outside [0, Tmax) attend to the cache, write nothing */
+  int32_t G, H, D, Tmax, nsplit, dtype;
+  int64_t cache_seq_stride;
+  float scale;
+  int32_t reserved;
+} sx_attn_decode_args;
+int sx_attn_decode_fused(const sx_attn_decode_args* args, void* stream);
 int sx_greedy_next_b(float* logits, int ld_logits, int vocab, const int32_t* img_ids_dev, int n_img,
                      const int32_t* prev_id_dev, int32_t* next_id_dev, int32_t* out_ids, int ld_out,
                      const int32_t* step_dev, int G, void* stream);

@@ -38,6 +38,13 @@ class OneshotArgs(C.Structure):
                 ("n", c_i32), ("cap", c_i32), ("rank", c_i32), ("world", c_i32), ("max_spin", C.c_uint32), ("chunk", c_i32)]
 
 
+class AttnDecodeArgs(C.Structure):
+    _fields_ = [("qkv", c_vp), ("kcache", c_vp), ("vcache", c_vp), ("out", c_vp), ("scratch", c_vp), ("counters", c_vp),
+                ("cos_tab", c_vp), ("sin_tab", c_vp), ("pos_dev", c_vp),
+                ("G", c_i32), ("H", c_i32), ("D", c_i32), ("Tmax", c_i32), ("nsplit", c_i32), ("dtype", c_i32),
+                ("cache_seq_stride", c_i64), ("scale", c_f32), ("reserved", c_i32)]
+
+
 class AttnArgs(C.Structure):
     _fields_ = [("Q", c_vp), ("K", c_vp), ("V", c_vp), ("O", c_vp),
                 ("B", c_i32), ("H", c_i32), ("Sq", c_i32), ("Skv", c_i32), ("D", c_i32), ("reserved", c_i32),
@@ -87,6 +94,7 @@ SIGNATURES = {
     "sx_attn_decode": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_i32, c_vp],
     "sx_rope_kv_append": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp],
     "sx_rope_kv_append_b": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64, c_i32, c_vp],
+    "sx_attn_decode_fused": [C.POINTER(AttnDecodeArgs), c_vp],
     "sx_attn_decode_b": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i64, c_i32, c_f32, c_i32, c_i64, c_vp],
     "sx_greedy_next_b": [c_vp, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_vp],
     "sx_scatter_rows_step": [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp],

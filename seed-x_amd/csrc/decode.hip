@@ -383,6 +383,203 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const unsigned short* 
   }
 }
 
+// ---- fused decode attention: RoPE of the new token + KV append + split-KV attention + combine, ONE launch ------------------------
+// The three-kernel form above costs 6 us (rope) + 18 us (attention) + 5.5 us (combine) per layer, two of them launch-latency
+// sized. Here every (head, split, sequence) workgroup rotates q itself (128 values), the one 16-lane group whose key index is the
+// new position takes K / V of the new token straight from the qkv row (rotating K, writing both into the cache for later
+// steps), and the LAST split of a head to arrive (agent-scope partial stores + arrival counter, as in the skinny GEMM's
+// split-K) combines the partials in split order. Same arithmetic, same order, same roundings as rope_kv_append_kernel +
+// attn_decode_kernel + attn_decode_combine_kernel: bit-identical output and cache contents.
+struct AttnDecP {
+  const unsigned short* qkv;   // [G][3*H*D]: q | k | v of the new token, un-rotated
+  unsigned short* kc;
+  unsigned short* vc;
+  unsigned short* out;
+  float* scratch;              // [G][H][nsplit][D + 2]
+  unsigned* counters;          // [G*H], zero between launches
+  const float* cos_t;
+  const float* sin_t;
+  const int* pos_dev;          // [G]
+  int H, D, Tmax, nsplit, tiled;
+  float scale;
+  long long seq_stride;
+};
+
+template <typename TT>
+__device__ __forceinline__ void rope_chunk(const unsigned short* base, int dl, int D, const float* cos_t, const float* sin_t, int pos,
+                                           float* out8) {
+  // rotated elements 8dl .. 8dl+7 of a D-wide head vector at `base`, rounded to the activation dtype (rope_kv_append_kernel)
+  const int half = D / 2, j0 = dl * 8;
+  const bool lo = j0 < half;
+  const u32x4_t a = *(const u32x4_t*)(base + j0);
+  const u32x4_t b = *(const u32x4_t*)(base + (lo ? j0 + half : j0 - half));
+  // the 8 table entries of this chunk are contiguous (half % 8 == 0): two 16-B loads per table
+  const size_t tb = (size_t)pos * half + (lo ? j0 : j0 - half);
+  const f32x4_t c0 = *(const f32x4_t*)(cos_t + tb), c1 = *(const f32x4_t*)(cos_t + tb + 4);
+  const f32x4_t s0 = *(const f32x4_t*)(sin_t + tb), s1 = *(const f32x4_t*)(sin_t + tb + 4);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float c = TT::to_f32(TT::from_f32(e < 4 ? c0[e & 3] : c1[e & 3]));
+    const float sn = TT::to_f32(TT::from_f32(e < 4 ? s0[e & 3] : s1[e & 3]));
+    const float x = TT::to_f32((e & 1) ? (a[e >> 1] >> 16) : (a[e >> 1] & 0xffff));
+    const float y = TT::to_f32((e & 1) ? (b[e >> 1] >> 16) : (b[e >> 1] & 0xffff));
+    // first half: x*c - y*s (y = partner in the second half); second half: x*c + y*s (y = partner in the first half)
+    out8[e] = TT::to_f32(TT::from_f32(lo ? x * c - y * sn : x * c + y * sn));
+  }
+}
+
+template <typename TT>
+__global__ __launch_bounds__(256) void attn_decode_fused_kernel(const AttnDecP p) {
+  __shared__ float red[16][132];
+  __shared__ unsigned s_last;
+  const int h = blockIdx.x, sp = blockIdx.y, g = blockIdx.z, H = p.H, D = p.D, nsplit = p.nsplit;
+  const int pos = p.pos_dev[g];
+  const bool pos_ok = pos >= 0 && pos < p.Tmax;
+  const int ctx = pos_ok ? pos + 1 : (pos < 0 ? 0 : p.Tmax);   // a position past the cache: attend to the cache only, write nothing
+  const unsigned short* row = p.qkv + (size_t)g * 3 * H * D;
+  unsigned short* kh = p.kc + (size_t)g * p.seq_stride + (size_t)h * p.Tmax * D;
+  unsigned short* vh = p.vc + (size_t)g * p.seq_stride + (size_t)h * p.Tmax * D;
+  float* scratch = p.scratch + (size_t)g * H * nsplit * (D + 2);
+  const int chunk = (ctx + nsplit - 1) / nsplit;
+  const int t0 = sp * chunk, t1 = min(ctx, t0 + chunk);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int grp = wave * 4 + (lane >> 4);
+  const int dl = lane & 15;
+  const bool dvalid = dl * 8 < D;
+  const int rpos = pos_ok ? pos : 0;
+  float qv[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) qv[e] = 0.f;
+  if (dvalid) {
+    rope_chunk<TT>(row + (size_t)h * D, dl, D, p.cos_t, p.sin_t, rpos, qv);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) qv[e] *= p.scale;
+  }
+  float m_run = -INFINITY, l_run = 0.f, o[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = 0.f;
+  for (int t = t0 + grp; t < t1; t += 16) {
+    float kf[8], vf[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { kf[e] = 0.f; vf[e] = 0.f; }
+    if (dvalid) {
+      if (pos_ok && t == pos) {      // the new token: from the qkv row, and into the cache
+        rope_chunk<TT>(row + (size_t)(H + h) * D, dl, D, p.cos_t, p.sin_t, pos, kf);
+        const u32x4_t vr = *(const u32x4_t*)(row + (size_t)(2 * H + h) * D + dl * 8);
+        u32x4_t kw;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          kw[e] = (unsigned)TT::from_f32(kf[2 * e]) | ((unsigned)TT::from_f32(kf[2 * e + 1]) << 16);
+          vf[2 * e] = TT::to_f32(vr[e] & 0xffff);
+          vf[2 * e + 1] = TT::to_f32(vr[e] >> 16);
+        }
+        *(u32x4_t*)(kh + (size_t)pos * D + dl * 8) = kw;
+        *(u32x4_t*)(vh + (size_t)pos * D + dl * 8) = vr;
+      } else {
+        const u32x4_t kr = *(const u32x4_t*)(kh + (size_t)t * D + dl * 8);
+        const u32x4_t vr = *(const u32x4_t*)(vh + (size_t)t * D + dl * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          kf[2 * e] = TT::to_f32(kr[e] & 0xffff); kf[2 * e + 1] = TT::to_f32(kr[e] >> 16);
+          vf[2 * e] = TT::to_f32(vr[e] & 0xffff); vf[2 * e + 1] = TT::to_f32(vr[e] >> 16);
+        }
+      }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s += kf[2 * e] * qv[2 * e] + kf[2 * e + 1] * qv[2 * e + 1];
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    s += __shfl_xor(s, 4, 64);
+    s += __shfl_xor(s, 8, 64);
+    const float m_new = fmaxf(m_run, s);
+    const float alpha = __expf(m_run - m_new);
+    const float pr = __expf(s - m_new);
+    l_run = l_run * alpha + pr;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = o[e] * alpha + pr * vf[e];
+    m_run = m_new;
+  }
+  if (dvalid) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[grp][dl * 8 + e] = o[e];
+  }
+  if (dl == 0) {
+    red[grp][128] = m_run;
+    red[grp][129] = l_run;
+  }
+  __syncthreads();
+  const int d = threadIdx.x;
+  float* part = scratch + ((size_t)h * nsplit + sp) * (D + 2);
+  float mg = -INFINITY;
+#pragma unroll
+  for (int gg = 0; gg < 16; ++gg) mg = fmaxf(mg, red[gg][128]);
+  if (d < D) {
+    float acc = 0.f;
+#pragma unroll
+    for (int gg = 0; gg < 16; ++gg) {
+      const float mgk = red[gg][128];
+      const float w = (mgk == -INFINITY) ? 0.f : __expf(mgk - mg);
+      acc += w * red[gg][d];
+    }
+    __hip_atomic_store(part + d, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (d == 0) {
+    float lsum = 0.f;
+    for (int gg = 0; gg < 16; ++gg) {
+      const float mgk = red[gg][128];
+      lsum += (mgk == -INFINITY) ? 0.f : __expf(mgk - mg) * red[gg][129];
+    }
+    __hip_atomic_store(part + D, mg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(part + D + 1, lsum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  // arrival: every thread's partial stores are acknowledged, then one count per workgroup; the last split combines
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0)
+    s_last = __hip_atomic_fetch_add(p.counters + (size_t)g * H + h, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(nsplit - 1);
+  __syncthreads();
+  if (!s_last) return;
+  if (threadIdx.x == 0) __hip_atomic_store(p.counters + (size_t)g * H + h, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (d >= D) return;
+  const float* base = scratch + (size_t)h * nsplit * (D + 2);
+  float mall = -INFINITY, acc = 0.f, l = 0.f;
+  if (nsplit <= 8) {
+    // all 3 x nsplit partial loads in flight together (they miss to memory: the partials came from other CUs / XCDs), then the
+    // same arithmetic in the same order as the loop below
+    float pm[8], pl[8], pa[8];
+#pragma unroll
+    for (int s2 = 0; s2 < 8; ++s2) {
+      const size_t o2 = (size_t)(s2 < nsplit ? s2 : 0) * (D + 2);
+      pm[s2] = __hip_atomic_load(base + o2 + D, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      pl[s2] = __hip_atomic_load(base + o2 + D + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      pa[s2] = __hip_atomic_load(base + o2 + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 8; ++s2)
+      if (s2 < nsplit) mall = fmaxf(mall, pm[s2]);
+#pragma unroll
+    for (int s2 = 0; s2 < 8; ++s2)
+      if (s2 < nsplit) {
+        const float w = (pm[s2] == -INFINITY) ? 0.f : __expf(pm[s2] - mall);
+        acc += w * pa[s2];
+        l += w * pl[s2];
+      }
+  } else {
+    for (int s2 = 0; s2 < nsplit; ++s2)
+      mall = fmaxf(mall, __hip_atomic_load(base + (size_t)s2 * (D + 2) + D, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    for (int s2 = 0; s2 < nsplit; ++s2) {
+      const float ms = __hip_atomic_load(base + (size_t)s2 * (D + 2) + D, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const float w = (ms == -INFINITY) ? 0.f : __expf(ms - mall);
+      acc += w * __hip_atomic_load(base + (size_t)s2 * (D + 2) + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      l += w * __hip_atomic_load(base + (size_t)s2 * (D + 2) + D + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  const int col = h * D + d;
+  const size_t oo = p.tiled ? (size_t)(col >> 5) * 512 + (size_t)g * 32 + (col & 31) : (size_t)g * H * D + col;
+  p.out[oo] = TT::from_f32(l > 0.f ? acc / l : 0.f);
+}
+
 template <typename TT>
 __global__ void attn_decode_combine_kernel(const float* scratch, unsigned short* out, int D, int nsplit, int tiled) {
   const int h = blockIdx.x, d = threadIdx.x, g = blockIdx.y, H = gridDim.x;
@@ -635,6 +832,27 @@ extern "C" int sx_attn_decode_b(const void* q, const void* kcache, const void* v
   SX_HIP_LAUNCH_CHECK();
   return SX_OK;
 }
+extern "C" int sx_attn_decode_fused(const sx_attn_decode_args* a, void* stream) {
+  SX_CHECK(a && a->qkv && a->kcache && a->vcache && a->out && a->scratch && a->counters && a->cos_tab && a->sin_tab && a->pos_dev,
+           "sx_attn_decode_fused: null pointer");
+  const int tiled = (a->dtype & SX_TILED16) ? 1 : 0, dt = a->dtype & 0xff;
+  SX_CHECK(dt == SX_F16 || dt == SX_BF16, "sx_attn_decode_fused: dtype");
+  SX_CHECK(a->D % 16 == 0 && a->D <= 128, "sx_attn_decode_fused: head_dim %d (must be a multiple of 16, <= 128)", a->D);
+  SX_CHECK(a->nsplit >= 1 && a->nsplit <= 64 && a->G >= 1 && a->H >= 1, "sx_attn_decode_fused: nsplit/G/H");
+  SX_CHECK(!tiled || (a->G <= 16 && (a->H * a->D) % 32 == 0), "sx_attn_decode_fused: SX_TILED16 needs G <= 16 and H*D %% 32 == 0");
+  AttnDecP p;
+  p.qkv = (const unsigned short*)a->qkv; p.kc = (unsigned short*)a->kcache; p.vc = (unsigned short*)a->vcache;
+  p.out = (unsigned short*)a->out; p.scratch = a->scratch; p.counters = (unsigned*)a->counters;
+  p.cos_t = a->cos_tab; p.sin_t = a->sin_tab; p.pos_dev = a->pos_dev;
+  p.H = a->H; p.D = a->D; p.Tmax = a->Tmax; p.nsplit = a->nsplit; p.tiled = tiled; p.scale = a->scale;
+  p.seq_stride = a->cache_seq_stride;
+  const dim3 grid(a->H, a->nsplit, a->G);
+  if (dt == SX_BF16) hipLaunchKernelGGL(attn_decode_fused_kernel<BF16>, grid, dim3(256), 0, ST, p);
+  else hipLaunchKernelGGL(attn_decode_fused_kernel<F16>, grid, dim3(256), 0, ST, p);
+  SX_HIP_LAUNCH_CHECK();
+  return SX_OK;
+}
+
 extern "C" int sx_attn_decode(const void* q, const void* kcache, const void* vcache, void* out, float* scratch,
                               const int32_t* ctx_len_dev, int H, int D, int Tmax, int nsplit, float scale, int dtype,
                               void* stream) {

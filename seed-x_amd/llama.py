@@ -68,6 +68,10 @@ class LlamaForCausalLM:
         self.H_l = self.nh_l * self.hd
         self.Tmax = max_cache_len or c.max_position_embeddings
         self.G = int(max_batch)
+        # True: RoPE + KV append + split-KV attention + combine as ONE launch (sx_attn_decode_fused, bit-identical). Measured
+        # 1.8 % slower per token than the three launches inside the step's HIP graph (6.80 vs 6.68 ms, 16 sequences,
+        # tools/bench_decode_attention_ab.py): the arrival-counter tail costs more than two graph launches → off by default
+        self.fused_decode_attention = False
         assert 1 <= self.G <= 16, "lock-step batch is limited to 16 sequences (sx_gemv rows)"
         self.device, self.dtype = None, torch.float16
         self._sd, self._P = None, None
@@ -183,6 +187,7 @@ class LlamaForCausalLM:
         P["ctx"] = torch.ones(G, dtype=torch.int32, device=dev)          # pos + 1 (keys visible to that token)
         P["step"] = torch.zeros(G, dtype=torch.int32, device=dev)        # index into out_ids / hidden buffer
         P["cur"] = torch.zeros(G, dtype=torch.int32, device=dev)         # current input token id
+        P["attn_cnt"] = torch.zeros(G * self.nh_l, dtype=torch.int32, device=dev)   # arrival counters of the fused decode attention
         self._P = P
         self._sd = None
         self._graph = None
@@ -267,9 +272,14 @@ class LlamaForCausalLM:
         for li, lw in enumerate(P["layers"]):
             h = ops.rmsnorm(x, lw["ln1"], eps, dt, tiled=tl)
             qkv = ops.gemv(h, lw["wqkv"], w_tiles=lw["wqkv_t"])                       # [G, 3H]
-            ops.rope_kv_append_b(qkv, P["kc"][li], P["vc"][li], P["cos"], P["sin"], P["pos"], G, 1, nh, hd)
-            q = qkv[:, :H].unflatten(1, (nh, hd))                                    # strided view into qkv: no copy
-            att = ops.attn_decode_b(q, P["kc"][li], P["vc"][li], P["ctx"], scale, out_tiled=tl)
+            if self.fused_decode_attention and hd % 16 == 0:
+                # RoPE + KV append + split-KV attention + combine as one launch (bit-identical to the three-kernel form below)
+                att = ops.attn_decode_fused(qkv, P["kc"][li], P["vc"][li], P["pos"], P["cos"], P["sin"], scale, nh, hd,
+                                            P["attn_cnt"], out_tiled=tl)
+            else:
+                ops.rope_kv_append_b(qkv, P["kc"][li], P["vc"][li], P["cos"], P["sin"], P["pos"], G, 1, nh, hd)
+                q = qkv[:, :H].unflatten(1, (nh, hd))                                # strided view into qkv: no copy
+                att = ops.attn_decode_b(q, P["kc"][li], P["vc"][li], P["ctx"], scale, out_tiled=tl)
             x = comm.all_reduce(ops.gemv(att, lw["wo"], residual=x if lead else None, out_dtype=torch.float32,
                                          w_tiles=lw["wo_t"], workspace=ws))
             h = ops.rmsnorm(x, lw["ln2"], eps, dt, tiled=tl)

@@ -517,6 +517,29 @@ def attn_decode_b(q, kcache, vcache, ctx_dev, scale, nsplit=8, out_tiled=False):
     return ot if out_tiled else out
 
 
+def attn_decode_fused(qkv, kcache, vcache, pos_dev, cos_tab, sin_tab, scale, H, D, counters, nsplit=8, out_tiled=False):
+    """RoPE + KV append + split-KV attention + combine for ONE new token of each of G sequences, one launch.
+    qkv [G, 3*H*D] (left untouched); caches [G, H, Tmax, D]; pos_dev int32 [G]; counters: zero int32 [>= G*H] (left zero).
+    Returns [G, H*D] (out_tiled: as a Tiled16 for the o-projection)."""
+    lib = _lib.load()
+    G = qkv.shape[0]
+    assert qkv.is_contiguous() and qkv.shape[1] == 3 * H * D and counters.dtype == torch.int32 and counters.numel() >= G * H
+    code = _DT[qkv.dtype]
+    if out_tiled:
+        ot = Tiled16(G, H * D, qkv.dtype, qkv.device)
+        out, code = ot.t, code | _lib.SX_TILED16
+    else:
+        out = torch.empty((G, H * D), dtype=qkv.dtype, device=qkv.device)
+    scratch = torch.empty((G, H, nsplit, D + 2), dtype=torch.float32, device=qkv.device)
+    a = _lib.AttnDecodeArgs()
+    a.qkv, a.kcache, a.vcache, a.out, a.scratch, a.counters = _p(qkv), _p(kcache), _p(vcache), _p(out), _p(scratch), _p(counters)
+    a.cos_tab, a.sin_tab, a.pos_dev = _p(cos_tab), _p(sin_tab), _p(pos_dev)
+    a.G, a.H, a.D, a.Tmax, a.nsplit, a.dtype = G, H, D, kcache.shape[2], nsplit, code
+    a.cache_seq_stride, a.scale = kcache.stride(0), float(scale)
+    check(lib.sx_attn_decode_fused(C.byref(a), _stream()), "sx_attn_decode_fused")
+    return ot if out_tiled else out
+
+
 def greedy_next_b(logits, vocab, img_ids_dev, cur_dev, out_ids, step_dev):
     """logits fp32 [G, ld]; cur_dev int32 [G] (in: previous id, out: next id); out_ids int32 [G, ld_out]; step_dev [G]."""
     lib = _lib.load()
