@@ -220,6 +220,24 @@ def test_product_path_has_no_cpu_fallback():
 # ---------------------------------------------------------------------------------------------------------
 # host logic
 # ---------------------------------------------------------------------------------------------------------
+def test_tiled16_layout_contract():
+    """ops.Tiled16 = the SX_TILED16 layout of include/seedx_hip.h: element (m, k) of a [rows <= 16, cols] activation sits at tile
+    k // 32, row m, column k % 32 of [cols/32][16][32] (what sx_gemv reads with x_layout = 1 and what the decode step's producers
+    write). Host-side index arithmetic only."""
+    from seedx_amd import ops
+    t = ops.Tiled16(5, 96, torch.float32, "cpu")
+    t.t.zero_()
+    dense = torch.arange(5 * 96, dtype=torch.float32).view(5, 96)
+    t.t[:, :5] = dense.view(5, 3, 32).permute(1, 0, 2)
+    assert t.t.shape == (3, 16, 32) and torch.equal(t.dense(), dense)
+    assert t.t[2, 4, 7].item() == dense[4, 2 * 32 + 7].item()
+    hdr = open(os.path.join(ROOT, "include", "seedx_hip.h")).read()
+    from seedx_amd import _lib
+    assert "#define SX_TILED16 0x100" in hdr and _lib.SX_TILED16 == 0x100
+    with pytest.raises(AssertionError):
+        ops.Tiled16(17, 64, torch.float32, "cpu")
+
+
 def test_glu_pack_rows_contract():
     from seedx_amd.llama import glu_pack_rows
     lin = torch.arange(64 * 3).float().view(64, 3)
