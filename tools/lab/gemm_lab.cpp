@@ -407,6 +407,16 @@ int main(int argc, char** argv) {
     cases.push_back({"conv_up640", 0, 640, 0, 0, 0, 0, 1, 1, 1, 32, 32, 32, 640, 1, 1, 5, {5, 1100}});
     cases.push_back({"conv_s2_640", 0, 640, 0, 0, 0, 0, 1, 1, 1, 32, 64, 64, 640, 2, 0, 5, {5, 1100}});
   }
+  if (suite == "hbm") {   // the fp32-residual shapes whose roofline is HBM: every tile config of the menu
+    cases.push_back({"outproj_res", 32768, 1280, 1280, 0, 0, 1, 1, 1, 0, 0, 0, 0, 0, 1, 0, 5, {5, 0, 1, 2, 3, 4, 6, 7, 8}});
+    cases.push_back({"c640_out_res", 131072, 640, 640, 0, 0, 1, 1, 1, 0, 0, 0, 0, 0, 1, 0, 5, {5, 0, 1, 2, 3, 4, 6, 7, 8}});
+    cases.push_back({"c320_out_res", 524288, 320, 320, 0, 0, 1, 1, 1, 0, 0, 0, 0, 0, 1, 0, 5, {5, 0, 1, 2, 3, 4, 6, 7, 8}});
+  }
+  if (suite == "io") {    // K = 64: one k-tile, the launch is the residual pre-load + the store epilogue (336 MB of fp32 in + out)
+    cases.push_back({"res_k64", 32768, 1280, 64, 0, 0, 1, 1, 1, 0, 0, 0, 0, 0, 1, 0, 5, {5, 8, 7, 0}});
+    cases.push_back({"nores_k64", 32768, 1280, 64, 0, 0, 0, 1, 1, 0, 0, 0, 0, 0, 1, 0, 5, {5, 8, 7, 0}});
+    cases.push_back({"bf16_k64", 32768, 1280, 64, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 1, 0, 5, {5, 8, 7, 0}});
+  }
   if (suite == "rs") {
     cases.push_back({"rs_small", 1024, 1280, 1280, 0, 0, 1, 1, 1, 0, 0, 0, 0, 0, 1, 0, 5, {5, 1100, 1000}});
     cases.push_back({"outproj_res", 32768, 1280, 1280, 0, 0, 1, 1, 1, 0, 0, 0, 0, 0, 1, 0, 5, {5, 1100, 1000}});
