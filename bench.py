@@ -389,6 +389,20 @@ def _kernel_source_sha():
     return h.hexdigest()[:16]
 
 
+def _csrc_sha():
+    """Hash of every kernel / ABI source the line was measured with (the GPU box has no .git): ties a stored line to a tree."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "seed-x_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            with open(os.path.join(d, f), "rb") as fh:
+                h.update(f.encode() + fh.read())
+    with open(os.path.join(ROOT, "include", "seedx_hip.h"), "rb") as fh:
+        h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def measure_roofline(w):
     """Instrumented (eager, un-graphed, ONE kernel chain) step with HIP events on the launch stream around EVERY sx_gemm,
     sx_gemv and sx_attention launch, and around every phase of the step (ViT / prefill / decode / UNet loop / VAE):
@@ -818,6 +832,7 @@ def main(argv=None):
                                                               "fast": "single 16-bit operands"}.get(VAE_PRECISION, "auto"))},
                "flops_per_generation": w.flops(), "generations_per_step": a.batch}
         rec["model_tflops"] = rec["flops_per_generation"] * rec["value"] / world / 1e12
+        rec["source_sha"] = {"csrc": _csrc_sha(), "gemm": _kernel_source_sha()}
         if roof is not None:
             rec["roofline"] = roof
             rec["roofline_phases"] = phases
