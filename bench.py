@@ -816,7 +816,10 @@ def main(argv=None):
         dt = du.max_over_ranks(ctx, time.perf_counter() - t0)
         roof = phases = None
         if rank == 0 and gpu and not a.no_roofline:
-            roof, phases = measure_roofline(w)
+            try:
+                roof, phases = measure_roofline(w)
+            except Exception as ex:      # the timed result above stands on its own: report the failure instead of losing the line
+                roof, phases = {"error": repr(ex)}, None
     if rank == 0:
         total = du.total_units(ctx, a.steps) * a.batch
         rec = {"metric": "end-to-end generations/sec (img-in -> txt + 1024px-img-out)" if a.config == 0 else
