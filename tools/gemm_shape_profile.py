@@ -50,6 +50,7 @@ def main():
         w.step(0)                                                               # warm-up (graphs, caches)
         w.agent.use_graph = False
         w.adapter._loop.use_graph = False
+        w.adapter._loop.chains = 1          # ONE kernel chain: with two concurrent chains an event pair also contains the other chain's kernels
         lib.sx_gemm = Hook()
         try:
             w.step(1)
