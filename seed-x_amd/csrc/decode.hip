@@ -514,6 +514,44 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const AttnDecP p
   float mg = -INFINITY;
 #pragma unroll
   for (int gg = 0; gg < 16; ++gg) mg = fmaxf(mg, red[gg][128]);
+  if (nsplit == 1) {
+    // one split per head: this workgroup holds the whole result — no partials in memory, no counter, no second pass. The
+    // split's (acc, m, l) go through LDS and the combine's arithmetic runs on them unchanged (same expressions as the split
+    // path and the combine below, so the bits are those of the three-launch form)
+    __shared__ float fin[132];
+    if (d < D) {
+      float acc = 0.f;
+#pragma unroll
+      for (int gg = 0; gg < 16; ++gg) {
+        const float mgk = red[gg][128];
+        const float w = (mgk == -INFINITY) ? 0.f : __expf(mgk - mg);
+        acc += w * red[gg][d];
+      }
+      fin[d] = acc;
+    }
+    if (d == 0) {
+      float lsum = 0.f;
+      for (int gg = 0; gg < 16; ++gg) {
+        const float mgk = red[gg][128];
+        lsum += (mgk == -INFINITY) ? 0.f : __expf(mgk - mg) * red[gg][129];
+      }
+      fin[D] = mg;
+      fin[D + 1] = lsum;
+    }
+    __syncthreads();
+    if (d >= D) return;
+    float mall = -INFINITY;
+    mall = fmaxf(mall, fin[D]);
+    const float ms = fin[D];
+    const float w1 = (ms == -INFINITY) ? 0.f : __expf(ms - mall);
+    float a2 = 0.f, l2 = 0.f;
+    a2 += w1 * fin[d];
+    l2 += w1 * fin[D + 1];
+    const int col1 = h * D + d;
+    const size_t o1 = p.tiled ? (size_t)(col1 >> 5) * 512 + (size_t)g * 32 + (col1 & 31) : (size_t)g * H * D + col1;
+    p.out[o1] = TT::from_f32(l2 > 0.f ? a2 / l2 : 0.f);
+    return;
+  }
   if (d < D) {
     float acc = 0.f;
 #pragma unroll

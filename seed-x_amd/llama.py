@@ -68,10 +68,14 @@ class LlamaForCausalLM:
         self.H_l = self.nh_l * self.hd
         self.Tmax = max_cache_len or c.max_position_embeddings
         self.G = int(max_batch)
-        # True: RoPE + KV append + split-KV attention + combine as ONE launch (sx_attn_decode_fused, bit-identical). Measured
-        # 1.8 % slower per token than the three launches inside the step's HIP graph (6.80 vs 6.68 ms, 16 sequences,
-        # tools/bench_decode_attention_ab.py): the arrival-counter tail costs more than two graph launches → off by default
-        self.fused_decode_attention = False
+        # Decode attention (tools/bench_decode_attention_ab.py, 16 sequences x 40 heads, ms per token of the graph-replayed step):
+        # three launches (RoPE + append, split-KV attention, combine) with 8 / 2 / 1 KV splits 6.70 / 6.46 / 6.52; ONE launch
+        # (sx_attn_decode_fused, bit-identical) with 8 splits 6.80 — its arrival-counter tail costs more than two graph
+        # launches — but with ONE split per head it needs no partials, counter or second pass at all. So: G x heads >= 512
+        # workgroups without splitting → fused, 1 split; fewer → three launches with just enough splits for ~1024 workgroups.
+        # Both from the GLOBAL head count: tensor-parallel ranks split exactly like one rank (bit-identical per head).
+        self.fused_decode_attention = self.G * self.nh >= 512
+        self.decode_nsplit = 1 if self.fused_decode_attention else min(8, max(1, -(-1024 // (self.G * self.nh))))
         assert 1 <= self.G <= 16, "lock-step batch is limited to 16 sequences (sx_gemv rows)"
         self.device, self.dtype = None, torch.float16
         self._sd, self._P = None, None
@@ -275,11 +279,11 @@ class LlamaForCausalLM:
             if self.fused_decode_attention and hd % 16 == 0:
                 # RoPE + KV append + split-KV attention + combine as one launch (bit-identical to the three-kernel form below)
                 att = ops.attn_decode_fused(qkv, P["kc"][li], P["vc"][li], P["pos"], P["cos"], P["sin"], scale, nh, hd,
-                                            P["attn_cnt"], out_tiled=tl)
+                                            P["attn_cnt"], nsplit=self.decode_nsplit, out_tiled=tl)
             else:
                 ops.rope_kv_append_b(qkv, P["kc"][li], P["vc"][li], P["cos"], P["sin"], P["pos"], G, 1, nh, hd)
                 q = qkv[:, :H].unflatten(1, (nh, hd))                                # strided view into qkv: no copy
-                att = ops.attn_decode_b(q, P["kc"][li], P["vc"][li], P["ctx"], scale, out_tiled=tl)
+                att = ops.attn_decode_b(q, P["kc"][li], P["vc"][li], P["ctx"], scale, nsplit=self.decode_nsplit, out_tiled=tl)
             x = comm.all_reduce(ops.gemv(att, lw["wo"], residual=x if lead else None, out_dtype=torch.float32,
                                          w_tiles=lw["wo_t"], workspace=ws))
             h = ops.rmsnorm(x, lw["ln2"], eps, dt, tiled=tl)

@@ -391,11 +391,13 @@ def test_gemv_tiled_activations_and_split_k(dev, dtype, M, N, K):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("nsplit", [8, 1, 3])
 @pytest.mark.parametrize("G,H,D,tiled", [(7, 8, 128, True), (1, 5, 128, False), (16, 4, 64, True), (3, 2, 112, False)])
-def test_attn_decode_fused_equals_three_kernel_form(dev, dtype, G, H, D, tiled):
+def test_attn_decode_fused_equals_three_kernel_form(dev, dtype, G, H, D, tiled, nsplit):
     """sx_attn_decode_fused (RoPE + KV append + split-KV attention + combine in one launch) against sx_rope_kv_append_b +
     sx_attn_decode_b: the SAME bits in the output and in both caches, for positions 0, mid-chunk, chunk boundaries and the last
-    cache slot; positions outside the cache write nothing. The arrival counters are left at zero."""
+    cache slot; positions outside the cache write nothing. The arrival counters are left at zero. nsplit = 1 is the
+    no-partials fast path the lock-step batch uses (one workgroup per head and sequence)."""
     from seedx_amd import ops
     T = 96
     pos_list = ([0, 5, 95, 40, 17, 64, 33, 8, 15, 16, 31, 32, 47, 48, 63, 94] * 2)[:G]
@@ -409,12 +411,12 @@ def test_attn_decode_fused_equals_three_kernel_form(dev, dtype, G, H, D, tiled):
     # three-kernel form
     q1, kc1, vc1 = qkv.clone(), kc0.clone(), vc0.clone()
     ops.rope_kv_append_b(q1, kc1, vc1, cos, sin, pos, G, 1, H, D)
-    ref = ops.attn_decode_b(q1[:, :H * D].unflatten(1, (H, D)), kc1, vc1, pos + 1, scale)
+    ref = ops.attn_decode_b(q1[:, :H * D].unflatten(1, (H, D)), kc1, vc1, pos + 1, scale, nsplit=nsplit)
     # fused
     q2, kc2, vc2 = qkv.clone(), kc0.clone(), vc0.clone()
     cnt = torch.zeros(G * H, dtype=torch.int32, device=dev)
     for rep in range(3):               # repeated launches: counters must have been left at zero
-        out = ops.attn_decode_fused(q2, kc2, vc2, pos, cos, sin, scale, H, D, cnt, out_tiled=tiled and (H * D) % 32 == 0)
+        out = ops.attn_decode_fused(q2, kc2, vc2, pos, cos, sin, scale, H, D, cnt, nsplit=nsplit, out_tiled=tiled and (H * D) % 32 == 0)
         got = out.dense() if isinstance(out, ops.Tiled16) else out
         assert torch.equal(got, ref), f"rep {rep}: max diff {(got.float() - ref.float()).abs().max().item()}"
     assert torch.equal(kc2, kc1) and torch.equal(vc2, vc1) and torch.equal(q2, qkv)
@@ -422,7 +424,7 @@ def test_attn_decode_fused_equals_three_kernel_form(dev, dtype, G, H, D, tiled):
     # a position past the cache: nothing is written
     bad = pos.clone(); bad[0] = T
     kc3, vc3 = kc0.clone(), vc0.clone()
-    ops.attn_decode_fused(qkv.clone(), kc3, vc3, bad, cos, sin, scale, H, D, cnt)
+    ops.attn_decode_fused(qkv.clone(), kc3, vc3, bad, cos, sin, scale, H, D, cnt, nsplit=nsplit)
     assert torch.equal(kc3[0], kc0[0]) and torch.equal(vc3[0], vc0[0])
 
 

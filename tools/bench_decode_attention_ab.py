@@ -13,8 +13,9 @@ with torch.no_grad():
     ids = torch.full((G, 200), -1, dtype=torch.int32, device=dev)
     hid = torch.zeros((G, 200, llm.config.hidden_size), device=dev)
     img_ids = torch.arange(llm.V - 200, llm.V - 134, dtype=torch.int32, device=dev)
-    for fused in (True, False, True, False):
+    for fused, nsplit in ((False, 8), (False, 2), (True, 8), (True, 1), (False, 1), (False, 2), (True, 1)):
         llm.fused_decode_attention = fused
+        llm.decode_nsplit = nsplit
         llm._graph = None
         llm.reset()
         llm._P["pos"].fill_(230); llm._P["ctx"].fill_(231); llm._P["step"].zero_(); llm._P["cur"].fill_(5)
@@ -26,4 +27,4 @@ with torch.no_grad():
         for _ in range(64):
             llm.decode_step(img_ids, ids, hid, use_graph=True)
         e1.record(); torch.cuda.synchronize()
-        print("fused" if fused else "three kernels", "%.3f ms per token (16 sequences, ~260 keys)" % (e0.elapsed_time(e1) / 64), flush=True)
+        print("fused" if fused else "three kernels", "nsplit", nsplit, "%.3f ms per token (16 sequences, ~260 keys)" % (e0.elapsed_time(e1) / 64), flush=True)
