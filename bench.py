@@ -412,7 +412,7 @@ def measure_roofline(w):
     Returns (roofline of the dominant kernel family, per-phase dict)."""
     from seedx_amd import _lib, ops
     lib = _lib.load()
-    real = {n: getattr(lib, n) for n in ("sx_gemm", "sx_gemv", "sx_attention", "sx_attn_decode_b")}
+    real = {n: getattr(lib, n) for n in ("sx_gemm", "sx_gemv", "sx_attention", "sx_attn_decode_b", "sx_attn_decode_fused")}
     rec = []                       # (family, phase, flops, bytes, start, end)
     executed = {}                  # phase -> MFMA FLOPs actually issued (plane-carrying launches counted with their tripled K)
     stack = ["other"]
@@ -454,6 +454,11 @@ def measure_roofline(w):
         keys = float(w.agent.llm._P["ctx"][:G].sum().item())
         return timed("attn_decode", 4.0 * keys * H * D, 2.0 * 2.0 * keys * H * D, real["sx_attn_decode_b"], *args)
 
+    def h_attn_decode_fused(args_ref, stream):
+        a = args_ref._obj          # one-launch form: K and V of pos[g] + 1 keys per sequence
+        keys = float(w.agent.llm._P["pos"][:a.G].sum().item()) + a.G
+        return timed("attn_decode", 4.0 * keys * a.H * a.D, 2.0 * 2.0 * keys * a.H * a.D, real["sx_attn_decode_fused"], args_ref, stream)
+
     def phase_wrap(obj, name, phase):
         cls = type(obj)
         orig = getattr(cls, name)
@@ -493,6 +498,7 @@ def measure_roofline(w):
         lib.sx_gemm, lib.sx_gemv, lib.sx_attention = h_gemm, h_gemv, h_attn
         if agent is not None:
             lib.sx_attn_decode_b = h_attn_decode
+            lib.sx_attn_decode_fused = h_attn_decode_fused
         w.step(1)
         torch.cuda.synchronize()
     finally:
