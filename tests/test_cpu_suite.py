@@ -191,7 +191,8 @@ def test_ctypes_struct_layout_matches_header():
     from seedx_amd import _lib
     src = open(os.path.join(ROOT, "include", "seedx_hip.h")).read()
     for cname, cls in (("sx_gemm_args", _lib.GemmArgs), ("sx_gemv_args", _lib.GemvArgs), ("sx_attn_args", _lib.AttnArgs),
-                       ("sx_attn_small_args", _lib.AttnSmallArgs), ("sx_oneshot_args", _lib.OneshotArgs)):
+                       ("sx_attn_small_args", _lib.AttnSmallArgs), ("sx_oneshot_args", _lib.OneshotArgs),
+                       ("sx_attn_decode_args", _lib.AttnDecodeArgs)):
         body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), src, flags=re.S).group(1)
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
         names = []
