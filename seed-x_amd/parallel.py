@@ -106,11 +106,14 @@ class IpcComm(Comm):
 
     CHUNK = 4096                               # floats per workgroup (SX_ONESHOT_CHUNK in include/seedx_hip.h)
 
-    def __init__(self, bootstrap=None, cap_floats=131072, device=None, max_spin=0):
+    def __init__(self, bootstrap=None, cap_floats=131072, device=None, max_spin=0, graph_safe=True):
         import ctypes as C
         import torch.distributed as dist
         from . import _lib
         self._dist, self.group = dist, bootstrap
+        # graph_safe=False: for callers whose payloads also take the bootstrap-group fallback (the row-sharded UNet: halo rows
+        # fit the one-shot kernel, the K|V gathers and fp64 GroupNorm sums go to RCCL) — an RCCL call cannot be captured
+        self.graph_safe = bool(graph_safe)
         self.rank, self.world = dist.get_rank(bootstrap), dist.get_world_size(bootstrap)
         self.cap, self.max_spin = -(-int(cap_floats) // self.CHUNK) * self.CHUNK, int(max_spin)
         nchunk = self.cap // self.CHUNK
@@ -173,8 +176,13 @@ class IpcComm(Comm):
     def all_gather(self, t):
         t = t.contiguous()
         out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        nbytes = t.numel() * t.element_size()
         if self._fits(t):
             self._launch(t, gather_out=out)
+        elif t.is_cuda and t.dtype != torch.float32 and nbytes % 4 == 0 and 0 < nbytes // 4 <= self.cap:
+            # a gather moves bits, it does no arithmetic: any dtype travels as 32-bit words (the row-sharded UNet's 16-bit conv
+            # halo rows, int32 ids, ...) through the same one-shot kernel
+            self._launch(t.view(-1).view(torch.float32), gather_out=out.view(-1).view(torch.float32))
         else:
             parts = [torch.empty_like(t) for _ in range(self.world)]
             self._dist.all_gather(parts, t, group=self.group)

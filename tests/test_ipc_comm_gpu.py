@@ -3,7 +3,7 @@ PROCESSES ON ONE GPU — the only way the 1-GPU pool can exercise the real cross
 flags, system-scope visibility, HIP-graph capture of the collective). Multi-GPU timing over xGMI remains unmeasured.
   * all-reduce: bit-identical to the rank-ordered sum (= ThreadComm's `parts[0] + parts[1]`) for payloads from 4 B to the
     staging capacity, 300 back-to-back epochs (slot reuse), then captured into a HIP graph and replayed
-  * all-gather through the same staging
+  * all-gather through the same staging (fp32, and 16-bit payloads as 32-bit words: the UNet's conv halo rows)
   * tensor-parallel Llama (tp = 2): prefill + graph-replayed decode steps with their all-reduces INSIDE the graph; logits and
     greedy ids equal the single-rank run's tokens and agree with the oracle"""
 import os
@@ -51,6 +51,12 @@ for it in range(20):
     parts = [payload(r, 7000 + it, 4000).view(8, 500) for r in range(world)]
     out = comm.all_gather(parts[rank].to(dev))
     assert out.shape == (world, 8, 500) and torch.equal(out.cpu(), torch.stack(parts))
+
+# 16-bit payloads (the row-sharded UNet's conv halo rows) travel as 32-bit words through the same kernel
+for it in range(10):
+    parts = [payload(r, 8000 + it, 2 * 2 * 64 * 320).view(2, 2, 64, 320).to(torch.bfloat16) for r in range(world)]
+    out = comm.all_gather(parts[rank].to(dev))
+    assert out.dtype == torch.bfloat16 and out.shape == (world, 2, 2, 64, 320) and torch.equal(out.cpu(), torch.stack(parts))
 
 # ---- the collective inside a HIP graph -----------------------------------------------------------------------------------
 buf = torch.zeros(16 * 5120, device=dev)

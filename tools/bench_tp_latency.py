@@ -46,6 +46,9 @@ def main():
     ap.add_argument("--config", type=int, default=0, choices=[0, 4])
     ap.add_argument("--unet", default="rows", choices=["rows", "cfg"])
     ap.add_argument("--llm-comm", default="ipc", choices=["ipc", "rccl"])
+    ap.add_argument("--unet-comm", default="rccl", choices=["ipc", "rccl"],
+                    help="ipc: the conv halo rows of the row-sharded UNet go through the one-shot kernel (K|V gathers and fp64 "
+                         "GroupNorm sums stay on the process group)")
     ap.add_argument("--share-gpu", action="store_true", help="all ranks on GPU 0, gloo bootstrap (functional check on a 1-GPU box)")
     a = ap.parse_args()
     if a.gpus and a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -67,7 +70,7 @@ def main():
     unet_comm = cfg_comm = None
     edit = a.config == 4
     if multi and a.unet == "rows":
-        unet_comm = TorchDistComm()
+        unet_comm = IpcComm(None, device=dev, graph_safe=False) if a.unet_comm == "ipc" else TorchDistComm()
     elif multi:
         nb = 3 if edit else 2
         assert ctx.world >= nb, "CFG-parallel needs one rank per guidance branch"
