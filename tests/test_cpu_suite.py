@@ -239,6 +239,28 @@ def test_tiled16_layout_contract():
         ops.Tiled16(17, 64, torch.float32, "cpu")
 
 
+def test_decode_attention_policy_is_tp_invariant():
+    """The decode-attention form (one fused launch with one KV split per head, or RoPE + split-KV + combine with just enough
+    splits) is chosen from the lock-step batch and the GLOBAL head count: every tensor-parallel degree must make the same
+    choice as a single rank, otherwise per-head results would differ between TP degrees in the last bit."""
+    from seedx_amd.llama import LlamaForCausalLM
+    from seedx_amd.parallel import Comm
+
+    class FakeComm(Comm):
+        def __init__(self, rank, world):
+            self.rank, self.world = rank, world
+    cfg = dict(hidden_size=5120, intermediate_size=13824, num_hidden_layers=2, num_attention_heads=40, vocab_size=32330,
+               rms_norm_eps=1e-5, max_position_embeddings=2048)
+    seen = {}
+    for G in (1, 4, 13, 16):
+        for tp in (1, 2, 4, 8):
+            m = LlamaForCausalLM(dict(cfg), max_cache_len=64, max_batch=G, comm=FakeComm(0, tp))
+            seen.setdefault(G, set()).add((m.fused_decode_attention, m.decode_nsplit))
+    assert all(len(v) == 1 for v in seen.values()), seen
+    assert seen[16] == {(True, 1)} and seen[13] == {(True, 1)}          # 520+ (sequence, head) pairs: no split needed
+    assert seen[1] == {(False, 8)} and seen[4] == {(False, 7)}         # few pairs: ~1024 workgroups through KV splits
+
+
 def test_glu_pack_rows_contract():
     from seedx_amd.llama import glu_pack_rows
     lin = torch.arange(64 * 3).float().view(64, 3)
