@@ -182,6 +182,8 @@ class IpcComm(Comm):
         elif t.is_cuda and t.dtype != torch.float32 and nbytes % 4 == 0 and 0 < nbytes // 4 <= self.cap:
             # a gather moves bits, it does no arithmetic: any dtype travels as 32-bit words (the row-sharded UNet's 16-bit conv
             # halo rows, int32 ids, ...) through the same one-shot kernel
+            if (t.storage_offset() * t.element_size()) % 4:
+                t = t.clone()                    # a 16-bit view starting on an odd element: re-base it on a 4-byte boundary
             self._launch(t.view(-1).view(torch.float32), gather_out=out.view(-1).view(torch.float32))
         else:
             parts = [torch.empty_like(t) for _ in range(self.world)]
