@@ -202,6 +202,161 @@ def run_reference_preproc():
     return {"anyres_mini.npz": arrs}
 
 
+# ---- path B orchestration: the reference's OWN ContinuousLVLM.generate, executed over oracle/hf_generate_shim.py -------
+LVLM_VIT_DIM, LVLM_GRID, LVLM_HEADS = 128, 4, 2
+LVLM_MIN_GAP = 0.08          # every free (non-forced) arg-max of a committed transcript wins by at least this much
+
+
+def lvlm_cases(variant=0):
+    """Inputs of the four generate() cases (seeded by `variant`; the fixture stores the inputs it was made with, the
+    reference's OUTPUTS, and the lm_head rows that were re-aimed to steer the transcript). 16 resampled tokens per crop."""
+    nq = LVLM_GRID * LVLM_GRID
+    v = variant
+
+    def crops(n, seed):
+        return torch.randn(n, 36, LVLM_VIT_DIM, generator=torch.Generator().manual_seed(seed + 100 * v))
+    cases = {}
+    # (a) comprehension: 1 image = 2 crops (tile + global, any_res.py:185-189), ends on EOS
+    ids = [1, 11, 12, 13 + v] + [0] * nq + [0] * nq + [21, 22, 23, 24, 25]
+    m = torch.zeros(1, len(ids), dtype=torch.bool)
+    m[0, 4:4 + 2 * nq] = True
+    cases["comp2"] = dict(input_ids=[ids], ids_cmp_mask=m, image_embeds=crops(2, 5), embeds_cmp_mask=torch.tensor([True, True]),
+                          patch_positions=torch.tensor([[0.0, 0.0], [0.5, 0.5]]), max_new_tokens=24, num_img_gen_tokens=16,
+                          aim=(2, 9))                      # re-aim lm_head[EOS] so that new token #9 is EOS
+    # (b) text → image: prompt STRING through the tokenizer (seed_x.py:151-152), no image input, default 64 image tokens,
+    #     transcript = text, one image block, text until max_new_tokens
+    cases["t2i"] = dict(prompt=f"31 32 33 34 35 36 37 38 39 40 41 {42 + v}", max_new_tokens=80, num_img_gen_tokens=64,
+                        aim=(400, 4))
+    # (c) any-res: 896-px-style input = 2x2 tiles + global = 5 crops, one of six embeds NOT selected (embeds_cmp_mask False:
+    #     seed_x.py:173 indexes image_embeds_lm with it), input_ids as a LongTensor (seed_x.py:154-157), image block(s) out
+    ids = [1, 51, 52 + v] + ([0] * nq + [53]) * 5 + [54, 55, 56]
+    m = torch.zeros(1, len(ids), dtype=torch.bool)
+    for c in range(5):
+        m[0, 3 + c * (nq + 1):3 + c * (nq + 1) + nq] = True
+    pp = torch.tensor([[0.0, 0.0], [0.0, 0.5], [0.7, 0.7], [0.5, 0.0], [0.5, 0.5], [0.5, 0.5]])
+    cases["anyres5"] = dict(input_ids=torch.tensor([ids]), ids_cmp_mask=m, image_embeds=crops(6, 6),
+                            embeds_cmp_mask=torch.tensor([True, True, False, True, True, True]), patch_positions=pp,
+                            max_new_tokens=48, num_img_gen_tokens=16, aim=(400, 7))
+    # (d) no image in, image block cut by max_new_tokens: <img> + part of the chain, no </img> → has_img_output False
+    cases["truncated"] = dict(input_ids=[[1, 61, 62, 63, 64, 65, 66 + v]], max_new_tokens=12, num_img_gen_tokens=16, aim=(400, 5))
+    return cases
+
+
+def _lvlm_weights():
+    cfg = weights.MINI_LLM
+    return cfg, weights.llama_sd(cfg), weights.agent_sd(cfg, LVLM_VIT_DIM, in_grid=LVLM_GRID, out_grid=LVLM_GRID)
+
+
+def _run_ref_generate(sd_llm, sd_agent, case):
+    """One call of the reference's ContinuousLVLM.generate (fp32, CPU). Returns its result dict + what llm.generate produced."""
+    from oracle import hf_generate_shim as hs
+    cfg = weights.MINI_LLM
+    m = hs.build_reference_lvlm(cfg, sd_llm, sd_agent, LVLM_VIT_DIM, LVLM_GRID, LVLM_GRID, LVLM_HEADS)
+    rec = {}
+    inner = m.llm.generate
+
+    def recording_generate(**kw):                         # observes (does not alter) the call made at seed_x.py:184-189
+        rec["kwargs"] = {k: v for k, v in kw.items() if k not in ("input_ids", "inputs_embeds", "logits_processor")}
+        rec["out"] = inner(output_scores=True, **kw)
+        return rec["out"]
+    m.llm.generate = recording_generate
+    kw = {k: v for k, v in case.items() if k != "aim"}
+    with torch.no_grad():
+        out = m.generate(hs.StubTokenizer(), dtype=torch.float32, device="cpu", **kw)
+    return out, rec
+
+
+def _aim_row(sd_llm, sd_agent, case):
+    """Re-aims ONE lm_head row so that the seeded random-weight model emits EOS / <img> as new token #step and not before:
+    the minimum-norm row w with w·h_t = -4 for the final states h_t of the earlier steps and w·h_step = (that step's best
+    logit) + 3, h_t taken from the reference's own run. Other rows are untouched, so the transcript before #step is too."""
+    row, step = case["aim"]
+    _, rec = _run_ref_generate(sd_llm, sd_agent, dict(case, max_new_tokens=step + 1))
+    hs_ = torch.stack([rec["out"].hidden_states[t][-1][0, -1] for t in range(step + 1)])       # [step+1, H]
+    tgt = torch.full((step + 1,), -4.0)
+    tgt[step] = float(rec["out"].scores[step][0].max()) + 3.0
+    w = torch.linalg.pinv(hs_.double()) @ tgt.double()
+    sd_llm["lm_head.weight"][row] = w.float()
+    return row, sd_llm["lm_head.weight"][row].clone()
+
+
+def run_reference_generate(max_variants=40):
+    """{file: arrays}. Per case the input variant is advanced until every free arg-max of the reference's transcript wins by
+    ≥ LVLM_MIN_GAP (so a 16-bit implementation is expected to reproduce the ids exactly); the chosen inputs travel in the fixture."""
+    from oracle import hf_generate_shim as hs
+    cfg, sd_llm0, sd_agent = _lvlm_weights()
+    tok = hs.StubTokenizer()
+    arrs = {}
+    for name in lvlm_cases():
+        for variant in range(max_variants):
+            case = lvlm_cases(variant)[name]
+            sd_llm = {k: v.clone() for k, v in sd_llm0.items()}
+            rows = dict([_aim_row(sd_llm, sd_agent, case)]) if case["aim"] is not None else {}
+            out, rec = _run_ref_generate(sd_llm, sd_agent, case)
+            o = rec["out"]
+            top2 = torch.stack([torch.topk(s[0], 2).values for s in o.scores])
+            gap, std = top2[:, 0] - top2[:, 1], torch.stack([s[0].std() for s in o.scores])
+            free = gap < 9.0                                                # forced steps win by exactly 10 (generation.py:26)
+            if free.any() and float(gap[free].min()) >= LVLM_MIN_GAP:
+                break
+        else:
+            raise RuntimeError(f"{name}: no variant with a clear transcript")
+        assert rec["kwargs"]["do_sample"] is False and rec["kwargs"]["output_hidden_states"] and rec["kwargs"]["return_dict_in_generate"]
+        if "prompt" in case:
+            in_ids = torch.tensor([tok.encode(case["prompt"], add_special_tokens=True)])
+        else:
+            in_ids = torch.as_tensor(case["input_ids"]).reshape(1, -1)
+        n_in = in_ids.shape[1]
+        seq = o.sequences[0]
+        assert torch.equal(seq[:n_in], in_ids[0])                          # quirk 14: the prompt ids lead .sequences
+        last_hidden = torch.cat([hs_[-1] for hs_ in o.hidden_states], dim=1)[0, n_in:, :]   # seed_x.py:196-197
+        a = dict(variant=np.array(variant), input_ids=in_ids, max_new_tokens=np.array(case["max_new_tokens"]),
+                 num_img_gen_tokens=np.array(case["num_img_gen_tokens"]), prompt=np.array(case.get("prompt", "")),
+                 sequences=seq, generate_ids=seq[n_in:], top2_gap=gap, score_std=std, last_hidden_states=last_hidden,
+                 text=np.array(out["text"]), has_img_output=np.array(out["has_img_output"]),
+                 num_gen_imgs=np.array(out["num_gen_imgs"]),
+                 img_gen_feat=out["img_gen_feat"] if out["img_gen_feat"] is not None else torch.zeros(0))
+        for k in ("ids_cmp_mask", "image_embeds", "embeds_cmp_mask", "patch_positions"):
+            if k in case:
+                a[k] = case[k]
+        for r, v in rows.items():
+            a[f"lm_head_row_{r}"] = v
+        print(f"  {name}: variant {variant}, {len(seq) - n_in} new tokens {seq[n_in:].tolist()}, min free gap {float(gap[free].min()):.3f}, "
+              f"text {out['text']!r}, images {out['num_gen_imgs']}")
+        arrs.update({f"{name}.{k}": v for k, v in a.items()})
+    return {"lvlm_generate_mini.npz": arrs}
+
+
+LVLM_CASE_NAMES = ("comp2", "t2i", "anyres5", "truncated")
+
+
+def lvlm_case_weights(name, gold):
+    """(cfg, sd_llm, sd_agent) of a committed case: the seeded weights + the fixture's re-aimed lm_head rows."""
+    cfg, sd_llm, sd_agent = _lvlm_weights()
+    for k in gold.files:
+        if k.startswith(name + ".lm_head_row_"):
+            sd_llm["lm_head.weight"][int(k.rsplit("_", 1)[1])] = torch.as_tensor(np.asarray(gold[k]))
+    return cfg, sd_llm, sd_agent
+
+
+def lvlm_case_inputs(name, gold):
+    """generate() keyword arguments of a committed case, rebuilt from the fixture."""
+    kw = dict(max_new_tokens=int(gold[f"{name}.max_new_tokens"]), num_img_gen_tokens=int(gold[f"{name}.num_img_gen_tokens"]))
+    if str(gold[f"{name}.prompt"]):
+        kw["prompt"] = str(gold[f"{name}.prompt"])
+    else:
+        kw["input_ids"] = torch.as_tensor(gold[f"{name}.input_ids"])
+    for k in ("ids_cmp_mask", "image_embeds", "embeds_cmp_mask", "patch_positions"):
+        if f"{name}.{k}" in gold.files:
+            kw[k] = torch.as_tensor(gold[f"{name}.{k}"])
+    return kw
+
+
+def main_generate():
+    for name, arrs in run_reference_generate().items():
+        _save(name, **arrs)
+
+
 def main_detok():
     for name, arrs in run_reference_preproc().items():
         _save(name, **arrs)
@@ -212,6 +367,10 @@ def main_detok():
 if __name__ == "__main__":
     if not refshim.available():
         raise SystemExit("/root/reference is not available: golden fixtures can only be generated in the build container")
+    if "--generate-only" in sys.argv:
+        main_generate()
+        raise SystemExit(0)
     if "--detok-only" not in sys.argv:
         main()
+        main_generate()
     main_detok()

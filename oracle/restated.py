@@ -222,8 +222,9 @@ def greedy_generate(sd, cfg, input_ids, inputs_embeds, img_ids, max_new_tokens, 
 
 def lvlm_generate(sd_llm, sd_agent, cfg, res_cfg, input_ids, image_embeds, embeds_cmp_mask, ids_cmp_mask,
                   patch_positions, img_ids, boi_id, eoi_id, max_new_tokens, num_img_gen_tokens=64, eos_id=None,
-                  table_dtype=None, force_ids=None, trace=None, return_prefill=False):
-    """ContinuousLVLM.generate (seed_x.py:130-223). input_ids: list[int]; image_embeds [n,256,4096]-like or None.
+                  table_dtype=None, force_ids=None, trace=None, return_prefill=False, tokenizer=None):
+    """ContinuousLVLM.generate (seed_x.py:130-223). Pinned against the reference's own generate() executed over
+    oracle/hf_generate_shim.py: tests/golden/lvlm_generate_mini.npz (tests/test_cpu_suite.py, test_oracle_vs_reference.py). input_ids: list[int]; image_embeds [n,256,4096]-like or None.
     sd_agent keys: input_resampler.*, output_resampler.*, patch_pos_embed. Returns dict like the reference plus ids."""
     emb = sd_llm["model.embed_tokens.weight"]
     x = emb[torch.tensor([input_ids])].clone()                                          # :158
@@ -249,8 +250,15 @@ def lvlm_generate(sd_llm, sd_agent, cfg, res_cfg, input_ids, image_embeds, embed
         # last_hidden has one row fewer than `new` when generation stops on the last token (it is never fed).
         st = [last_hidden[e - num_img_gen_tokens:e] for e in eoi_idx]                    # :204-205
         feats = resampler_forward(sd_agent, "output_resampler.", torch.stack(st), res_cfg["out_heads"], 1e-5)  # :209-210
-    return {"ids": new, "has_img_output": bool(eoi_idx), "img_gen_feat": feats, "num_gen_imgs": len(eoi_idx),
-            "last_hidden": last_hidden}
+    res = {"ids": new, "has_img_output": bool(eoi_idx), "img_gen_feat": feats, "num_gen_imgs": len(eoi_idx),
+           "last_hidden": last_hidden}
+    if tokenizer is not None:                                                            # :201-216
+        text_mask = torch.ones_like(gen, dtype=torch.bool)
+        for e in eoi_idx:
+            text_mask[e - num_img_gen_tokens:e] = False      # (a negative start makes this an empty slice, as in the reference)
+        text_mask[gen == boi_id] = False
+        res["text"] = tokenizer.decode(gen[text_mask], skip_special_tokens=False)
+    return res
 
 
 # ---------------------------------------------------------------------------------------------------------

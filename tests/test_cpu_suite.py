@@ -67,6 +67,35 @@ def test_oracle_resamplers_match_golden():
     assert _rel(pe, g["prompt"]) < 2e-5 and _rel(pooled, g["pooled"]) < 2e-5
 
 
+@pytest.mark.parametrize("name", ["comp2", "t2i", "anyres5", "truncated"])
+def test_oracle_lvlm_generate_matches_reference_executed_golden(name):
+    """oracle/restated.lvlm_generate (+ greedy_generate, logits_rule) against tests/golden/lvlm_generate_mini.npz = the
+    reference's OWN ContinuousLVLM.generate / prepare_inputs_for_generation / AutoImageTokenGenerationProcessor executed over
+    the HF-4.30.2 greedy stand-in (oracle/hf_generate_shim.py): ids, per-step final hidden states, text, image features."""
+    from oracle import gen_golden as gg, hf_generate_shim as hs
+    gold = np.load(os.path.join(GOLD, "lvlm_generate_mini.npz"))
+    cfg, sd_llm, sd_agent = gg.lvlm_case_weights(name, gold)
+    kw = gg.lvlm_case_inputs(name, gold)
+    tok = hs.StubTokenizer()
+    nimg = kw["num_img_gen_tokens"]
+    img_ids = tok.encode("".join(["<img>"] + [f"<img_{i:05d}>" for i in range(nimg)] + ["</img>"]))
+    ids = tok(kw["prompt"]).input_ids[0].tolist() if "prompt" in kw else kw["input_ids"].reshape(-1).tolist()
+    assert ids == gold[f"{name}.input_ids"].reshape(-1).tolist()
+    out = restated.lvlm_generate(sd_llm, sd_agent, cfg, {"in_heads": 2, "out_heads": 2}, ids, kw.get("image_embeds"),
+                                 kw.get("embeds_cmp_mask"), kw.get("ids_cmp_mask"), kw.get("patch_positions"), img_ids,
+                                 img_ids[0], img_ids[-1], kw["max_new_tokens"], nimg, eos_id=tok.eos_token_id, tokenizer=tok)
+    assert out["ids"] == gold[f"{name}.generate_ids"].tolist()
+    assert out["text"] == str(gold[f"{name}.text"])
+    assert out["has_img_output"] == bool(gold[f"{name}.has_img_output"]) and out["num_gen_imgs"] == int(gold[f"{name}.num_gen_imgs"])
+    assert out["last_hidden"].shape == gold[f"{name}.last_hidden_states"].shape
+    assert _rel(out["last_hidden"], gold[f"{name}.last_hidden_states"]) < 2e-5
+    if out["has_img_output"]:
+        assert out["img_gen_feat"].shape == gold[f"{name}.img_gen_feat"].shape
+        assert _rel(out["img_gen_feat"], gold[f"{name}.img_gen_feat"]) < 2e-5
+    else:
+        assert out["img_gen_feat"] is None and gold[f"{name}.img_gen_feat"].size == 0
+
+
 def test_oracle_detok_matches_reference_executed_golden():
     """tests/golden/{t2i,edit}_mini.npz were produced by EXECUTING the reference's adapter_modules.py and
     pipeline_stable_diffusion_xl_t2i_edit.py (oracle/diffusers_shim.py supplies the third-party base classes); the

@@ -138,3 +138,40 @@ def test_detok_goldens_are_reproducible_and_pin_the_restated_adapter():
                                image_embeds=edit["feats"], image_latents=edit["image_latents"], **kw)
     img = ra.decode_to_pt(rv.vae_sd(gg.DETOK_VAE), gg.DETOK_VAE, lat2)
     assert (img - edit["image_pt"]).abs().max() < 1e-4
+
+
+# ---- path B orchestration: the reference's OWN ContinuousLVLM.generate over the HF-4.30.2 greedy stand-in -------------------
+def test_lvlm_generate_golden_is_reproducible():
+    """Re-executes seed_x.py:130-223 (+ modeling_llama_xformer.py:748-779, generation.py:19-31) through
+    oracle/hf_generate_shim.py and gets the committed tests/golden/lvlm_generate_mini.npz back bit for bit."""
+    import os
+    import numpy as np
+    from oracle import gen_golden as gg
+    live = gg.run_reference_generate()["lvlm_generate_mini.npz"]
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lvlm_generate_mini.npz"))
+    assert set(live) == set(gold.files)
+    for k, v in live.items():
+        v = v.detach().numpy() if torch.is_tensor(v) else np.asarray(v)
+        assert np.array_equal(gold[k], v), f"{k} differs from the committed fixture"
+
+
+def test_generate_shim_drives_the_reference_hooks():
+    """The stand-in must call the MODEL's own prepare_inputs_for_generation every step (step 0: inputs_embeds AND input_ids,
+    later: the last id only, position = cumsum(mask) - 1) and hand the growing attention_mask back to it."""
+    from oracle import gen_golden as gg, hf_generate_shim as hs
+    cfg, sd_llm, sd_agent = gg._lvlm_weights()
+    m = hs.build_reference_lvlm(cfg, sd_llm, sd_agent, gg.LVLM_VIT_DIM, gg.LVLM_GRID, gg.LVLM_GRID, gg.LVLM_HEADS)
+    calls = []
+    inner = m.llm.prepare_inputs_for_generation
+
+    def spy(input_ids, inputs_embeds=None, **kw):          # the stand-in inspects the signature for `inputs_embeds`, as 4.30.2 does
+        out = inner(input_ids, inputs_embeds=inputs_embeds, **kw)
+        calls.append((tuple(input_ids.shape), "inputs_embeds" in out, tuple(out["input_ids"].shape),
+                      out["position_ids"].tolist(), tuple(kw["attention_mask"].shape), kw.get("past_key_values") is not None))
+        return out
+    m.llm.prepare_inputs_for_generation = spy
+    with torch.no_grad():
+        m.generate(hs.StubTokenizer(), input_ids=[[1, 7, 8, 9]], max_new_tokens=3, dtype=torch.float32, device="cpu")
+    assert calls[0] == ((1, 4), True, (1, 4), [[0, 1, 2, 3]], (1, 4), False)
+    assert calls[1] == ((1, 5), False, (1, 1), [[4]], (1, 5), True)
+    assert calls[2] == ((1, 6), False, (1, 1), [[5]], (1, 6), True)
