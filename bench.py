@@ -40,6 +40,11 @@ FLOP_LLM_TOKEN = 25.71e9
 FLOP_UNET_SAMPLE = 6.747e12
 FLOP_VAE_DECODE = 10.47e12   # SDXL VAE decoder at 128x128 latents (conv/linear/attention MACs x 2)
 
+# rel-L2 bounds vs the fp32 oracle ASSERTED by the full-size GPU parity tests (tests/test_fullsize*_gpu.py)
+PARITY_BOUND = {"fp16": {"rel_l2_vs_fp32_oracle": 1e-3, "scope": "ViT features / LLM logits / UNet latents at BASELINE dimensions"},
+                "bf16": {"rel_l2_vs_fp32_oracle": 1.2e-2, "after_50_unet_steps": 2.5e-2,
+                         "note": "bf16 eps = 7.8e-3: north_star's 1e-3 is not reachable with bf16 operands"}}
+
 CONFIGS = {
     0: "headline: 1x448px image in -> text + one 1024px image out (BASELINE configs 2+3 composed)",
     1: "de-tokenizer only: 1x448px ViT features (B=2 incl. zero image) -> ResamplerXLV2 -> ONE SDXL-UNet CFG-2 Euler step",
@@ -221,8 +226,11 @@ class Headline(Workload):
     def describe(self):
         return ("SEED-X-I: 448x448 uint8 image -> GPU any-res/resize/normalise (2 crops) -> ViT-G -> 165-token prefill -> "
                 "128 greedy tokens (%d text + <img> + 64 forced + </img>) -> %d-step SDXL-UNet CFG-2 de-tokenize @1024x1024 "
-                "-> %s" % (self.a.text_tokens, self.a.unet_steps,
-                           "SDXL VAE decode to a uint8 [1024,1024,3] image" if USE_VAE else "latents (VAE decode skipped)"))
+                "-> %s. Batch of %d generations in lock step. Per-model constant cached outside the step: the CFG negative "
+                "branch's ViT(zeros) features (adapter_modules.py:110-116 recomputes them per call); the %d identical input "
+                "images are resized once per step" % (self.a.text_tokens, self.a.unet_steps,
+                           "SDXL VAE decode to a uint8 [1024,1024,3] image" if USE_VAE else "latents (VAE decode skipped)",
+                           BATCH, BATCH))
 
 
 class DetokOneStep(Workload):                                                   # config 1
@@ -742,7 +750,12 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", type=int, default=0, choices=sorted(CONFIGS), help="; ".join(f"{k}: {v}" for k, v in CONFIGS.items()))
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
+    ap.add_argument("--dtype", default="fp16", choices=["bf16", "fp16"],
+                    help="operand dtype of the timed run. Default fp16 = the reference scripts' dtype (eval_*.py) and the one whose "
+                         "full-size parity is asserted at north_star's 1e-3 (bf16: 1.2e-2, DESIGN.md §7)")
+    ap.add_argument("--also-dtype", default="auto", choices=["auto", "none", "bf16", "fp16"],
+                    help="after the timed run, time a short pass (1 warm-up + 2 steps) in a second dtype and report it as "
+                         "value_<dtype> in the same JSON line. auto: the other 16-bit type for config 0 on one GPU, else none")
     ap.add_argument("--unet-steps", type=int, default=50)
     ap.add_argument("--text-tokens", type=int, default=61)
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay (profiling aid)")
@@ -826,6 +839,32 @@ def main(argv=None):
                 roof, phases = measure_roofline(w)
             except Exception as ex:      # the timed result above stands on its own: report the failure instead of losing the line
                 roof, phases = {"error": repr(ex)}, None
+        # second dtype, short pass (same workload, same kernels, other operand type) → value_<dtype> in the same line
+        other = a.also_dtype
+        if other == "auto":
+            other = ({"fp16": "bf16", "bf16": "fp16"}[a.dtype]) if (a.config == 0 and world == 1 and gpu) else "none"
+        second = None
+        if other not in ("none", a.dtype) and gpu and world == 1:
+            try:
+                import gc
+                desc0, flops0 = w.describe(), w.flops()
+                w = pipe = None
+                gc.collect()
+                torch.cuda.empty_cache()
+                w2 = WORKLOADS[a.config](a, dev, torch.bfloat16 if other == "bf16" else torch.float16)
+                if getattr(getattr(w2, "adapter", None), "_loop", None) is not None:
+                    w2.adapter._loop.chains = a.chains
+                w2.step(100)
+                sync()
+                t1 = time.perf_counter()
+                for sd_ in (0, 1):
+                    w2.step(sd_)
+                sync()
+                dt2 = time.perf_counter() - t1
+                second = {"dtype": other, "value": 2 * a.batch / dt2, "ms_per_step": dt2 / 2 * 1e3, "steps": 2, "warmup": 1}
+                w = w2
+            except Exception as ex:
+                second = {"dtype": other, "error": repr(ex)}
     if rank == 0:
         total = du.total_units(ctx, a.steps) * a.batch
         rec = {"metric": "end-to-end generations/sec (img-in -> txt + 1024px-img-out)" if a.config == 0 else
@@ -834,12 +873,22 @@ def main(argv=None):
                "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": a.dtype if gpu else "none",
                "data": "synthetic (seeded random uint8 image / prompt ids, random-init weights of the real dims)",
-               "config": {"workload": w.describe() if gpu else "stub (launch-path test)", "baseline_config": a.config,
+               "config": {"workload": (desc0 if second is not None else w.describe()) if gpu else "stub (launch-path test)",
+                          "baseline_config": a.config,
+                          "parity_bound": PARITY_BOUND.get(a.dtype) if gpu else None,
                           "parallelism": "replica x%d (independent generations, no data-path collective)" % world,
                           "batch_per_gpu": a.batch, "request_pipelining": bool(a.overlap),
                           "vae": ("none" if not USE_VAE else {"fp32": "fp32-grade (two bf16 planes per operand, fp32 accumulation)",
                                                               "fast": "single 16-bit operands"}.get(VAE_PRECISION, "auto"))},
-               "flops_per_generation": w.flops(), "generations_per_step": a.batch}
+               "flops_per_generation": flops0 if second is not None else w.flops(), "generations_per_step": a.batch}
+        if second is not None:
+            if "error" in second:
+                rec["value_" + second["dtype"]] = None
+                rec["second_dtype"] = second
+            else:
+                rec["value_" + second["dtype"]] = second["value"]
+                rec["second_dtype"] = dict(second, parity_bound=PARITY_BOUND.get(second["dtype"]),
+                                           note="same workload and kernels in the other 16-bit operand type; short pass after the timed region")
         rec["model_tflops"] = rec["flops_per_generation"] * rec["value"] / world / 1e12
         rec["source_sha"] = {"csrc": _csrc_sha(), "gemm": _kernel_source_sha()}
         if roof is not None:

@@ -110,7 +110,8 @@ typedef struct sx_gemv_args {
   int32_t w_layout;    /* 0: W row-major [N][K]. 1: decode tiles [N/16][K/32][16][32] (each 16-row x 32-k MFMA operand tile
                         * is 1 KB contiguous, tiles of a row group follow each other along K): MFMA path only (M >= 2) */
   int32_t x_layout;    /* 0: x row-major [M][K]. 1: operand tiles [K/32][16][32] (tile t holds x[0..15][32t .. 32t+31], rows >= M
-                        * are padding with any finite content; 16 * K elements in all): MFMA path only */
+                        * are padding with ARBITRARY content (uninitialised is fine, NaN bit patterns included): an MFMA output column depends
+                        * only on its own operand column and columns >= M are never stored; 16 * K elements in all): MFMA path only */
   void* workspace;     /* optional, MFMA path: device scratch for split-K over workgroups (shapes whose N / 16 row groups do not
                         * fill the chip). Layout: 16 KB of arrival counters, then the partial sums. Must be ZERO when first used
                         * and is left with its counters at zero; bytes >= 16384 + 8 * 16 * N * 4 allows every split factor

@@ -61,8 +61,10 @@ __global__ __launch_bounds__(1024) void oneshot_kernel(const ArP p) {
   const float* in = p.data + lo;
   if (vec) for (int i = 2 * tid; i < cnt; i += 2 * T) st_sys2(mine + i, *(const float2*)(in + i));
   else     for (int i = tid; i < cnt; i += T) st_sys(mine + i, in[i]);
-  __syncthreads();
-  if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");        // system scope: the payload is visible before the flags
+  // every wave drains and releases its OWN staging stores at system scope before the barrier: a workgroup barrier alone does
+  // not wait for other waves' outstanding global stores, so a single-thread fence would let a peer see the flag first
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   // 2. signal every peer, 3. wait for every peer (threads 0 .. world-1, one peer each)
   if (tid < p.world) {
@@ -80,7 +82,7 @@ __global__ __launch_bounds__(1024) void oneshot_kernel(const ArP p) {
   if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
   __syncthreads();
   if (!s_ok) {                                                       // a peer never arrived: report, do not hang
-    if (tid == 0) { atomicExch(p.status, e ? e : 1u); p.epoch[b] = e; }
+    if (tid == 0) { atomicCAS(p.status, 0u, e ? e : 1u); p.epoch[b] = e; }   // sticky: the FIRST failed epoch stays recorded
     return;
   }
   // 4. reduce in rank order / gather
@@ -115,8 +117,13 @@ using namespace sxk_comm;
 
 extern "C" int sx_comm_alloc(void** ptr, uint64_t bytes) {
   SX_CHECK(ptr && bytes > 0, "sx_comm_alloc: bad arguments");
-  hipError_t e = hipMalloc(ptr, bytes);
-  SX_CHECK(e == hipSuccess, "sx_comm_alloc: hipMalloc(%llu) failed: %s", (unsigned long long)bytes, hipGetErrorString(e));
+  // Fine-grained, uncached device memory (MTYPE UC): these buffers are written by PEER GPUs over xGMI and polled / read by
+  // kernels that are already in flight. Ordinary hipMalloc memory is coarse-grained — coherent only at kernel boundaries — so a
+  // peer's flag store could sit behind a stale line of the local XCD's L2 no matter how the load is scoped. (Same choice as
+  // RCCL's and vLLM's custom-all-reduce signal buffers.)
+  hipError_t e = hipExtMallocWithFlags(ptr, bytes, hipDeviceMallocUncached);
+  if (e != hipSuccess) { (void)hipGetLastError(); e = hipExtMallocWithFlags(ptr, bytes, hipDeviceMallocFinegrained); }
+  SX_CHECK(e == hipSuccess, "sx_comm_alloc: hipExtMallocWithFlags(%llu, uncached | fine-grained) failed: %s", (unsigned long long)bytes, hipGetErrorString(e));
   e = hipMemset(*ptr, 0, bytes);
   SX_CHECK(e == hipSuccess, "sx_comm_alloc: hipMemset failed: %s", hipGetErrorString(e));
   return SX_OK;
@@ -163,7 +170,7 @@ extern "C" int sx_allreduce_oneshot(const sx_oneshot_args* a, void* stream) {
   p.n = a->n; p.cap = a->cap; p.rank = a->rank; p.world = a->world;
   p.chunk = a->chunk > 0 ? a->chunk : SX_ONESHOT_CHUNK;
   SX_CHECK((p.chunk & 1) == 0 && a->cap % p.chunk == 0, "sx_allreduce_oneshot: chunk %d must be even and divide the capacity %d", p.chunk, a->cap);
-  p.max_spin = a->max_spin ? a->max_spin : (1u << 22);
+  p.max_spin = a->max_spin ? a->max_spin : (1u << 24);     // ~16 s of polling: rank skew from lazy module loads is seconds
   hipLaunchKernelGGL(oneshot_kernel, dim3((a->n + p.chunk - 1) / p.chunk), dim3(1024), 0, (hipStream_t)stream, p);
   SX_HIP_LAUNCH_CHECK();
   return SX_OK;

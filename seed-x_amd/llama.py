@@ -9,7 +9,7 @@ logits, past_key_values, hidden_states with the LAST entry = post-final-norm sta
   * q/k/v and gate/up projections are fused GEMMs (weights concatenated / GLU-packed at load)
   * the 4 NaN/Inf guards (:702-713) and the per-layer ``attention_mask.sum()`` sync (:236) are dropped: prefill and
     multi-token chunks are causal (bottom-right aligned), q_len == 1 attends to the whole cache — same math
-  * logits are only produced for the last position (the greedy loop never reads the others)
+  * the generate loop only produces the last position's logits (``forward`` returns all positions like the reference)
   * ``max_batch`` > 1: G independent sequences (separate KV caches / positions) decode in lock step, so the 25.7 GB of
     weights are streamed from HBM once per step for all G tokens (the reference is batch 1 only, seed_x.py:191)
   * ``comm`` with world > 1: Megatron tensor parallelism (parallel.py) — this rank owns nh/tp heads (their q/k/v rows, KV
@@ -53,6 +53,25 @@ class _Embedding:
         return e.view(*input_ids.shape, -1)
 
 
+class CausalLMOutputWithPast(dict):
+    """Stand-in for transformers.modeling_outputs.CausalLMOutputWithPast (modeling_llama_xformer.py:740-746): fields by
+    attribute (``out.logits``), by key (``out["logits"]``) or by position over the non-None fields (``out[0]``)."""
+
+    def __getattr__(self, k):
+        try:
+            return dict.__getitem__(self, k)
+        except KeyError:
+            raise AttributeError(k) from None
+
+    def __getitem__(self, k):
+        if isinstance(k, (int, slice)):
+            return self.to_tuple()[k]
+        return dict.__getitem__(self, k)
+
+    def to_tuple(self):
+        return tuple(v for v in self.values() if v is not None)
+
+
 class LlamaForCausalLM:
     def __init__(self, config, max_cache_len=None, max_batch=1, comm=None):
         self.config = config if not isinstance(config, dict) else LlamaConfigLite(**config)
@@ -68,6 +87,7 @@ class LlamaForCausalLM:
         self.H_l = self.nh_l * self.hd
         self.Tmax = max_cache_len or c.max_position_embeddings
         self.G = int(max_batch)
+        assert 1 <= self.G <= 16, "lock-step batch is limited to 16 sequences (sx_gemv rows)"
         # Decode attention (tools/bench_decode_attention_ab.py, 16 sequences x 40 heads, ms per token of the graph-replayed step):
         # three launches (RoPE + append, split-KV attention, combine) with 8 / 2 / 1 KV splits 6.70 / 6.46 / 6.52; ONE launch
         # (sx_attn_decode_fused, bit-identical) with 8 splits 6.80 — its arrival-counter tail costs more than two graph
@@ -76,7 +96,6 @@ class LlamaForCausalLM:
         # Both from the GLOBAL head count: tensor-parallel ranks split exactly like one rank (bit-identical per head).
         self.fused_decode_attention = self.G * self.nh >= 512
         self.decode_nsplit = 1 if self.fused_decode_attention else min(8, max(1, -(-1024 // (self.G * self.nh))))
-        assert 1 <= self.G <= 16, "lock-step batch is limited to 16 sequences (sx_gemv rows)"
         self.device, self.dtype = None, torch.float16
         self._sd, self._P = None, None
         self._graph = None
@@ -147,6 +166,8 @@ class LlamaForCausalLM:
         if self.device is None or self.device.type != "cuda":
             raise RuntimeError("LlamaForCausalLM runs on the GPU only")
         sd, dev, dt = self._sd, self.device, self.dtype
+        if self.tp > 1:     # the captured decode step all-reduces [G, H] and all-gathers [G, Vpad/tp] fp32 (see _decode_step_body)
+            self.comm.require_capacity(self.G * max(self.H, self.V_l))
         f32 = lambda t: t.detach().to(dev, torch.float32).contiguous()
         w16 = lambda t: t.detach().to(dev, dt).contiguous()
         P = {"embed": w16(sd["model.embed_tokens.weight"]), "norm": f32(sd["model.norm.weight"]), "layers": []}
@@ -338,22 +359,56 @@ class LlamaForCausalLM:
         P["ctx"][seq] = pos + 1
 
     # reference-style entry (prefill + cached steps through inputs_embeds / input_ids), batch 1
-    def forward(self, input_ids=None, inputs_embeds=None, past_key_values=None, use_cache=True,
-                output_hidden_states=False, return_dict=True, **_):
-        """Subset of the reference forward (:643-746) that the inference path uses: batch 1 (sequence 0); the KV cache
-        lives in the module (``past_key_values=None`` resets it, anything else continues). Returns a dict with
-        ``logits`` [1, 1, V] (last position only), ``hidden_states`` = (final-norm states [1, T, H],) and
-        ``past_key_values`` = a token standing for the internal cache."""
-        self._pack()
+    def forward(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None, inputs_embeds=None,
+                labels=None, use_cache=True, output_attentions=None, output_hidden_states=None, return_dict=True,
+                logits_positions="all"):
+        """The reference forward's inference contract (modeling_llama_xformer.py:643-746), batch 1 (sequence 0).
+        Returns a ``CausalLMOutputWithPast`` (attribute / key / index access like transformers' ModelOutput) with
+          * ``logits`` [1, T, V] fp32 for EVERY position (:707; ``logits_positions="last"`` → [1, 1, V], what the greedy loop needs),
+          * ``past_key_values``: per layer (k, v) VIEWS [1, heads, T_total, hd] of the module's pre-allocated cache (:217-220 builds
+            them with torch.cat). Passing any non-None value back continues from the internal cache — its length must equal the
+            cache position; ``None`` starts a new sequence,
+          * ``hidden_states`` (if requested): a tuple of L + 1 entries like the reference's (:580-599) whose LAST entry is the
+            post-final-norm state [1, T, H]; the intermediate entries are None (never materialised; the path only reads [-1],
+            seed_x.py:98,196).
+        ``attention_mask`` is accepted and ignored exactly as far as the reference ignores it (padding is never honoured, :236;
+        prefill is causal, a q_len == 1 step sees the whole cache); ``position_ids`` must be the default arange (what
+        prepare_inputs_for_generation :759-765 produces for an all-ones mask). Training inputs (``labels``) are out of scope."""
+        if labels is not None:
+            raise NotImplementedError("LlamaForCausalLM.forward: the loss path (labels) is training-side and not built")
+        if output_attentions:
+            raise NotImplementedError("LlamaForCausalLM.forward: attention probabilities are never materialised (flash attention)")
+        P = self._pack()
         if past_key_values is None:
             self.reset(0)
+        else:
+            held = int(P["pos"][0].item())
+            if isinstance(past_key_values, (tuple, list)) and len(past_key_values) and isinstance(past_key_values[0], (tuple, list)):
+                got = int(past_key_values[0][0].shape[2])
+                assert got == held, f"past_key_values holds {got} tokens but the module's cache is at position {held}"
         if inputs_embeds is None:
             inputs_embeds = self.get_input_embeddings()(input_ids)
         x = inputs_embeds.reshape(-1, self.H)
-        logits, hn = self.forward_embeds(x, seq=0)
-        out = {"logits": logits[: self.V].view(1, 1, -1), "past_key_values": "internal-cache",
-               "hidden_states": (hn.view(1, -1, self.H),) if output_hidden_states else None}
-        return out
+        T = x.shape[0]
+        if position_ids is not None:
+            p0 = int(P["pos"][0].item())
+            want = torch.arange(p0, p0 + T)
+            assert torch.equal(position_ids.reshape(-1).cpu().long(), want), "only the default (arange) position_ids are supported"
+        if logits_positions == "last":
+            logits, hn = self.forward_embeds(x, seq=0)
+            logits = logits[: self.V].view(1, 1, -1)
+        else:
+            _, hn = self.forward_embeds(x, need_logits=False, seq=0)
+            logits = ops.linear(ops.cast(hn.contiguous(), self.dtype), P["lm_head"], out_dtype=torch.float32)   # [T, Vpad / tp]
+            if self.tp > 1:
+                logits = self.comm.all_gather(logits).permute(1, 0, 2).reshape(T, self.Vpad)
+            logits = logits[:, : self.V].unsqueeze(0)
+        Tk = int(P["pos"][0].item())
+        pkv = tuple((P["kc"][li][0][:, :Tk].unsqueeze(0), P["vc"][li][0][:, :Tk].unsqueeze(0)) for li in range(self.L)) \
+            if use_cache else None
+        hs = ((None,) * self.L + (hn.view(1, -1, self.H),)) if output_hidden_states else None
+        out = CausalLMOutputWithPast(loss=None, logits=logits, past_key_values=pkv, hidden_states=hs, attentions=None)
+        return out if return_dict else out.to_tuple()
 
     __call__ = forward
 

@@ -42,6 +42,13 @@ class Comm:
     def barrier(self):
         pass
 
+    def require_capacity(self, n_floats):
+        """Called by a model that will CAPTURE collectives of up to n_floats fp32 elements into a HIP graph: a communicator
+        that could not run such a payload inside a capture raises here, at load time, instead of failing mid-capture."""
+
+    def check(self):
+        """Raises if an earlier collective failed asynchronously (bounded poll expired). Host sync; no-op by default."""
+
 
 class _Done:
     def __init__(self, value):
@@ -166,10 +173,23 @@ class IpcComm(Comm):
     def _fits(self, t):
         return t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and 0 < t.numel() <= self.cap
 
+    def require_capacity(self, n_floats):
+        if self.graph_safe and n_floats > self.cap:
+            raise RuntimeError(f"IpcComm: a captured collective of {n_floats} floats does not fit the staging capacity {self.cap}; "
+                               f"construct it with cap_floats >= {n_floats}")
+
+    def _fallback_guard(self, t, what):
+        # the bootstrap-group path is a host-driven RCCL / gloo call: inside a HIP-graph capture it is either a capture error
+        # or work that silently is not part of the replayed graph
+        if t.is_cuda and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError(f"IpcComm.{what}: payload {tuple(t.shape)} {t.dtype} does not fit the one-shot kernel "
+                               f"(fp32, contiguous, <= {self.cap} elements) and the fallback cannot run under graph capture")
+
     def all_reduce(self, t):
         if self._fits(t):
             self._launch(t)
         else:                                  # large / non-fp32 payloads: the bootstrap group's ring
+            self._fallback_guard(t, "all_reduce")
             self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self.group)
         return t
 
@@ -186,16 +206,21 @@ class IpcComm(Comm):
                 t = t.clone()                    # a 16-bit view starting on an odd element: re-base it on a 4-byte boundary
             self._launch(t.view(-1).view(torch.float32), gather_out=out.view(-1).view(torch.float32))
         else:
+            self._fallback_guard(t, "all_gather")
             parts = [torch.empty_like(t) for _ in range(self.world)]
             self._dist.all_gather(parts, t, group=self.group)
             out = torch.stack(parts, dim=0)
         return out
 
     def check(self):
-        """Raises if a collective gave up waiting for a peer (host sync: call outside the hot loop)."""
+        """Raises if a collective gave up waiting for a peer: the kernel then returned WITHOUT reducing, so everything
+        computed since is wrong. The status word is sticky (first failed epoch) and the communicator stays failed — the
+        slot-reuse argument of csrc/comm.hip no longer holds after a missed epoch. One 4-byte read-back; the generate loop
+        calls it next to its per-token read-back."""
         st = int(self._status.item())
         if st:
-            raise RuntimeError(f"IpcComm rank {self.rank}: a peer did not arrive in epoch {st} (bounded poll expired)")
+            raise RuntimeError(f"IpcComm rank {self.rank}: a peer did not arrive in epoch {st} (bounded poll expired); "
+                               f"results since then are invalid and this communicator must be rebuilt")
 
     def barrier(self):
         self._dist.barrier(group=self.group)

@@ -187,6 +187,7 @@ class ContinuousLVLM:
         ops.add_i32(P["step"], 1)
         n_new = [1] * G
         cur = P["cur"].tolist()
+        llm.comm.check()
 
         def force(g):
             # synthetic-weights benchmarking only: random-init weights never emit <img>, so the transcript is pinned by
@@ -227,6 +228,7 @@ class ContinuousLVLM:
                 break
             llm.decode_step(img_ids_dev, out_ids, hid, use_graph=self.use_graph)            # one token for every sequence
             cur = P["cur"].tolist()                                                          # the only read-back per step
+            llm.comm.check()                              # (tensor-parallel only: + 4 bytes) a timed-out collective must not pass
             for g in range(G):
                 if done[g]:
                     continue

@@ -157,7 +157,7 @@ def test_vit_b20_and_long_prefill(dev):
     llm.load_state_dict(lsd)
     llm.eval().to(dev, dt)
     out = llm(inputs_embeds=xe.to(dev), output_hidden_states=True)
-    e_l, e_h = relerr(out["logits"][0, 0], lref[0, -1]), relerr(out["hidden_states"][-1], href)
+    e_l, e_h = relerr(out["logits"][0, -1], lref[0, -1]), relerr(out["hidden_states"][-1], href)
     _verdict("Llama-13B dims, 1536-token prefill, fp16: last-position logits", e_l, 1e-3)
     _verdict("Llama-13B dims, 1536-token prefill, fp16: final-norm states", e_h, 1e-3)
     assert e_l < 1e-3 and e_h < 1e-3

@@ -94,11 +94,11 @@ def run(c, use_graph):
     out = llm(inputs_embeds=xe.to(dev), output_hidden_states=True)
     ids = torch.full((1, 8), -1, dtype=torch.int32, device=dev)
     hid = torch.zeros((1, 8, cfg["hidden_size"]), device=dev)
-    llm._P["cur"].fill_(int(out["logits"][0, 0].argmax()))
+    llm._P["cur"].fill_(int(out["logits"][0, -1].argmax()))
     for _ in range(5):
         llm.decode_step(img_ids, ids, hid, use_graph=use_graph)
     torch.cuda.synchronize()
-    return out["logits"][0, 0].float().cpu(), ids.cpu(), llm
+    return out["logits"][0, -1].float().cpu(), ids.cpu(), llm
 
 single_logits, single_ids, _ = run(Comm(), True)
 dist.barrier()

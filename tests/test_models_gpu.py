@@ -154,7 +154,7 @@ def test_llm_prefill_logits_vs_oracle(dev, dtype):
     llm.load_state_dict(sd)
     llm.eval().to(dev, dtype=dtype)
     out = llm(inputs_embeds=x.to(dev), output_hidden_states=True)
-    e_l = relerr(out["logits"][0, 0], logits_ref[0, -1])
+    e_l = relerr(out["logits"][0, -1], logits_ref[0, -1])
     e_h = relerr(out["hidden_states"][-1], hn_ref)
     print(f"llm prefill {dtype} logits relerr {e_l:.3e} hidden relerr {e_h:.3e}")
     assert e_l < TOL[dtype] and e_h < TOL[dtype]

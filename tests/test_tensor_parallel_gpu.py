@@ -36,11 +36,11 @@ def test_llama_tp_prefill_and_decode(dev, tp):
         out = llm(inputs_embeds=xe.to(dev), output_hidden_states=True)
         ids = torch.full((1, 8), -1, dtype=torch.int32, device=dev)
         hid = torch.zeros((1, 8, cfg["hidden_size"]), device=dev)
-        llm._P["cur"].fill_(int(out["logits"][0, 0].argmax()))
+        llm._P["cur"].fill_(int(out["logits"][0, -1].argmax()))
         for _ in range(4):
             llm.decode_step(img_ids, ids, hid)
         torch.cuda.synchronize()
-        return out["logits"][0, 0].float().cpu(), out["hidden_states"][0][0].float().cpu(), ids.cpu(), hid.cpu()
+        return out["logits"][0, -1].float().cpu(), out["hidden_states"][-1][0].float().cpu(), ids.cpu(), hid.cpu()
 
     from seedx_amd.parallel import Comm
     single = run(Comm())
