@@ -177,6 +177,45 @@ def llama_forward(sd, cfg, inputs_embeds, past=None, table_dtype=None):
     return logits, new_past, hn
 
 
+def llama_forward_16bit_like_reference(sd, cfg, inputs_embeds, dtype):
+    """What the REFERENCE computes when its scripts run the module in 16 bit (`.to(device, dtype=torch.float16)`,
+    eval_img2text_seed_x_i.py:60-62,91-92), restated with the reference's dtype flow — the yardstick for "how far is 16-bit
+    inference from the fp32 oracle at full depth": weights AND the residual stream in `dtype`; nn.Linear = 16-bit operands with
+    fp32 accumulation, result rounded to `dtype`; LlamaRMSNorm [ext 4.30.2] = fp32 variance, x·rsqrt rounded to `dtype`, then ·weight;
+    RoPE tables cast to `dtype` (:128-131) and applied in `dtype` (:141-149); attention = xformers memory_efficient_attention [ext]
+    (fp32 scores / softmax / accumulation inside the kernel, output in `dtype`). Prefill only (no cache). Same shapes as llama_forward."""
+    H, nh, L = cfg["hidden_size"], cfg["num_attention_heads"], cfg["num_hidden_layers"]
+    hd, eps = H // nh, cfg["rms_norm_eps"]
+    w = lambda k: sd[k].to(dtype)
+
+    def norm(x, k):
+        xf = x.float()
+        return w(k) * (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps)).to(dtype)
+    x = inputs_embeds.to(dtype)
+    T = x.shape[1]
+    cos, sin = rope_tables(hd, T)
+    cos, sin = cos.to(dtype)[None, None].to(x.device), sin.to(dtype)[None, None].to(x.device)
+    ii = torch.arange(T, device=x.device)
+    causal = ii[None, :] > ii[:, None]
+    for i in range(L):
+        p = f"model.layers.{i}."
+        h = norm(x, p + "input_layernorm.weight")
+        q = F.linear(h, w(p + "self_attn.q_proj.weight")).view(1, T, nh, hd).transpose(1, 2)
+        k = F.linear(h, w(p + "self_attn.k_proj.weight")).view(1, T, nh, hd).transpose(1, 2)
+        v = F.linear(h, w(p + "self_attn.v_proj.weight")).view(1, T, nh, hd).transpose(1, 2)
+        q = q * cos + rotate_half(q) * sin
+        k = k * cos + rotate_half(k) * sin
+        sc = (q.float() @ k.float().transpose(-1, -2)) / math.sqrt(hd)
+        pr = torch.softmax(sc.masked_fill(causal, float("-inf")), dim=-1)
+        o = (pr @ v.float()).to(dtype).transpose(1, 2).reshape(1, T, H)
+        x = x + F.linear(o, w(p + "self_attn.o_proj.weight"))
+        h = norm(x, p + "post_attention_layernorm.weight")
+        g = F.silu(F.linear(h, w(p + "mlp.gate_proj.weight"))) * F.linear(h, w(p + "mlp.up_proj.weight"))
+        x = x + F.linear(g, w(p + "mlp.down_proj.weight"))
+    hn = norm(x, "model.norm.weight")
+    return F.linear(hn, w("lm_head.weight")), hn
+
+
 def logits_rule(last_id, scores, img_ids):
     """AutoImageTokenGenerationProcessor.__call__ (generation.py:19-31) for batch 1; scores [V] modified in place."""
     if last_id in img_ids[:-1]:

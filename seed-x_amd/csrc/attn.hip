@@ -35,11 +35,25 @@ struct AttnP {
   float scale_log2;
 };
 
-template <typename TT, int DP, bool ALT = true>
-__global__ __launch_bounds__(256, (DP <= 64 ? 4 : 1)) void attn_kernel(const AttnP p) {  // D=64: 4 waves per SIMD (<= 128 VGPRs)
+// OPT (bit mask, A/B-able through sx_attention_variant(16 + OPT); 0 = round-3 kernel):
+//   1  s_setprio 1 around the two MFMA clusters of a tile: with 3-4 workgroups per CU every SIMD holds waves of different workgroups in
+//      different phases; the arbiter is age-first, so an older wave grinding through its ~130 softmax VALU issues starves a younger
+//      wave's MFMA cluster and the matrix pipe idles (MI355X_MICROARCH.md §Two waves per SIMD item 2; cdna_hip_programming.md T5)
+//   2  lane^32 exchange of the row maximum by v_permlane32_swap (VALU) instead of ds_bpermute (LDS queue, behind the fragment reads)
+//   4  row sums from the matrix pipe: one extra 32x32x16 MFMA per 16 keys with an all-ones A operand (every output row = the sum
+//      over all 16 keys of both lane halves) instead of 16 v_dot2 per tile; the sum is over the same ROUNDED probabilities
+//   8  software pipeline over KV tiles (cdna_hip_programming.md T15): S(t+1) = K(t+1)·Qᵀ is issued BEFORE the softmax of tile t, so
+//      one wave's instruction stream carries independent MFMAs next to its VALU-bound softmax; K tiles are staged one tile ahead
+//      of V tiles (same two 16-KB buffers). Costs 32 more live VGPRs → 3 workgroups per CU instead of 4 (measured neutral in round 3)
+//  16  (with 8) the S(t+1) MFMAs sit INSIDE the softmax's basic block, spread between its VALU instructions by
+//      sched_group_barrier (one MFMA per ~12 VALU / transcendental issues): an in-order wave only overlaps its own matrix and vector
+//      work when the two are interleaved in program order; as a leading cluster (8 alone) the 8 MFMAs stall issue for 8 x 32 cycles
+template <typename TT, int DP, int OPT = 0>
+__global__ __launch_bounds__(256, (DP <= 64 ? ((OPT & 24) ? 3 : 4) : 1)) void attn_kernel(const AttnP p) {  // D=64: 4 waves per SIMD (<= 128 VGPRs)
 #if defined(__HIP_DEVICE_COMPILE__)  // body uses gfx950-only builtins (LDS-DMA, MFMA); the host pass only needs the stub
   typedef typename TT::vec8 vec8;
   typedef typename TT::vec4 vec4;
+  constexpr bool PRIO = (OPT & 1) != 0, SWAP = (OPT & 2) != 0, ONES = (OPT & 4) != 0, PIPE = (OPT & 24) != 0, ILV = (OPT & 16) != 0;
   constexpr int KROW = DP * 2;                 // bytes per K row in LDS (128 | 256)
   constexpr int K_BYTES = 64 * KROW;           // K tile
   constexpr int V_BYTES = K_BYTES;             // V tile: 64 keys x DP, row-major like K
@@ -107,9 +121,8 @@ __global__ __launch_bounds__(256, (DP <= 64 ? 4 : 1)) void attn_kernel(const Att
     v_off[i] = (c * 8 < p.D) ? (unsigned)(c * 16) : 0x80000000u;
   }
 
-  auto stage = [&](int buf, int kvt) {
+  auto stage_k = [&](int buf, int kvt) {
     unsigned char* sK = smem + buf * STAGE;
-    unsigned char* sV = sK + K_BYTES;
     const int kv0 = kvt * 64;
 #pragma unroll
     for (int i = 0; i < K_SLOTS / 4; ++i) {
@@ -118,6 +131,10 @@ __global__ __launch_bounds__(256, (DP <= 64 ? 4 : 1)) void attn_kernel(const Att
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rK, SX_LDS_PTR(sK + (wave * (K_SLOTS / 4) + i) * 1024), 16, voff, 0,
                                                0, 0);
     }
+  };
+  auto stage_v = [&](int buf, int kvt) {
+    unsigned char* sV = smem + buf * STAGE + K_BYTES;
+    const int kv0 = kvt * 64;
 #pragma unroll
     for (int i = 0; i < V_SLOTS / 4; ++i) {
       const int kv = kv0 + v_row[i];                 // rows past Skv are fetched as zeros (0 · P, never NaN)
@@ -163,42 +180,38 @@ __global__ __launch_bounds__(256, (DP <= 64 ? 4 : 1)) void attn_kernel(const Att
 #pragma unroll
   for (int dt = 0; dt < NDT; ++dt) v_col[dt] = (unsigned)(((4 * dt + 2 * (vg & 1) + ((vR & 3) >> 1)) ^ v_key) << 4);
 
-  if (nt > 0) stage(0, 0);
-  __syncthreads();
-  // one KV tile; `cur` is a literal at both call sites, so every LDS offset folds into the ds_read immediates
-  auto tile = [&](const int cur, const int kvt) {
-    if (kvt + 1 < nt) stage(cur ^ 1, kvt + 1);
-    const unsigned char* sK = smem + cur * STAGE;
-    const unsigned char* sV = sK + K_BYTES;
-    const int kv0 = kvt * 64;
+  // all-ones A operand of the row-sum MFMA (OPT 4): 8 x 1.0 in the operand type
+  vec8 ones8;
+  {
+    const unsigned one2 = pack2<TT>(1.0f, 1.0f);
+    const u32x4_t o4 = {one2, one2, one2, one2};
+    __builtin_memcpy(&ones8, &o4, 16);
+  }
 
-    // ---- S^T = K · Q^T ---------------------------------------------------------------------------
-    f32x16_t s[2];
-    if (!ALT) {   // round-2 order, kept for A/B (sx_attention_variant(1))
+  // ---- S^T = K · Q^T of the K tile in buffer `buf` (a literal at every call site: offsets fold into the ds_read immediates).
+  // The two key blocks accumulate alternately: no MFMA issues directly behind the one it depends on
+  auto compute_s = [&](const int buf, f32x16_t (&s)[2]) {
+    const unsigned char* sK = smem + buf * STAGE;
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[jb][r] = 0.f;
+    if (PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
       for (int jb = 0; jb < 2; ++jb) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[jb][r] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) {
-          const vec8 kf = *(const vec8*)(sK + jb * 32 * KROW + k_rd + (((2 * ks + hi) ^ kkey) << 4));
-          s[jb] = TT::mfma32(kf, qf[ks], s[jb]);
-        }
+        const vec8 kf = *(const vec8*)(sK + jb * 32 * KROW + k_rd + (((2 * ks + hi) ^ kkey) << 4));
+        s[jb] = TT::mfma32(kf, qf[ks], s[jb]);
       }
-    } else {   // the two key blocks accumulate alternately: no MFMA issues directly behind the one it depends on (+1 %)
-#pragma unroll
-      for (int jb = 0; jb < 2; ++jb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[jb][r] = 0.f;
-#pragma unroll
-      for (int ks = 0; ks < NKS; ++ks)
-#pragma unroll
-        for (int jb = 0; jb < 2; ++jb) {
-          const vec8 kf = *(const vec8*)(sK + jb * 32 * KROW + k_rd + (((2 * ks + hi) ^ kkey) << 4));
-          s[jb] = TT::mfma32(kf, qf[ks], s[jb]);
-        }
-    }
-    // ---- online softmax (log2 domain), lane owns query row qrow ------------------------------------
+    if (PRIO) __builtin_amdgcn_s_setprio(0);
+  };
+
+  // ---- online softmax of tile kvt (scores s) + O^T += V^T · P^T from the V tile in buffer `buf` ------------------------
+  // (ILV: also S(t+1) of the K tile in buffer buf ^ 1 into sn, issued between the softmax's own instructions)
+  auto softmax_pv = [&](const int buf, const int kvt, f32x16_t (&s)[2], f32x16_t (&sn)[2]) {
+    const unsigned char* sV = smem + buf * STAGE + K_BYTES;
+    const int kv0 = kvt * 64;
     // raw scores stay unscaled: p = exp2(s*c - m*c) is ONE fma + v_exp per element; masking only on edge tiles
     const float c = p.scale_log2;
     if (p.causal || kv0 + 64 > p.Skv) {  // wave-uniform: interior tiles skip the mask entirely
@@ -219,7 +232,16 @@ __global__ __launch_bounds__(256, (DP <= 64 ? 4 : 1)) void attn_kernel(const Att
       mloc = max3f(mloc, s[0][r], s[1][r]);
       mloc2 = max3f(mloc2, s[0][r + 1], s[1][r + 1]);
     }
-    mloc = max3f(mloc, mloc2, __shfl_xor(fmaxf(mloc, mloc2), 32, 64));
+    if (SWAP) {
+      // v_permlane32_swap vdst, src: lanes 32-63 of vdst <-> lanes 0-31 of src. With both = x: a = {x.lo, x.lo}, b = {x.hi, x.hi}.
+      // (inline asm: hipcc 7.2 drops the builtin's second result; the s_nops cover the VALU-write → permlane-read wait states the
+      // compiler cannot see into)
+      float xa = fmaxf(mloc, mloc2), xb = xa;
+      asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(xa), "+v"(xb));
+      mloc = fmaxf(xa, xb);
+    } else {
+      mloc = max3f(mloc, mloc2, __shfl_xor(fmaxf(mloc, mloc2), 32, 64));
+    }
     const float m_new = fmaxf(m_run, mloc);
     const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
     const float alpha = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f((m_run - m_safe) * c);
@@ -227,6 +249,22 @@ __global__ __launch_bounds__(256, (DP <= 64 ? 4 : 1)) void attn_kernel(const Att
     const float mc = -m_safe * c;
     float psum = 0.f;
     vec8 pb[4];
+    // one softmax chunk = 4 scores → words 2*half, 2*half + 1 of pb[kk] (kk = 2jb + s2): 2 v_pk_fma, 4 v_exp, 2 cvt_pk, 2 dot2
+    unsigned pw[4][4];
+    auto chunk = [&](const int kk, const int half) {
+      const int jb = kk >> 1, s2 = kk & 1;
+#pragma unroll
+      for (int j = 2 * half; j < 2 * half + 2; ++j) {
+        typedef float f2_t __attribute__((ext_vector_type(2)));
+        const f2_t sv = {s[jb][8 * s2 + 2 * j], s[jb][8 * s2 + 2 * j + 1]};
+        const f2_t e = __builtin_elementwise_fma(sv, (f2_t){c, c}, (f2_t){mc, mc});
+        const float p0 = __builtin_amdgcn_exp2f(e[0]);
+        const float p1 = __builtin_amdgcn_exp2f(e[1]);
+        pw[kk][j] = pack2<TT>(p0, p1);
+        psum = TT::pair_sum(pw[kk][j], psum);
+      }
+    };
+    if (!ILV)
 #pragma unroll
     for (int jb = 0; jb < 2; ++jb)
 #pragma unroll
@@ -242,11 +280,11 @@ __global__ __launch_bounds__(256, (DP <= 64 ? 4 : 1)) void attn_kernel(const Att
           const float p0 = __builtin_amdgcn_exp2f(e[0]);
           const float p1 = __builtin_amdgcn_exp2f(e[1]);
           w[j] = pack2<TT>(p0, p1);
-          psum = TT::pair_sum(w[j], psum);          // sums the ROUNDED probabilities, i.e. exactly what P·V multiplies
+          if (!ONES) psum = TT::pair_sum(w[j], psum);          // sums the ROUNDED probabilities, i.e. exactly what P·V multiplies
         }
         __builtin_memcpy(&pb[2 * jb + s2], w, 16);
       }
-    l_run = l_run * alpha + psum;
+    if (!ONES && !ILV) l_run = l_run * alpha + psum;
     if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {  // wave-uniform: the running max rarely moves after the first tiles
 #pragma unroll
       for (int i = 0; i < NDT; ++i)
@@ -254,45 +292,121 @@ __global__ __launch_bounds__(256, (DP <= 64 ? 4 : 1)) void attn_kernel(const Att
         for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
     }
 
-    // ---- O^T += V^T · P^T ---------------------------------------------------------------------------
-    if (!ALT) {
+    if (ILV) {
+      // One basic block (it follows the rare O-rescale branch), issue order fixed by hand with sched_barrier fences:
+      //   c0 S0 c1 S1 c2 S2 P0 c3 S3 P1 c4 S4 P2 c5 S5 P3 c6 S6 P4 c7 S7 P5 P6 P7
+      // c = softmax chunk (4 scores: ~6 VALU + 4 v_exp ≈ 90 issue cycles), S = one MFMA of S(t+1) = K(t+1)·Qᵀ (unconditional: past
+      // the last tile the buffer holds stale keys and the scores are never used), P = one MFMA of O += Vᵀ·Pᵀ, P(2kk + dt) as soon
+      // as chunks 2kk, 2kk + 1 have produced pb[kk]. Every MFMA (32 matrix-pipe cycles) sits behind ≥ 1 chunk of independent VALU work, so
+      // an in-order wave keeps its matrix pipe and its VALU busy at the same time; operand fragments are read from LDS one
+      // step ahead. Same per-accumulator MFMA order as the round-3 kernel → bit-identical output.
+      const unsigned char* sKn = smem + (buf ^ 1) * STAGE;
+      auto read_k = [&](const int i) -> vec8 {          // i = 2ks + jb
+        return *(const vec8*)(sKn + (i & 1) * 32 * KROW + k_rd + (((2 * (i >> 1) + hi) ^ kkey) << 4));
+      };
+      auto read_v = [&](const int pi) -> vec8 {         // pi = 2kk + dt (NDT == 2)
+        const unsigned char* vp = sV + v_rd + v_col[pi & 1] + (pi >> 1) * 16 * KROW;
+        const tr4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr4_t*)SX_LDS_PTR(vp));
+        const tr4_t hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr4_t*)SX_LDS_PTR(vp + 4 * KROW));
+        vec8 vf;
+        __builtin_memcpy(&vf, &lo, 8);
+        __builtin_memcpy((char*)&vf + 8, &hi4, 8);
+        return vf;
+      };
+#pragma unroll
+      for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sn[jb][r] = 0.f;
+      vec8 kfn = read_k(0), vfn;
+      if (PRIO) __builtin_amdgcn_s_setprio(1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int cc = 0; cc < 8; ++cc) {
+        chunk(cc >> 1, cc & 1);
+        if (cc & 1) __builtin_memcpy(&pb[cc >> 1], pw[cc >> 1], 16);
+        __builtin_amdgcn_sched_barrier(0);
+        sn[cc & 1] = TT::mfma32(kfn, qf[cc >> 1], sn[cc & 1]);
+        if (cc + 1 < 8) kfn = read_k(cc + 1);
+        if (cc >= 2) o[(cc - 2) & 1] = TT::mfma32(vfn, pb[(cc - 2) >> 1], o[(cc - 2) & 1]);
+        if (cc >= 1) vfn = read_v(cc - 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      o[0] = TT::mfma32(vfn, pb[3], o[0]);
+      vfn = read_v(7);
+      o[1] = TT::mfma32(vfn, pb[3], o[1]);
+      if (PRIO) __builtin_amdgcn_s_setprio(0);
+      l_run = l_run * alpha + psum;
+      return;
+    }
+    // ---- O^T += V^T · P^T (kk = 2jb + s2 : 16 keys; kk outer, d-tile inner: accumulators alternate) --------------------
+    f32x16_t ls;
+    if (PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      if (ONES) {
+        if (kk == 0) {
+          f32x16_t z;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) z[r] = 0.f;
+          ls = TT::mfma32(ones8, pb[0], z);
+        } else {
+          ls = TT::mfma32(ones8, pb[kk], ls);
+        }
+      }
 #pragma unroll
       for (int dt = 0; dt < NDT; ++dt) {
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {  // kk = 2jb + s2 : 16 keys
-          const unsigned char* vp = sV + v_rd + v_col[dt] + kk * 16 * KROW;
-          const tr4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr4_t*)SX_LDS_PTR(vp));
-          const tr4_t hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr4_t*)SX_LDS_PTR(vp + 4 * KROW));
-          vec8 vf;
-          __builtin_memcpy(&vf, &lo, 8);
-          __builtin_memcpy((char*)&vf + 8, &hi4, 8);
-          o[dt] = TT::mfma32(vf, pb[kk], o[dt]);
-        }
-      }
-    } else {
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-#pragma unroll
-        for (int dt = 0; dt < NDT; ++dt) {
-          const unsigned char* vp = sV + v_rd + v_col[dt] + kk * 16 * KROW;
-          const tr4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr4_t*)SX_LDS_PTR(vp));
-          const tr4_t hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr4_t*)SX_LDS_PTR(vp + 4 * KROW));
-          vec8 vf;
-          __builtin_memcpy(&vf, &lo, 8);
-          __builtin_memcpy((char*)&vf + 8, &hi4, 8);
-          o[dt] = TT::mfma32(vf, pb[kk], o[dt]);
-        }
+        const unsigned char* vp = sV + v_rd + v_col[dt] + kk * 16 * KROW;
+        const tr4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr4_t*)SX_LDS_PTR(vp));
+        const tr4_t hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr4_t*)SX_LDS_PTR(vp + 4 * KROW));
+        vec8 vf;
+        __builtin_memcpy(&vf, &lo, 8);
+        __builtin_memcpy((char*)&vf + 8, &hi4, 8);
+        o[dt] = TT::mfma32(vf, pb[kk], o[dt]);
       }
     }
-    __syncthreads();
+    if (PRIO) __builtin_amdgcn_s_setprio(0);
+    if (ONES) l_run = l_run * alpha + ls[0];       // every row of the ones-product is the full 64-key row sum (both lane halves)
   };
-  for (int kvt = 0; kvt < nt; kvt += 2) {
-    tile(0, kvt);
-    if (kvt + 1 < nt) tile(1, kvt + 1);
+
+  f32x16_t sA[2], sB[2];
+  if (!PIPE) {
+    if (nt > 0) { stage_k(0, 0); stage_v(0, 0); }
+    __syncthreads();
+    // one KV tile; `cur` is a literal at both call sites
+    auto tile = [&](const int cur, const int kvt) {
+      if (kvt + 1 < nt) { stage_k(cur ^ 1, kvt + 1); stage_v(cur ^ 1, kvt + 1); }
+      compute_s(cur, sA);
+      softmax_pv(cur, kvt, sA, sB);
+      __syncthreads();
+    };
+    for (int kvt = 0; kvt < nt; kvt += 2) {
+      tile(0, kvt);
+      if (kvt + 1 < nt) tile(1, kvt + 1);
+    }
+  } else {
+    // K(t) lives in buffer t & 1 like V(t), but is staged one tile earlier: at tile t the DMA of K(t+2) and V(t+1) is issued, S(t+1)
+    // is computed from K(t+1) (staged during tile t-1, complete since that tile's barrier) and the softmax + P·V of tile t run on
+    // the scores computed one tile ago. A buffer's K half is overwritten one barrier after its last read (S(t) ran during tile
+    // t-1), its V half likewise (P·V(t-1) ran during tile t-1).
+    if (nt > 0) { stage_k(0, 0); stage_v(0, 0); }
+    if (nt > 1) stage_k(1, 1);
+    __syncthreads();
+    if (nt > 0) compute_s(0, sA);
+    for (int kvt = 0; kvt < nt; kvt += 2) {
+      if (kvt + 2 < nt) stage_k(0, kvt + 2);
+      if (kvt + 1 < nt) { stage_v(1, kvt + 1); if (!ILV) compute_s(1, sB); }
+      softmax_pv(0, kvt, sA, sB);
+      __syncthreads();
+      if (kvt + 1 >= nt) break;
+      if (kvt + 3 < nt) stage_k(1, kvt + 3);
+      if (kvt + 2 < nt) { stage_v(0, kvt + 2); if (!ILV) compute_s(0, sA); }
+      softmax_pv(1, kvt + 1, sB, sA);
+      __syncthreads();
+    }
   }
 
   // ---- epilogue: O[q][d] = o / l ------------------------------------------------------------------------
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float l_tot = ONES ? l_run : l_run + __shfl_xor(l_run, 32, 64);
   const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
   if (qrow < p.Sq) {
     unsigned short* Or = p.O + b * p.obs + (long long)qrow * p.ors + (long long)h * p.D;
@@ -382,7 +496,10 @@ __global__ __launch_bounds__(256) void attn_small_kernel(const AttnSmallP p) {
 }  // namespace sxk_attn
 using namespace sxk_attn;
 
-static int g_attn_variant = 0;   // tuning hook (tools/lab/attn_lab): 0 = shipped kernel
+#ifndef SX_ATTN_OPT_D64
+#define SX_ATTN_OPT_D64 0      // OPT bits of the shipped head_dim-64 kernel (see attn_kernel)
+#endif
+static int g_attn_variant = 0;   // tuning hook (tools/lab/attn_lab): 0 = shipped kernel; 16 + OPT = the head_dim-64 kernel with those OPT bits
 extern "C" int sx_attention_variant(int v) { g_attn_variant = v; return SX_OK; }
 
 extern "C" int sx_attention(const sx_attn_args* a, void* stream) {
@@ -413,16 +530,24 @@ extern "C" int sx_attention(const sx_attn_args* a, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   const int dp = a->D <= 64 ? 64 : 128;
   const size_t lds = 2 * (size_t)(2 * 64 * dp * 2);     // 2 stages x (K tile + V tile)
-  if (g_attn_variant == 1 && dp == 64 && a->dtype == SX_BF16) {   // A/B: round-2 MFMA order (each accumulator's four MFMAs back to back)
-    hipLaunchKernelGGL((attn_kernel<BF16, 64, false>), dim3(grid), dim3(256), lds, st, p);
+  if (g_attn_variant >= 16 && g_attn_variant < 48 && dp == 64) {   // A/B: OPT bits of attn_kernel (tools/lab/attn_lab)
+    const bool bf = a->dtype == SX_BF16;
+#define ATTN_OPT_CASE(O) case O: if (bf) hipLaunchKernelGGL((attn_kernel<BF16, 64, O>), dim3(grid), dim3(256), lds, st, p); \
+                                 else hipLaunchKernelGGL((attn_kernel<F16, 64, O>), dim3(grid), dim3(256), lds, st, p); break;
+    switch (g_attn_variant - 16) {
+      ATTN_OPT_CASE(1) ATTN_OPT_CASE(2) ATTN_OPT_CASE(3) ATTN_OPT_CASE(4) ATTN_OPT_CASE(7) ATTN_OPT_CASE(8) ATTN_OPT_CASE(9)
+      ATTN_OPT_CASE(10) ATTN_OPT_CASE(11) ATTN_OPT_CASE(16) ATTN_OPT_CASE(17) ATTN_OPT_CASE(18) ATTN_OPT_CASE(19)
+      default: SX_CHECK(false, "sx_attention: variant %d not built", g_attn_variant);
+    }
+#undef ATTN_OPT_CASE
     SX_HIP_LAUNCH_CHECK();
     return SX_OK;
   }
   if (a->dtype == SX_BF16) {
-    if (dp == 64) hipLaunchKernelGGL((attn_kernel<BF16, 64>), dim3(grid), dim3(256), lds, st, p);
+    if (dp == 64) hipLaunchKernelGGL((attn_kernel<BF16, 64, SX_ATTN_OPT_D64>), dim3(grid), dim3(256), lds, st, p);
     else hipLaunchKernelGGL((attn_kernel<BF16, 128>), dim3(grid), dim3(256), lds, st, p);
   } else {
-    if (dp == 64) hipLaunchKernelGGL((attn_kernel<F16, 64>), dim3(grid), dim3(256), lds, st, p);
+    if (dp == 64) hipLaunchKernelGGL((attn_kernel<F16, 64, SX_ATTN_OPT_D64>), dim3(grid), dim3(256), lds, st, p);
     else hipLaunchKernelGGL((attn_kernel<F16, 128>), dim3(grid), dim3(256), lds, st, p);
   }
   SX_HIP_LAUNCH_CHECK();
