@@ -420,7 +420,7 @@ def measure_roofline(w):
     Returns (roofline of the dominant kernel family, per-phase dict)."""
     from seedx_amd import _lib, ops
     lib = _lib.load()
-    real = {n: getattr(lib, n) for n in ("sx_gemm", "sx_gemv", "sx_attention", "sx_attn_decode_b", "sx_attn_decode_fused")}
+    real = {n: getattr(lib, n) for n in ("sx_gemm", "sx_gemm_gn", "sx_gemv", "sx_attention", "sx_attn_decode_b", "sx_attn_decode_fused")}
     rec = []                       # (family, phase, flops, bytes, start, end)
     executed = {}                  # phase -> MFMA FLOPs actually issued (plane-carrying launches counted with their tripled K)
     stack = ["other"]
@@ -434,14 +434,17 @@ def measure_roofline(w):
         rec.append((fam, stack[-1], fl, byt, s, e))
         return r
 
-    def h_gemm(args_ref, stream):
+    def h_gemm(args_ref, *rest):
+        # sx_gemm(args, stream) | sx_gemm_gn(args, stats, groups, rows, fused, stream): the same launch, with the next GroupNorm's
+        # statistics accumulated in its epilogue
+        fn = real["sx_gemm"] if len(rest) == 1 else real["sx_gemm_gn"]
         a = args_ref._obj
         n_out = a.N // 2 if a.glu else a.N
         n_st = a.n_valid if a.n_valid else n_out
         a_bytes = 2.0 * (a.B * a.Hin * a.Win * a.Cin if a.a_mode == 1 else a.M * a.K)   # operands once + output once
         byt = a_bytes + 2.0 * a.N * a.K + a.M * n_st * (4.0 if a.out_dtype == 2 else 2.0) + (4.0 * a.M * n_st if a.residual else 0.0)
         executed[stack[-1]] = executed.get(stack[-1], 0.0) + 2.0 * a.M * a.N * a.K
-        return timed("gemm", 2.0 * a.M * a.N * a.K / ops.OPERAND_PLANES, byt, real["sx_gemm"], args_ref, stream)
+        return timed("gemm", 2.0 * a.M * a.N * a.K / ops.OPERAND_PLANES, byt, fn, args_ref, *rest)
 
     def h_gemv(args_ref, stream):
         a = args_ref._obj
@@ -503,7 +506,7 @@ def measure_roofline(w):
         if loop is not None:
             patched.append(phase_wrap(loop, "run", "unet"))
             patched.append(phase_wrap(w.adapter, "_finish", "vae"))
-        lib.sx_gemm, lib.sx_gemv, lib.sx_attention = h_gemm, h_gemv, h_attn
+        lib.sx_gemm, lib.sx_gemm_gn, lib.sx_gemv, lib.sx_attention = h_gemm, h_gemm, h_gemv, h_attn
         if agent is not None:
             lib.sx_attn_decode_b = h_attn_decode
             lib.sx_attn_decode_fused = h_attn_decode_fused
@@ -601,21 +604,27 @@ def measure_roofline(w):
     fl, tot_s, n, alg_bytes = g["flop"], g["s"], g["n"], g["bytes"]
     # traffic: bytes per launch from rocprofv3 --pmc passes of THIS command (tools/bench_pmc_traffic.py; eager launches).
     # Only quoted when the stored profile was taken with the GEMM sources as they are now, at this batch size / config.
-    traffic, tnote = None, "no PMC profile taken with the current GEMM kernels at this batch size / config"
-    for name in ("r3_bench_pmc_traffic.json", "r3_unet_pmc_traffic.json"):
+    traffic, tnote, tscope = None, "no PMC profile taken with the current GEMM kernels at this batch size / dtype / config", None
+    for name in ("r4_unet_pmc_traffic.json",):
         try:
             prof = json.load(open(os.path.join(ROOT, "profiles", name)))
-            if prof.get("batch_per_gpu") == BATCH and w.a.config == 0 and prof.get("kernel_source_sha") == _kernel_source_sha():
+            if prof.get("batch_per_gpu") == BATCH and w.a.config == 0 and prof.get("kernel_source_sha") == _kernel_source_sha() \
+                    and prof.get("dtype") == w.a.dtype:
                 traffic, tnote = prof["traffic_bytes_per_launch"], prof["method"]
-                if prof.get("scope") == "unet_only":
-                    tnote += ("; scope: the UNet's sx_gemm launches only (2 eager CFG steps, tools/r3_pmc_unet.sh) — rocprofv3 crashes "
-                              "with these counters on the composite bench command; the UNet holds 96 % of the step's GEMM time")
+                tscope = {"scope": prof["scope"], "launches": prof["launches"],
+                          "algorithmic_bytes_per_launch_same_launches": prof["algorithmic_bytes_per_launch"],
+                          "traffic_over_algorithmic": prof["traffic_over_algorithmic"],
+                          "attention_kernel": prof["families"].get("attention"),
+                          "note": "PMC traffic and algorithmic bytes are over the SAME launches (the UNet's, 96 % of the step's GEMM time: "
+                                  "rocprofv3 crashes with these counters on the composite bench command); `algorithmic_bytes_per_launch` "
+                                  "one level up is over every sx_gemm launch of the whole step (VAE / ViT / LLM included) and is NOT "
+                                  "comparable with `traffic`"}
                 break
         except (OSError, ValueError, KeyError):
             pass
     roof = {"bound": "mfma", "achieved": fl / tot_s / 1e12, "peak": PEAK_TFLOPS_16BIT, "unit": "TFLOP/s",
             "frac": fl / tot_s / 1e12 / PEAK_TFLOPS_16BIT, "traffic": traffic, "traffic_unit": "bytes/launch",
-            "traffic_source": tnote, "algorithmic_bytes_per_launch": alg_bytes / n,
+            "traffic_source": tnote, "traffic_detail": tscope, "algorithmic_bytes_per_launch": alg_bytes / n,
             "kernel": "sxk_gemm::gemm_pp_kernel<*> + gemm_kernel<*> (every sx_gemm launch)",
             "launches_per_step": n, "avg_launch_us": tot_s / n * 1e6, "avg_launch_gflop": fl / n / 1e9,
             "gemm_time_s_per_step": tot_s}

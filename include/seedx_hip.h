@@ -84,6 +84,12 @@ typedef struct sx_gemm_args {
                        padding=0 + F.pad(x, (0,1,0,1)): the stride-2 convs of the VAE encoder [ext])                 */
 } sx_gemm_args;
 int sx_gemm(const sx_gemm_args* args, void* stream);
+/* sx_gemm + the statistics pass of the GroupNorm that reads its output (diffusers ResnetBlock2D.norm2 / Transformer2DModel.norm /
+ * conv_norm_out [ext] after conv1 / conv2 / proj_out; call site pipeline_stable_diffusion_xl_t2i_edit.py:915-922), fused into the
+ * GEMM epilogue: stats[row / rows_per_sample][column / (N / groups)][2] (fp64, host-zeroed or pre-accumulated) += (sum, sum of
+ * squares) of the stored fp32 output. Only the 256-row ping-pong tiles carry it: *fused_host = 1 if this launch accumulated,
+ * 0 if the GEMM ran unchanged (then run sx_groupnorm's own statistics pass). */
+int sx_gemm_gn(const sx_gemm_args* args, double* stats, int groups, int rows_per_sample, int* fused_host, void* stream);
 /* tuning/test hook: force tile config 0..8 (lock-step 128x128, 128x80, 64x128, 64x64, 256x256, 256x320, 256x160; ping-pong
  * 256x256, 256x320 — the two-wave-group schedule of csrc/gemm_pp.hip); -1 = automatic (cost model); 100/101 = 2-D XCD
  * partition off/on; 200/201 = ping-pong tiles excluded from / offered to the cost model; 300+g = g tile-rows per in-XCD

@@ -19,7 +19,7 @@ def get_image_embeds(sd_vit, cfg_vit, sd_x, cfg_x, image_tensor=None, image_embe
         feats = restated.vit_forward(sd_vit, cfg_vit, x)                               # no pooling on this branch (:108)
     else:
         s = image_size or cfg_vit["image_size"]
-        neg = restated.vit_forward(sd_vit, cfg_vit, torch.zeros(1, 3, s, s))           # :110-111
+        neg = restated.vit_forward(sd_vit, cfg_vit, torch.zeros(1, 3, s, s, device=image_embeds.device))   # :110-111
         if vit_down:
             neg = F.avg_pool1d(neg.permute(0, 2, 1), kernel_size=4, stride=4).permute(0, 2, 1)   # :112-115
         feats = torch.cat([image_embeds.float(), neg.expand(image_embeds.shape[0], -1, -1)], dim=0)   # :116
@@ -42,7 +42,7 @@ def adapter_generate(sd_vit, cfg_vit, sd_x, cfg_x, sd_unet, cfg_unet, latents, s
     → edit variant. Returns final latents."""
     pe, pe_neg, pool, pool_neg = get_image_embeds(sd_vit, cfg_vit, sd_x, cfg_x, image_tensor, image_embeds, vit_down)
     _, _, init = ru.euler_tables(steps)
-    tid = torch.tensor([[height, width, 0, 0, height, width]], dtype=torch.float32)     # pipeline…:554-566
+    tid = torch.tensor([[height, width, 0, 0, height, width]], dtype=torch.float32, device=latents.device)   # pipeline…:554-566
     fn = lambda s, t, e, p, ti: ru.unet_forward(sd_unet, cfg_unet, s, t, e, p, ti)
     lat0 = latents.float() * init
     if image_latents is None:

@@ -250,7 +250,7 @@ def unet_forward(sd, cfg, sample, timestep, encoder_hidden_states, text_embeds, 
 def euler_tables(num_inference_steps, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, steps_offset=1):
     """scaled_linear betas, `leading` spacing, steps_offset 1, linear sigma interpolation, final sigma 0 [ext].
     Returns (timesteps float32 [N], sigmas float32 [N+1], init_noise_sigma)."""
-    betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
+    betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32, device="cpu") ** 2
     ac = torch.cumprod(1.0 - betas, dim=0).numpy()
     step_ratio = num_train_timesteps // num_inference_steps
     ts = (np.arange(0, num_inference_steps) * step_ratio).round()[::-1].copy().astype(np.float32) + steps_offset

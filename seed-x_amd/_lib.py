@@ -69,6 +69,7 @@ class AttnSmallArgs(C.Structure):
 SIGNATURES = {
     "sx_version": [],
     "sx_gemm": [C.POINTER(GemmArgs), c_vp],
+    "sx_gemm_gn": [C.POINTER(GemmArgs), c_vp, c_i32, c_i32, C.POINTER(c_i32), c_vp],
     "sx_gemm_force_tile": [c_i32],
     "sx_gemm_debug_stamps": [c_vp],
     "sx_gemm_pick_tile": [c_i32, c_i32, c_i32, c_i32, c_i32],

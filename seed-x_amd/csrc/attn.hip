@@ -497,7 +497,7 @@ __global__ __launch_bounds__(256) void attn_small_kernel(const AttnSmallP p) {
 using namespace sxk_attn;
 
 #ifndef SX_ATTN_OPT_D64
-#define SX_ATTN_OPT_D64 0      // OPT bits of the shipped head_dim-64 kernel (see attn_kernel)
+#define SX_ATTN_OPT_D64 2      // OPT bits of the shipped head_dim-64 kernel (see attn_kernel; round-4 lab: profiles/r4_attn_lab_opt_variants.log)
 #endif
 static int g_attn_variant = 0;   // tuning hook (tools/lab/attn_lab): 0 = shipped kernel; 16 + OPT = the head_dim-64 kernel with those OPT bits
 extern "C" int sx_attention_variant(int v) { g_attn_variant = v; return SX_OK; }

@@ -412,8 +412,22 @@ extern "C" int sx_gemm_force_tile(int cfg) {  // tuning / test hook: -1 = automa
   return SX_OK;
 }
 
-extern "C" int sx_gemm(const sx_gemm_args* a, void* stream) {
+static int gemm_impl(const sx_gemm_args* a, double* gn_stats, int gn_groups, int gn_rows, int* gn_fused, void* stream);
+
+extern "C" int sx_gemm(const sx_gemm_args* a, void* stream) { return gemm_impl(a, nullptr, 0, 0, nullptr, stream); }
+
+// sx_gemm + GroupNorm statistics of the output it stores (the statistics pass of the NEXT sx_groupnorm, fused into this launch's
+// epilogue): stats[row / rows_per_sample][column / (N / groups)][2] += (sum, sum of squares), fp64, by atomics — `stats` must be
+// zero (or hold the partial sums of other launches) beforehand. Only the ping-pong tiles carry the fused epilogue: *fused (host)
+// reports whether THIS launch accumulated; if 0 the GEMM ran unchanged and the caller runs sx_groupnorm's own statistics pass.
+extern "C" int sx_gemm_gn(const sx_gemm_args* a, double* stats, int groups, int rows_per_sample, int* fused, void* stream) {
+  SX_CHECK(stats && fused && groups > 0 && rows_per_sample > 0, "sx_gemm_gn: bad statistics arguments");
+  return gemm_impl(a, stats, groups, rows_per_sample, fused, stream);
+}
+
+static int gemm_impl(const sx_gemm_args* a, double* gn_stats, int gn_groups, int gn_rows, int* gn_fused, void* stream) {
   SX_CHECK(a && a->A && a->W && a->C, "sx_gemm: null pointer");
+  if (gn_fused) *gn_fused = 0;
   SX_CHECK(a->dtype == SX_F16 || a->dtype == SX_BF16, "sx_gemm: dtype must be f16/bf16");
   SX_CHECK(a->out_dtype >= SX_F16 && a->out_dtype <= SX_F32, "sx_gemm: bad out_dtype");
   SX_CHECK(a->M > 0 && a->N > 0 && a->K > 0, "sx_gemm: empty problem M=%d N=%d K=%d", a->M, a->N, a->K);
@@ -469,7 +483,15 @@ extern "C" int sx_gemm(const sx_gemm_args* a, void* stream) {
   SX_CHECK(!(g_force_tile == 7 || g_force_tile == 8) || ((allow >> g_force_tile) & 1u),
            "sx_gemm: forced ping-pong tile has no kernel for this epilogue");
   const int cfg = pick_tile(a->M, a->N, a->K, a->glu != 0, a->a_mode == SX_A_CONV3X3, g_force_tile, allow);
-  if (cfg == 7 || cfg == 8) return launch_pp(p, a->dtype, cfg == 7 ? 256 : 320, a->a_mode, st);
+  if (cfg == 7 || cfg == 8) {
+    // fused GroupNorm statistics: fp32 output of all N columns, whole 256-row tiles inside one sample, even channels per group
+    if (gn_stats && a->out_dtype == SX_F32 && !a->glu && a->act == SX_ACT_NONE && p.n_valid == a->N && a->N % gn_groups == 0 &&
+        (a->N / gn_groups) % 2 == 0 && gn_rows % 256 == 0 && a->M % gn_rows == 0) {
+      p.gn_stats = gn_stats; p.gn_groups = gn_groups; p.gn_cpg = a->N / gn_groups; p.gn_rows = gn_rows;
+      *gn_fused = 1;
+    }
+    return launch_pp(p, a->dtype, cfg == 7 ? 256 : 320, a->a_mode, st);
+  }
 #define SX_GEMM_DISPATCH(TT)                                                  \
   switch (cfg) {                                                              \
     case 0: return launch_cfg<TT, 128, 128, 2, 2, 2>(p, a->a_mode, st);       \

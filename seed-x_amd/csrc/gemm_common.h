@@ -19,6 +19,10 @@ struct GemmP {
   int n_tiles;                    // persistent kernels: logical grid size (blocks loop bid += gridDim.x)
   unsigned a_bytes, w_bytes;
   unsigned long long* dbg;        // tuning hook: per-block s_memtime stamps [block][4] = start, first tile landed, main loop done, end
+  // fused GroupNorm statistics of the stored fp32 output (sx_gemm_gn; ping-pong tiles only): stats[sample][group][2] += (sum, sum of
+  // squares) over the tile's rows and the group's channels; sample = row / gn_rows, group = column / gn_cpg
+  double* gn_stats;
+  int gn_cpg, gn_groups, gn_rows;
 };
 
 template <int N>

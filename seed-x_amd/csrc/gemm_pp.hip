@@ -324,6 +324,12 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p) {
     o[1] = pack2<TT>(x[2], x[3]);
     return o;
   };
+  // fused GroupNorm statistics (fp32-output kernels only): per lane the sums of its two column PAIRS of every n-fragment over its 8
+  // rows — a pair never straddles a group (channels per group are even), a quad can (C = 320: 10 channels per group)
+  const bool gn = OUT32 && p.gn_stats != nullptr;
+  float gsl[FN], gql[FN], gsh[FN], gqh[FN];
+#pragma unroll
+  for (int i = 0; i < FN; ++i) gsl[i] = gql[i] = gsh[i] = gqh[i] = 0.f;
 #pragma unroll
   for (int j = 0; j < FM; ++j) {
     const int m = m0 + g * 128 + j * 16 + (lane & 15);
@@ -360,6 +366,15 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p) {
 #pragma unroll
       for (int i = 0; i < FN; ++i)
         if (mok && nok[i]) *(f32x4_t*)((float*)p.C + (size_t)m * p.ldc + nout[i]) = v[i];
+      if (gn && mok) {
+#pragma unroll
+        for (int i = 0; i < FN; ++i) {
+          gsl[i] += v[i][0] + v[i][1];
+          gql[i] += v[i][0] * v[i][0] + v[i][1] * v[i][1];
+          gsh[i] += v[i][2] + v[i][3];
+          gqh[i] += v[i][2] * v[i][2] + v[i][3] * v[i][3];
+        }
+      }
     } else {
 #pragma unroll
       for (int i = 0; i < FN; ++i) {
@@ -383,6 +398,51 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p) {
         if (mok && nok[i]) *(u32x2_t*)((unsigned short*)p.C + (size_t)m * p.ldc + nout[i]) = pack4(v[i]);
       }
     }
+  }
+  if (OUT32 && gn) {
+    // 16 lanes (lane & 15 = the rows of a fragment) → one; then one LDS accumulator pair per group the tile touches (the
+    // operand ring is dead: every wave has drained its DMAs and passed its last fragment read), then one fp64 atomic per value.
+    // A 256-row tile lies inside one sample (host: gn_rows % 256 == 0).
+    // sum over the 16 lanes of a DPP row with four DPP moves (no LDS traffic): quad_perm [1,0,3,2], quad_perm [2,3,0,1], then
+    // row_half_mirror and row_mirror — after the two quad steps the four lanes of a quad agree, so the mirrors act as xor 4 / xor 8
+    auto row16_sum = [](float x) -> float {
+      x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));
+      x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true));
+      x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xF, 0xF, true));
+      x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x140, 0xF, 0xF, true));
+      return x;
+    };
+#pragma unroll
+    for (int i = 0; i < FN; ++i) {
+      gsl[i] = row16_sum(gsl[i]);
+      gql[i] = row16_sum(gql[i]);
+      gsh[i] = row16_sum(gsh[i]);
+      gqh[i] = row16_sum(gqh[i]);
+    }
+    float* gacc = (float*)smem;
+    const int gbase = n0 / p.gn_cpg;
+    const int nlast = (n0 + BN < p.N ? n0 + BN : p.N) - 1;
+    const int ngr = nlast / p.gn_cpg - gbase + 1;                    // groups this tile contributes to (<= BN / 2 + 1)
+    __syncthreads();
+    for (int t = tid; t < 2 * ngr; t += 512) gacc[t] = 0.f;
+    __syncthreads();
+    if ((lane & 15) == 0) {
+#pragma unroll
+      for (int i = 0; i < FN; ++i) {
+        const int c0 = n0 + wc * TN + i * 16 + lq;
+        if (c0 < p.N) {
+          const int gl = c0 / p.gn_cpg - gbase, gh = (c0 + 2) / p.gn_cpg - gbase;
+          atomicAdd(&gacc[2 * gl], gsl[i]);
+          atomicAdd(&gacc[2 * gl + 1], gql[i]);
+          atomicAdd(&gacc[2 * gh], gsh[i]);
+          atomicAdd(&gacc[2 * gh + 1], gqh[i]);
+        }
+      }
+    }
+    __syncthreads();
+    const int smp = m0 / p.gn_rows;
+    for (int t = tid; t < 2 * ngr; t += 512)
+      atomicAdd(&p.gn_stats[((size_t)smp * p.gn_groups + gbase) * 2 + t], (double)gacc[t]);
   }
   if (p.dbg) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the tile's stores have been issued and accepted

@@ -7,6 +7,8 @@ library or a non-CUDA tensor raises.
 import ctypes as C
 import math
 
+import os
+
 import torch
 
 from . import _lib
@@ -45,9 +47,40 @@ def _f32c(t):
 # ---------------------------------------------------------------------------------------------------------
 # GEMM family
 # ---------------------------------------------------------------------------------------------------------
+class GnStats:
+    """fp64 GroupNorm statistics [B, groups, 2] of a tensor that a GEMM / conv is about to produce: handed to the PRODUCER
+    (``gemm(..., gn=...)`` / ``conv3x3(..., gn=...)``), whose epilogue accumulates them when it runs on a ping-pong tile (then
+    ``ready`` is set), and to the CONSUMER ``groupnorm(..., stats=...)``, which then skips its own zero + statistics launches.
+    ``buf`` must be zero before the producer runs (slices of one arena zeroed once per forward: ``GnStats.arena``)."""
+    __slots__ = ("buf", "groups", "rows", "ready")
+
+    def __init__(self, buf, groups, rows):
+        self.buf, self.groups, self.rows, self.ready = buf, int(groups), int(rows), False
+
+    @staticmethod
+    def arena(n, B, groups, device):
+        """n zeroed [B, groups, 2] fp64 slots with ONE fill launch."""
+        return torch.zeros((n, B, groups, 2), dtype=torch.float64, device=device)
+
+
+GN_FUSE = os.environ.get("SX_GN_FUSE", "1") != "0"     # A/B switch (tools/bench_unet_ab.py): 0 = every GroupNorm runs its own statistics pass
+
+
+def _launch_gemm(lib, args, gn, what):
+    if gn is None or not GN_FUSE:
+        check(lib.sx_gemm(C.byref(args), _stream()), what)
+        return
+    assert gn.buf.dtype == torch.float64 and gn.buf.is_contiguous() and args.M % gn.rows == 0 \
+        and gn.buf.numel() == (args.M // gn.rows) * gn.groups * 2, "GnStats does not describe this output"
+    fused = C.c_int32(0)
+    check(lib.sx_gemm_gn(C.byref(args), gn.buf.data_ptr(), gn.groups, gn.rows, C.byref(fused), _stream()), what)
+    gn.ready = bool(fused.value)
+
+
 def gemm(a, w, bias=None, bias2d=None, bias2d_rows=0, residual=None, res_mod=0, act=None, glu=False,
-         out_dtype=None, out=None, n_valid=0, ld_bias2d=0):
-    """out[M, N_out] = epilogue(a[M, K] @ w[N, K]^T). a, w: 16-bit contiguous. residual/bias fp32."""
+         out_dtype=None, out=None, n_valid=0, ld_bias2d=0, gn=None):
+    """out[M, N_out] = epilogue(a[M, K] @ w[N, K]^T). a, w: 16-bit contiguous. residual/bias fp32.
+    gn: optional GnStats of the output (the next GroupNorm's statistics pass fused into this launch, see GnStats)."""
     lib = _lib.load()
     assert a.dim() == 2 and w.dim() == 2 and a.is_contiguous() and w.is_contiguous()
     assert a.dtype == w.dtype and a.dtype in (torch.float16, torch.bfloat16)
@@ -81,12 +114,12 @@ def gemm(a, w, bias=None, bias2d=None, bias2d_rows=0, residual=None, res_mod=0, 
     args.act = ACT[act]
     args.glu = 1 if glu else 0
     args.a_mode = SX_A_LINEAR
-    check(lib.sx_gemm(C.byref(args), _stream()), "sx_gemm")
+    _launch_gemm(lib, args, gn, "sx_gemm")
     return out
 
 
 def conv3x3(x, w, bias=None, bias2d=None, residual=None, stride=1, upsample=False, out_dtype=None, act=None,
-            n_valid=0, pad_mode=0):
+            n_valid=0, pad_mode=0, gn=None):
     """3x3 / pad 1 convolution as implicit GEMM. x: [B, H, W, Cin] 16-bit NHWC contiguous; w: [Cout, 9*Cin]
     ((ky,kx,cin)-ordered). Returns [B, Hout*Wout, Cout] (NHWC flattened). bias2d: [B, Cout] fp32 per-sample add.
     residual: fp32 [B*Hout*Wout, Cout]. pad_mode 1 = pad only bottom/right (VAE encoder's stride-2 convs)."""
@@ -125,7 +158,7 @@ def conv3x3(x, w, bias=None, bias2d=None, residual=None, stride=1, upsample=Fals
     args.stride = stride
     args.upsample = 1 if upsample else 0
     args.pad_mode = pad_mode
-    check(lib.sx_gemm(C.byref(args), _stream()), "sx_gemm(conv3x3)")
+    _launch_gemm(lib, args, gn, "sx_gemm(conv3x3)")
     return out.view(B, Hout * Wout, n_store)
 
 
@@ -234,8 +267,10 @@ def rmsnorm(x, gamma, eps, out_dtype, tiled=False):
     return layernorm(x, gamma, None, eps, out_dtype, rms=True, tiled=tiled)
 
 
-def groupnorm(x, gamma, beta, groups, eps, silu, out_dtype, want_raw=False, x2=None, comm=None, hw_total=None, planes=False):
+def groupnorm(x, gamma, beta, groups, eps, silu, out_dtype, want_raw=False, x2=None, comm=None, hw_total=None, planes=False,
+              stats=None):
     """x: fp32 [B, HW, C] (NHWC). Returns y (16-bit) and optionally a 16-bit raw copy of x.
+    stats: GnStats filled by x's producer (``ready``): only the apply pass runs (single rank, no x2).
     planes: y (and raw) come out as bf16 [B, HW, 3C] rows [hi | hi | lo] (split_bf16 role "a") instead.
     x2: optional second fp32 [B, HW, C2] tensor — the op then runs over the channel concatenation [x | x2] (never built).
     comm / hw_total: x holds only this rank's pixel rows of images with hw_total rows (seqpar.py): the fp64 statistics are
@@ -253,6 +288,11 @@ def groupnorm(x, gamma, beta, groups, eps, silu, out_dtype, want_raw=False, x2=N
         code, cols = _DT[out_dtype], Cc
     y = torch.empty((B, HW, cols), dtype=out_dtype, device=x.device)
     raw = torch.empty((B, HW, cols), dtype=out_dtype, device=x.device) if want_raw else None
+    if stats is not None and stats.ready and x2 is None and (comm is None or comm.world == 1):
+        assert stats.groups == groups and stats.rows == HW and stats.buf.numel() == B * groups * 2
+        check(lib.sx_groupnorm_sp(_p(x), None, C1, _p(y), _p(raw), code, _p(_f32c(gamma)), _p(_f32c(beta)), _p(stats.buf), B, HW, HW,
+                                  Cc, groups, float(eps), 1 if silu else 0, 2, _stream()), "sx_groupnorm_sp(apply, fused statistics)")
+        return (y, raw) if want_raw else y
     stats = torch.empty((B, groups, 2), dtype=torch.float64, device=x.device)
     if comm is None or comm.world == 1:
         check(lib.sx_groupnorm2(_p(x), _p(x2), C1, _p(y), _p(raw), code, _p(_f32c(gamma)), _p(_f32c(beta)), _p(stats),

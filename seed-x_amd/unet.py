@@ -53,6 +53,7 @@ class UNet2DConditionModel:
         self.device, self.dtype = None, torch.float16
         self._sd, self._P = None, None
         self._ctx_key, self._ctx = None, None
+        self._gn_arena, self._gn_next, self._n_gn_slots = None, 0, 64     # fused GroupNorm statistics slots per forward (47 used by SDXL)
 
     @classmethod
     def from_pretrained(cls, path, subfolder=None, **kw):
@@ -246,12 +247,25 @@ class UNet2DConditionModel:
 
     # ---- building blocks ---------------------------------------------------------------------------------------------
     # ---- pixel-row sharding helpers (identity for a single rank) -----------------------------------------------------
-    def _gn(self, x, gb, eps, silu, Hc, Wc, want_raw=False, x2=None):
-        """GroupNorm of this rank's rows with statistics over the whole image (Hc x Wc global size)."""
+    def _gn(self, x, gb, eps, silu, Hc, Wc, want_raw=False, x2=None, stats=None):
+        """GroupNorm of this rank's rows with statistics over the whole image (Hc x Wc global size).
+        stats: ops.GnStats accumulated by the GEMM / conv that produced x (skips the zero + statistics launches)."""
         G, dt = self.cfg["norm_groups"], self.dtype
-        return ops.groupnorm(x, gb[0], gb[1], G, eps, silu, dt, want_raw=want_raw, x2=x2, comm=self.comm, hw_total=Hc * Wc)
+        return ops.groupnorm(x, gb[0], gb[1], G, eps, silu, dt, want_raw=want_raw, x2=x2, comm=self.comm, hw_total=Hc * Wc,
+                             stats=stats)
 
-    def _conv(self, h16, B, Hc, Wc, w, bias=None, bias2d=None, residual=None, stride=1, upsample=False, n_valid=0):
+    def _gn_slot(self, B, HW):
+        """Next zeroed statistics slot of this forward's arena (None when the forward is row-sharded: the statistics then need
+        the cross-rank all-reduce of the unfused path)."""
+        if self._gn_arena is None:
+            return None
+        i = self._gn_next
+        self._gn_next += 1
+        if i >= self._gn_arena.shape[0]:
+            return None
+        return ops.GnStats(self._gn_arena[i], self.cfg["norm_groups"], HW)
+
+    def _conv(self, h16, B, Hc, Wc, w, bias=None, bias2d=None, residual=None, stride=1, upsample=False, n_valid=0, gn=None):
         """3x3 conv on this rank's slab. h16: 16-bit [B, Hl*Wc, Cin] (Hl = Hc / tp rows). Returns fp32 [B, Hl'*Wc', Cout].
         With tp > 1 the slab is extended by the neighbours' boundary rows (seqpar.with_halo) so that no output pixel sees a
         wrong zero padding; rows computed from the artificial padding of the halo itself are dropped."""
@@ -259,7 +273,7 @@ class UNet2DConditionModel:
         Cin = h16.shape[-1]
         if tp == 1:
             return ops.conv3x3(h16.view(B, Hc, Wc, Cin), w, bias=bias, bias2d=bias2d, residual=residual, stride=stride,
-                               upsample=upsample, out_dtype=torch.float32, n_valid=n_valid)
+                               upsample=upsample, out_dtype=torch.float32, n_valid=n_valid, gn=gn)
         from . import seqpar
         Hl = Hc // tp
         Co = n_valid or w.shape[0]
@@ -280,27 +294,31 @@ class UNet2DConditionModel:
         return out
 
     # ---- building blocks ---------------------------------------------------------------------------------------------
-    def _resnet(self, r, x, B, Hc, Wc, temb_all, skip=None):
+    def _resnet(self, r, x, B, Hc, Wc, temb_all, skip=None, st_in=None):
         """x: fp32 [B, HW, Ci] → fp32 [B, HW, Co]  (diffusers ResnetBlock2D [ext]).
         skip: fp32 [B, HW, Cs] — the block input is torch.cat([x, skip], dim=1) (up blocks); the concatenation is never
         built: norm1 reads both tensors and emits the 16-bit operands of conv1 and of the 1x1 shortcut.
-        (HW = this rank's rows of the Hc x Wc image when the forward is row-sharded.)"""
+        (HW = this rank's rows of the Hc x Wc image when the forward is row-sharded.)
+        st_in: GroupNorm statistics of x accumulated by its producer. Returns (out, statistics of out accumulated by conv2)."""
         Ci = x.shape[-1] + (skip.shape[-1] if skip is not None else 0)
         if "ws" in r:
             h, raw = self._gn(x, r["n1"], 1e-5, True, Hc, Wc, want_raw=True, x2=skip)
         else:
             assert skip is None
-            h = self._gn(x, r["n1"], 1e-5, True, Hc, Wc)
+            h = self._gn(x, r["n1"], 1e-5, True, Hc, Wc, stats=st_in)
         off, Co = self._P["temb_off"][r["name"]]
-        h = self._conv(h, B, Hc, Wc, r["w1"], bias=r["b1"], bias2d=temb_all[:, off:off + Co])
-        h = self._gn(h, r["n2"], 1e-5, True, Hc, Wc)
+        HW = x.shape[1]
+        st2 = self._gn_slot(B, HW)
+        h = self._conv(h, B, Hc, Wc, r["w1"], bias=r["b1"], bias2d=temb_all[:, off:off + Co], gn=st2)
+        h = self._gn(h, r["n2"], 1e-5, True, Hc, Wc, stats=st2)
         if "ws" in r:
             sc = ops.gemm(raw.view(-1, Ci), r["ws"], bias=r["bs"], out_dtype=torch.float32)
         else:
             sc = x.view(-1, Ci)
-        return self._conv(h, B, Hc, Wc, r["w2"], bias=r["b2"], residual=sc).view(B, -1, Co)
+        st_out = self._gn_slot(B, HW)
+        return self._conv(h, B, Hc, Wc, r["w2"], bias=r["b2"], residual=sc, gn=st_out).view(B, -1, Co), st_out
 
-    def _transformer(self, t, x, B, ctx_kv, Hc, Wc):
+    def _transformer(self, t, x, B, ctx_kv, Hc, Wc, st_in=None):
         """Transformer2DModel with use_linear_projection [ext]. x: fp32 [B, HW, C] (this rank's rows of the Hc x Wc image);
         ctx_kv: list of cached cross-attention K|V tensors [B, L, 2, heads, 64] for this transformer's blocks."""
         dt, heads = self.dtype, t["heads"]
@@ -308,7 +326,7 @@ class UNet2DConditionModel:
         hd = C // heads
         scale = hd ** -0.5
         sp = self.comm.world > 1
-        h = self._gn(x, t["norm"], 1e-6, False, Hc, Wc)
+        h = self._gn(x, t["norm"], 1e-6, False, Hc, Wc, stats=st_in)
         hs = ops.gemm(h.view(-1, C), t["pin_w"], bias=t["pin_b"], out_dtype=torch.float32)
         nb = len(t["blocks"])
         for k, b in enumerate(t["blocks"]):
@@ -336,8 +354,9 @@ class UNet2DConditionModel:
             g = ops.gemm(n, b["wff1"], bias=b["bff1"], act="gelu", glu=True)
             last = k == nb - 1
             hs = ops.gemm(g, b["wff2"], bias=b["bff2"], residual=hs, out_dtype=dt if last else torch.float32)
-        out = ops.gemm(hs, t["pout_w"], bias=t["pout_b"], residual=x.view(-1, C), out_dtype=torch.float32)
-        return out.view(B, HW, C)
+        st_out = self._gn_slot(B, HW)
+        out = ops.gemm(hs, t["pout_w"], bias=t["pout_b"], residual=x.view(-1, C), out_dtype=torch.float32, gn=st_out)
+        return out.view(B, HW, C), st_out
 
     def prepare_context(self, encoder_hidden_states):
         """Cross-attention K/V of every transformer block for this conditioning (constant over the denoise loop)."""
@@ -393,32 +412,40 @@ class UNet2DConditionModel:
         skips = [(x, H, W)]
         ti = 0
         Hc, Wc = H, W
+        # GroupNorm statistics ride on the epilogue of the GEMM / conv that produces each normalised tensor (ops.GnStats): one
+        # zeroed fp64 arena per forward, one slot per producer. Not when row-sharded (cross-rank statistics).
+        self._gn_arena = ops.GnStats.arena(self._n_gn_slots, B, c["norm_groups"], x.device) if tp == 1 else None
+        self._gn_next = 0
+        st = None                                                    # statistics of x, if its producer accumulated them
         for blk in P["down"]:
             for j, r in enumerate(blk["res"]):
-                x = self._resnet(r, x, B, Hc, Wc, temb_all)
+                x, st = self._resnet(r, x, B, Hc, Wc, temb_all, st_in=st)
                 if blk["attn"]:
-                    x = self._transformer(blk["attn"][j], x, B, ctx[ti], Hc, Wc)
+                    x, st = self._transformer(blk["attn"][j], x, B, ctx[ti], Hc, Wc, st_in=st)
                     ti += 1
                 skips.append((x, Hc, Wc))
             if blk["down"] is not None:
-                x = self._conv(ops.cast(x, dt), B, Hc, Wc, blk["down"][0], bias=blk["down"][1], stride=2)
+                st = self._gn_slot(B, (Hc // 2) * (Wc // 2))
+                x = self._conv(ops.cast(x, dt), B, Hc, Wc, blk["down"][0], bias=blk["down"][1], stride=2, gn=st)
                 Hc, Wc = Hc // 2, Wc // 2
                 skips.append((x, Hc, Wc))
-        x = self._resnet(P["mid"]["res"][0], x, B, Hc, Wc, temb_all)
-        x = self._transformer(P["mid"]["attn"][0], x, B, ctx[ti], Hc, Wc)
+        x, st = self._resnet(P["mid"]["res"][0], x, B, Hc, Wc, temb_all, st_in=st)
+        x, st = self._transformer(P["mid"]["attn"][0], x, B, ctx[ti], Hc, Wc, st_in=st)
         ti += 1
-        x = self._resnet(P["mid"]["res"][1], x, B, Hc, Wc, temb_all)
+        x, st = self._resnet(P["mid"]["res"][1], x, B, Hc, Wc, temb_all, st_in=st)
         for blk in P["up"]:
             for j, r in enumerate(blk["res"]):
                 s, _, _ = skips.pop()
-                x = self._resnet(r, x.contiguous(), B, Hc, Wc, temb_all, skip=s)   # torch.cat([x, skip], dim=1), fused
-                if blk["attn"]:
-                    x = self._transformer(blk["attn"][j], x, B, ctx[ti], Hc, Wc)
+                x, st = self._resnet(r, x.contiguous(), B, Hc, Wc, temb_all, skip=s)   # torch.cat([x, skip], dim=1), fused (norm1 over
+                if blk["attn"]:                                                        # the concatenation keeps its own statistics pass)
+                    x, st = self._transformer(blk["attn"][j], x, B, ctx[ti], Hc, Wc, st_in=st)
                     ti += 1
             if blk["up"] is not None:
                 x = self._conv(ops.cast(x, dt), B, Hc, Wc, blk["up"][0], bias=blk["up"][1], upsample=True)
                 Hc, Wc = Hc * 2, Wc * 2
-        h = self._gn(x, P["norm_out"], 1e-5, True, Hc, Wc)
+                st = None
+        h = self._gn(x, P["norm_out"], 1e-5, True, Hc, Wc, stats=st)
+        self._gn_arena = None
         nv = 4 if c["out_channels"] == 4 else 0
         out = self._conv(h, B, Hc, Wc, P["conv_out_w"], bias=P["conv_out_b"], n_valid=nv)
         out = out.view(B, -1, out.shape[-1])

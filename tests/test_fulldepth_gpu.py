@@ -196,16 +196,16 @@ def test_config0_one_generation_end_to_end(dev, vit48, llm40):
         ref_emb = restated.vit_forward(sd_vit, vcfg, crops)
         img_ids = tok.encode("".join(["<img>"] + [f"<img_{i:05d}>" for i in range(64)] + ["</img>"]))
         old_device = torch.get_default_device()
-        torch.set_default_device(dev)                # the restatement builds its small index / mask tensors on the default device
+        torch.set_default_device(dev)                # restated.lvlm_generate builds its small index / mask / RoPE tensors on the default device
         try:
             ref = restated.lvlm_generate(sd_llm, sd_agent, lcfg, {"in_heads": 32, "out_heads": 32}, ids, ref_emb,
                                          torch.tensor([True, True]), mask, ppos.to(dev), img_ids, tok.BOI, tok.EOI, len(new), 64,
                                          None, DT, new, [])
-            ref_lat = ra.adapter_generate(sd_vit, vcfg, sd_x, weights.FULL_XLV2, sd_u, ucfg, noise.to(dev), 5,
-                                          image_embeds=ref["img_gen_feat"])
-            ref_img = ra.decode_to_pt(sd_vae, A, ref_lat)
         finally:
             torch.set_default_device(old_device)
+        ref_lat = ra.adapter_generate(sd_vit, vcfg, sd_x, weights.FULL_XLV2, sd_u, ucfg, noise.to(dev), 5,
+                                      image_embeds=ref["img_gen_feat"])
+        ref_img = ra.decode_to_pt(sd_vae, A, ref_lat)
     stages = {"ViT features [2,256,4096]": relerr(emb, ref_emb),
               "LLM final-norm states of the 70 fed tokens": relerr(out["last_hidden_states"], ref["last_hidden"]),
               "output-resampled image features [1,64,4096]": relerr(out["img_gen_feat"], ref["img_gen_feat"]),

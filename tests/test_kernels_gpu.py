@@ -581,3 +581,57 @@ def test_cfg_euler_step(dev, mode):
     for kk in range(nb):
         assert relerr(scaled[kk, :, :Cl], ref / math.sqrt(sn * sn + 1)) < 1e-5
     assert scaled[..., Cl:].abs().sum() == 0
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_gemm_fused_groupnorm_statistics(dev, dtype):
+    """sx_gemm_gn: the statistics pass of the GroupNorm that reads a GEMM's / conv's fp32 output, accumulated by that launch's
+    epilogue (ping-pong tiles). Checked against fp64 sums of the stored output; C = 320 puts group boundaries (10 channels) inside
+    the 4-column pieces a lane holds; the consumer's apply pass on the fused statistics must equal the unfused GroupNorm."""
+    from seedx_amd import ops
+    g = torch.Generator().manual_seed(11)
+    G = 32
+    # linear + bias + fp32 residual (proj_out / attention out-proj epilogue), 2 samples x 1024 rows, N = 640 and 1280
+    from seedx_amd import _lib
+    lib = _lib.load()
+    for N, K, B, HW in ((640, 640, 32, 4096), (1280, 1280, 32, 1024)):       # the UNet's out-proj shapes at 64^2 / 32^2, 32 samples
+        assert lib.sx_gemm_pick_tile(B * HW, N, K, 0, 0) in (7, 8), "test shape must run on a ping-pong tile"
+        a = (torch.randn(B * HW, K, generator=g) * 0.5).to(dtype).to(dev)
+        w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dtype).to(dev)
+        bias = torch.randn(N, generator=g).to(dev)
+        res = torch.randn(B * HW, N, generator=g).to(dev)
+        arena = ops.GnStats.arena(1, B, G, dev)
+        gs = ops.GnStats(arena[0], G, HW)
+        out = ops.gemm(a, w, bias=bias, residual=res, out_dtype=torch.float32, gn=gs)
+        plain = ops.gemm(a, w, bias=bias, residual=res, out_dtype=torch.float32)
+        assert torch.equal(out, plain), "the fused statistics must not change the stored output"
+        assert gs.ready
+        o64 = out.double().view(B, HW, G, N // G)
+        ref = torch.stack([o64.sum(dim=(1, 3)), (o64 * o64).sum(dim=(1, 3))], dim=-1)
+        assert torch.allclose(gs.buf, ref, rtol=2e-6, atol=1e-3), (gs.buf - ref).abs().max()
+        gamma, beta = torch.randn(N, generator=g).to(dev), torch.randn(N, generator=g).to(dev)
+        y_f = ops.groupnorm(out.view(B, HW, N), gamma, beta, G, 1e-5, True, dtype, stats=gs)
+        y_u = ops.groupnorm(out.view(B, HW, N), gamma, beta, G, 1e-5, True, dtype)
+        assert (y_f.float() - y_u.float()).abs().max() <= 2e-2 * y_u.float().abs().max() * (1 if dtype == torch.bfloat16 else 0.1)
+    # 3x3 conv 320 -> 320 at 32 x 32 (resnet conv1 with the per-sample time add): 10 channels per group
+    B, H, Cin, Co = 8, 128, 320, 320
+    assert lib.sx_gemm_pick_tile(B * H * H, Co, 9 * Cin, 0, 1) in (7, 8)
+    x = (torch.randn(B, H, H, Cin, generator=g) * 0.5).to(dtype).to(dev)
+    w = (torch.randn(Co, 9 * Cin, generator=g) / (9 * Cin) ** 0.5).to(dtype).to(dev)
+    b2 = torch.randn(B, Co, generator=g).to(dev)
+    arena = ops.GnStats.arena(1, B, G, dev)
+    gs = ops.GnStats(arena[0], G, H * H)
+    out = ops.conv3x3(x, w, bias=torch.zeros(Co, device=dev), bias2d=b2, out_dtype=torch.float32, gn=gs)
+    assert gs.ready
+    o64 = out.double().view(B, H * H, G, Co // G)
+    ref = torch.stack([o64.sum(dim=(1, 3)), (o64 * o64).sum(dim=(1, 3))], dim=-1)
+    assert torch.allclose(gs.buf, ref, rtol=2e-6, atol=1e-3), (gs.buf - ref).abs().max()
+    # a launch that does not run on a ping-pong tile reports ready = False and the consumer falls back to its own pass
+    a = torch.randn(256, 64, generator=g).to(dtype).to(dev)
+    w = torch.randn(64, 64, generator=g).to(dtype).to(dev)
+    gs = ops.GnStats(ops.GnStats.arena(1, 1, G, dev)[0], G, 256)
+    out = ops.gemm(a, w, out_dtype=torch.float32, gn=gs)
+    assert not gs.ready and float(gs.buf.abs().sum()) == 0.0
+    y = ops.groupnorm(out.view(1, 256, 64), torch.ones(64, device=dev), torch.zeros(64, device=dev), G, 1e-5, False, dtype, stats=gs)
+    y2 = ops.groupnorm(out.view(1, 256, 64), torch.ones(64, device=dev), torch.zeros(64, device=dev), G, 1e-5, False, dtype)
+    assert torch.equal(y, y2)
