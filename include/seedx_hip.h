@@ -125,7 +125,23 @@ typedef struct sx_gemv_args {
                         * workspace (launches on one stream are fine). NULL: never split. Results are deterministic either way
                         * (partials are added in split order by the last workgroup to arrive). */
   uint64_t workspace_bytes;
+  /* RMSNorm folded into the decode step's skinny GEMMs (MFMA path only; all NULL / 0 = off). LlamaRMSNorm (modeling_llama_xformer.py:95,
+   * 286, 301) is y = x * rsqrt(mean(x^2) + eps) * gamma: gamma is folded into the NEXT projection's weights at load time and
+   * rsqrt(...) is a per-row scalar, so the norm needs no pass of its own —
+   *   producer (a GEMV with an fp32 residual output = the new residual stream x): also stores x as 16-bit operand tiles
+   *     [N/32][16][32] (`x16_out`, the next GEMV's x with x_layout = 1) and, per workgroup p, the rows' sums of squares over its own
+   *     columns (`row_ssq_out`[16][parts], parts = the launch's workgroups in x = sx_gemv_ssq_parts(N, glu); the consumer needs parts % 64 == 0: 320 for N = 5120);
+   *   consumer: multiplies its accumulators by rsqrt(sum_p row_ssq_in[m][p] / ssq_dim + ssq_eps) before activation / GLU / store
+   *     (the partials are added in the fixed order p = 0, 1, ...: every workgroup computes the same scale). */
+  void* x16_out;
+  float* row_ssq_out;
+  const float* row_ssq_in;
+  int32_t ssq_in_parts, ssq_dim;
+  float ssq_eps;
+  int32_t reserved;
 } sx_gemv_args;
+/* workgroups in x (= partial rows of row_ssq_out) sx_gemv launches for an M x N x K problem with / without GLU on the MFMA path */
+int sx_gemv_ssq_parts(int N, int glu);
 int sx_gemv(const sx_gemv_args* args, void* stream);
 /* test hook: 1 = always take the VALU path (lets the tests compare both), 0 = automatic */
 int sx_gemv_force_valu(int on);

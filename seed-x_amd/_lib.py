@@ -30,7 +30,9 @@ class GemvArgs(C.Structure):
     _fields_ = [("x", c_vp), ("W", c_vp), ("y", c_vp), ("residual", c_vp),
                 ("M", c_i32), ("N", c_i32), ("K", c_i32),
                 ("dtype", c_i32), ("out_dtype", c_i32), ("act", c_i32), ("glu", c_i32),
-                ("w_layout", c_i32), ("x_layout", c_i32), ("workspace", c_vp), ("workspace_bytes", C.c_uint64)]
+                ("w_layout", c_i32), ("x_layout", c_i32), ("workspace", c_vp), ("workspace_bytes", C.c_uint64),
+                ("x16_out", c_vp), ("row_ssq_out", c_vp), ("row_ssq_in", c_vp), ("ssq_in_parts", c_i32), ("ssq_dim", c_i32),
+                ("ssq_eps", c_f32), ("reserved", c_i32)]
 
 
 class OneshotArgs(C.Structure):
@@ -74,6 +76,7 @@ SIGNATURES = {
     "sx_gemm_debug_stamps": [c_vp],
     "sx_gemm_pick_tile": [c_i32, c_i32, c_i32, c_i32, c_i32],
     "sx_gemv": [C.POINTER(GemvArgs), c_vp],
+    "sx_gemv_ssq_parts": [c_i32, c_i32],
     "sx_gemv_force_valu": [c_i32],
     "sx_layernorm": [c_vp, c_i32, c_vp, c_i32, c_vp, c_vp, c_i32, c_i32, c_f32, c_i32, c_vp],
     "sx_softmax_rows": [c_vp, c_i64, c_vp, c_i64, c_i32, c_i32, c_f32, c_i32, c_vp],

@@ -3,6 +3,7 @@
 // All loop state (position, current token) lives in DEVICE memory so a whole token step is hipGraph-replayable
 // with zero host round trips (the reference syncs ≥45× per token).
 #include "sx_common.h"
+#include <type_traits>
 
 namespace sxk_decode {
 
@@ -18,6 +19,12 @@ struct GemvP {
   int x_tiled;  // x is in operand tiles [K/32][16 rows][32 k] (one 1-KB tile per MFMA B operand; rows >= M are padding)
   unsigned* ws_cnt;   // split-K: arrival counters [N/16] (zero between launches)
   float* ws_part;     //          partial sums [S][16][N]
+  // RMSNorm fold (include/seedx_hip.h sx_gemv_args): producer side x16_out / ssq_out, consumer side ssq_in
+  unsigned short* x16_out;
+  float* ssq_out;
+  const float* ssq_in;
+  int ssq_parts;
+  float ssq_inv_dim, ssq_eps;
 };
 
 template <typename TT, int MR>
@@ -133,6 +140,30 @@ __global__ __launch_bounds__(NWV * 64) void gemm_skinny_kernel(const GemvP p) {
   f32x4_t acc[R];
 #pragma unroll
   for (int q = 0; q < R; ++q) acc[q] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  // folded RMSNorm, consumer side: rstd of row r from the producer's per-workgroup sums of squares [16][parts]. Done HERE, ahead of
+  // the weight stream, by all 256 threads at once: thread (slice = tid >> 4, r) loads its 1/16 of row r's list as independent 16-B
+  // loads (a serial chain of 20 dependent L2 round trips per workgroup cost 5.7 us per launch), two shuffles + one LDS hop add the
+  // 16 slices in a fixed order: every workgroup computes the same bits.
+  __shared__ float ssq_red[NWV][16];
+  float rstd_fold = 1.f;
+  if (p.ssq_in) {
+    const int per = p.ssq_parts >> 4;                                   // parts % 64 == 0 (host-checked) → per % 4 == 0
+    const f32x4_t* src = (const f32x4_t*)(p.ssq_in + (size_t)r * p.ssq_parts + (size_t)(wave * 4 + g) * per);
+    float s0 = 0.f;
+#pragma unroll 5
+    for (int i = 0; i < (per >> 2); ++i) {
+      const f32x4_t t = src[i];
+      s0 += (t[0] + t[1]) + (t[2] + t[3]);
+    }
+    s0 += __shfl_xor(s0, 16, 64);
+    s0 += __shfl_xor(s0, 32, 64);
+    if (g == 0) ssq_red[wave][r] = s0;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < NWV; ++w) tot += ssq_red[w][r];
+    rstd_fold = __builtin_amdgcn_rsqf(tot * p.ssq_inv_dim + p.ssq_eps);
+  }
   // Rounds of U k-steps through TWO register sets: round i+1's loads are issued before round i is consumed, so 1-2 rounds
   // (U..2U KB per row group and wave) are in flight at every moment. The pipelined loop has no branch inside (the waitcnt
   // pass then emits exact vmcnt(N) waits; with a guard inside it falls back to vmcnt(0) before the first MFMA). Last full
@@ -253,10 +284,17 @@ __global__ __launch_bounds__(NWV * 64) void gemm_skinny_kernel(const GemvP p) {
       }
     if (lane == 0) __hip_atomic_store(p.ws_cnt + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  if (!mvalid) return;
+  if (p.ssq_in) {
+#pragma unroll
+    for (int q = 0; q < R; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[q][e] *= rstd_fold;
+  }
+  float ssq_l = 0.f;
   const int ncols = p.glu ? p.N / 2 : p.N;
 #pragma unroll
   for (int q = 0; q < (R == 2 ? 2 : 1); ++q) {
+    if (!mvalid) break;
     f32x4_t o;
     int col;
     if (p.glu) {
@@ -278,12 +316,24 @@ __global__ __launch_bounds__(NWV * 64) void gemm_skinny_kernel(const GemvP p) {
       *(u32x2_t*)((unsigned short*)p.y + (size_t)(col >> 5) * 512 + (size_t)r * 32 + (col & 31)) = w2;
     } else if (p.out_dtype == SX_F32) {
       *(f32x4_t*)((float*)p.y + off) = o;
+      if (p.x16_out) {     // folded RMSNorm, producer side: the new residual stream also as the next GEMV's 16-bit operand tiles
+        u32x2_t w2;
+        if (std::is_same<TT, BF16>::value) { w2[0] = pack2<BF16>(o[0], o[1]); w2[1] = pack2<BF16>(o[2], o[3]); }
+        else { w2[0] = pack2<F16>(o[0], o[1]); w2[1] = pack2<F16>(o[2], o[3]); }
+        *(u32x2_t*)(p.x16_out + (size_t)(col >> 5) * 512 + (size_t)r * 32 + (col & 31)) = w2;
+        ssq_l += o[0] * o[0] + o[1] * o[1] + o[2] * o[2] + o[3] * o[3];
+      }
     } else {
       u32x2_t w2;
       if (p.out_dtype == SX_BF16) { w2[0] = pack2<BF16>(o[0], o[1]); w2[1] = pack2<BF16>(o[2], o[3]); }
       else { w2[0] = pack2<F16>(o[0], o[1]); w2[1] = pack2<F16>(o[2], o[3]); }
       *(u32x2_t*)((unsigned short*)p.y + off) = w2;
     }
+  }
+  if (p.ssq_out) {           // (whole wave: rows >= M contribute zeros and are never read)
+    ssq_l += __shfl_xor(ssq_l, 16, 64);
+    ssq_l += __shfl_xor(ssq_l, 32, 64);
+    if (g == 0) p.ssq_out[(size_t)r * gridDim.x + blockIdx.x] = ssq_l;      // [16][parts]
   }
 #endif
 }
@@ -777,6 +827,9 @@ extern "C" int sx_gemv_tune(int key, int value) {
 static int g_force_valu_gemv = 0;   // test hook (sx_gemv_force_valu): compare the two GEMV paths
 extern "C" int sx_gemv_force_valu(int on) { g_force_valu_gemv = on; return SX_OK; }   // 1 = VALU only, 2 = MFMA whenever legal
 
+// workgroups in x of the MFMA path (must mirror the r2 / gx choice in sx_gemv below)
+extern "C" int sx_gemv_ssq_parts(int N, int glu) { return (glu || N / 32 >= 256) ? N / 32 : N / 16; }
+
 extern "C" int sx_gemv(const sx_gemv_args* a, void* stream) {
   SX_CHECK(a && a->x && a->W && a->y, "sx_gemv: null pointer");
   SX_CHECK(a->dtype == SX_F16 || a->dtype == SX_BF16, "sx_gemv: dtype");
@@ -791,6 +844,13 @@ extern "C" int sx_gemv(const sx_gemv_args* a, void* stream) {
            "sx_gemv: SX_TILED16 needs a 16-bit output with n_out %% 32 == 0");
   p.packed = a->w_layout;
   p.ws_cnt = nullptr; p.ws_part = nullptr;
+  p.x16_out = (unsigned short*)a->x16_out; p.ssq_out = a->row_ssq_out; p.ssq_in = a->row_ssq_in;
+  p.ssq_parts = a->ssq_in_parts; p.ssq_inv_dim = a->ssq_dim > 0 ? 1.0f / (float)a->ssq_dim : 0.f; p.ssq_eps = a->ssq_eps;
+  SX_CHECK(!a->row_ssq_in || (a->ssq_in_parts > 0 && a->ssq_in_parts % 64 == 0 && a->ssq_dim > 0 && ((uintptr_t)a->row_ssq_in & 15) == 0),
+           "sx_gemv: row_ssq_in needs ssq_in_parts (a multiple of 64), ssq_dim and a 16-B aligned list");
+  SX_CHECK((a->x16_out == nullptr) == (a->row_ssq_out == nullptr), "sx_gemv: x16_out and row_ssq_out come together");
+  SX_CHECK(!a->x16_out || (p.out_dtype == SX_F32 && !a->glu && a->N % 32 == 0 && !p.y_tiled),
+           "sx_gemv: x16_out needs an fp32, non-GLU output with N %% 32 == 0");
   p.x_tiled = a->x_layout;
   SX_CHECK(a->x_layout == 0 || a->x_layout == 1, "sx_gemv: x_layout must be 0 (row-major) or 1 (operand tiles)");
   SX_CHECK(a->w_layout == 0 || a->w_layout == 1, "sx_gemv: w_layout must be 0 (row-major) or 1 (decode tiles)");
@@ -828,6 +888,7 @@ extern "C" int sx_gemv(const sx_gemv_args* a, void* stream) {
   }
   SX_CHECK(a->M <= 8, "sx_gemv: M=%d > 8 needs K %% 64 == 0 and N %% 32 == 0 (MFMA path)", a->M);
   SX_CHECK(p.packed == 0, "sx_gemv: the VALU kernel reads row-major weights only");
+  SX_CHECK(!a->x16_out && !a->row_ssq_in, "sx_gemv: the RMSNorm fold exists on the MFMA path only");
   const int pairs = (a->N + 1) / 2;
   const dim3 grid((pairs + 3) / 4), block(256);
   const int mr = a->M == 1 ? 1 : (a->M == 2 ? 2 : (a->M <= 4 ? 4 : 8));

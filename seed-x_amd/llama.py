@@ -18,6 +18,7 @@ logits, past_key_values, hidden_states with the LAST entry = post-final-norm sta
     all-gathered in front of the replicated greedy rule, so every rank holds identical tokens and loop state
 """
 import math
+import os
 
 import torch
 
@@ -185,6 +186,11 @@ class LlamaForCausalLM:
             N, K = w.shape
             return ops.pack_decode_tiles(w) if (self.G >= 5 and N % 32 == 0 and K % 64 == 0 and K >= 256) else None
         P["lm_head_t"] = tiles(lm)
+        # RMSNorm folded into the batched decode step (single rank, G >= 5; sx_gemv_args.x16_out / row_ssq_*): the decode-tile copies
+        # of the projections that FOLLOW a norm carry that norm's gamma (W' = W · diag(gamma), product rounded once to 16 bits) —
+        # wgu of every layer (post_attention_layernorm) and wqkv of layers >= 1 (input_layernorm; layer 0's input comes from the
+        # embedding, not from a GEMV). Prefill keeps the row-major, unfolded weights and the norm kernel.
+        fold = self.G >= 5 and tp == 1 and os.environ.get("SX_RMS_FOLD", "1") != "0"      # (0: A/B switch, tools/)
         for i in range(self.L):
             p = f"model.layers.{i}."
             sh = llama_tp_shard(sd, p, r, tp, self.nh, self.hd)
@@ -196,9 +202,18 @@ class LlamaForCausalLM:
             lw = P["layers"][-1]
             for k in ("wqkv", "wo", "wgu", "wd"):
                 lw[k + "_t"] = tiles(lw[k])
+            if fold and lw["wgu_t"] is not None and lw["wqkv_t"] is not None:
+                g2 = lw["ln2"][None, :]
+                lw["wgu_t"] = tiles(glu_pack_rows((sh["up"].detach().to(dev, torch.float32) * g2).to(dt),
+                                                  (sh["gate"].detach().to(dev, torch.float32) * g2).to(dt)))
+                if i > 0:
+                    lw["wqkv_t"] = tiles((qkv.to(dev, torch.float32) * lw["ln1"][None, :]).to(dt).contiguous())
         # every decode GEMV has the decode-tile weight copy → its 16-bit inputs travel as operand tiles too (_layers_single)
         P["decode_tiled"] = all(lw[k + "_t"] is not None for lw in P["layers"] for k in ("wqkv", "wo", "wgu", "wd")) \
             and (self.nh_l * self.hd) % 32 == 0
+        P["rms_fold"] = fold and P["decode_tiled"] and self.H % 32 == 0
+        assert P["rms_fold"] or not fold or not any(lw["wgu_t"] is not None for lw in P["layers"]), \
+            "folded decode tiles without the tiled decode path"
         # split-K scratch of the skinny GEMM: counters + 8 partial [16, H] blocks (include/seedx_hip.h: sx_gemv_args.workspace)
         P["gemv_ws"] = torch.zeros(16384 + 8 * 16 * self.H * 4, dtype=torch.uint8, device=dev) if P["decode_tiled"] else None
         inv = 1.0 / (self.config.rope_base ** (torch.arange(0, self.hd, 2).float() / self.hd))
@@ -294,9 +309,17 @@ class LlamaForCausalLM:
         # kernel that produces them (norm, attention combine, GLU epilogue) — one contiguous 1-KB load per operand instead of
         # 16 rows that all sit on the same L2 channel — and the down projection may split K over workgroups (workspace)
         tl, ws = P["decode_tiled"] and G >= 5, P["gemv_ws"]
+        # folded RMSNorm: the residual GEMVs (o, down) also emit the new residual stream as 16-bit operand tiles (x16) and its rows'
+        # sums of squares (ssq); the projection behind the norm reads x16 with gamma-folded weights and scales by rstd — no norm launch
+        fold = tl and P["rms_fold"]
+        x16 = ssq = None
+        nl = len(P["layers"])
         for li, lw in enumerate(P["layers"]):
-            h = ops.rmsnorm(x, lw["ln1"], eps, dt, tiled=tl)
-            qkv = ops.gemv(h, lw["wqkv"], w_tiles=lw["wqkv_t"])                       # [G, 3H]
+            if fold and li > 0:
+                qkv = ops.gemv(x16, lw["wqkv"], w_tiles=lw["wqkv_t"], ssq_in=(ssq, self.H, eps))
+            else:
+                h = ops.rmsnorm(x, lw["ln1"], eps, dt, tiled=tl)
+                qkv = ops.gemv(h, lw["wqkv"], w_tiles=lw["wqkv_t"])                   # [G, 3H]
             if self.fused_decode_attention and hd % 16 == 0:
                 # RoPE + KV append + split-KV attention + combine as one launch (bit-identical to the three-kernel form below)
                 att = ops.attn_decode_fused(qkv, P["kc"][li], P["vc"][li], P["pos"], P["cos"], P["sin"], scale, nh, hd,
@@ -305,6 +328,16 @@ class LlamaForCausalLM:
                 ops.rope_kv_append_b(qkv, P["kc"][li], P["vc"][li], P["cos"], P["sin"], P["pos"], G, 1, nh, hd)
                 q = qkv[:, :H].unflatten(1, (nh, hd))                                # strided view into qkv: no copy
                 att = ops.attn_decode_b(q, P["kc"][li], P["vc"][li], P["ctx"], scale, nsplit=self.decode_nsplit, out_tiled=tl)
+            if fold:
+                x, x16, ssq = ops.gemv(att, lw["wo"], residual=x, out_dtype=torch.float32, w_tiles=lw["wo_t"], workspace=ws,
+                                       emit_norm=True)
+                g = ops.gemv(x16, lw["wgu"], act="silu", glu=True, w_tiles=lw["wgu_t"], y_tiled=True, ssq_in=(ssq, self.H, eps))
+                if li + 1 < nl:
+                    x, x16, ssq = ops.gemv(g, lw["wd"], residual=x, out_dtype=torch.float32, w_tiles=lw["wd_t"], workspace=ws,
+                                           emit_norm=True)
+                else:                        # the final norm needs fp32 states (hidden-state output): its own launch
+                    x = ops.gemv(g, lw["wd"], residual=x, out_dtype=torch.float32, w_tiles=lw["wd_t"], workspace=ws)
+                continue
             x = comm.all_reduce(ops.gemv(att, lw["wo"], residual=x if lead else None, out_dtype=torch.float32,
                                          w_tiles=lw["wo_t"], workspace=ws))
             h = ops.rmsnorm(x, lw["ln2"], eps, dt, tiled=tl)

@@ -189,10 +189,14 @@ class Tiled16:
         return self.t.permute(1, 0, 2).reshape(16, self.cols)[:self.rows].contiguous()
 
 
-def gemv(x, w, residual=None, act=None, glu=False, out_dtype=None, w_tiles=None, y_tiled=False, workspace=None):
+def gemv(x, w, residual=None, act=None, glu=False, out_dtype=None, w_tiles=None, y_tiled=False, workspace=None,
+         emit_norm=False, ssq_in=None):
     """w_tiles: the same weight in the decode layout (pack_decode_tiles); used instead of w when the MFMA path runs.
     x may be a Tiled16 (then w_tiles is required); y_tiled returns the 16-bit result as a Tiled16 for the next gemv.
-    workspace: zero-initialised uint8 scratch enabling split-K over workgroups for shapes that need it (sx_gemv_args.workspace)."""
+    workspace: zero-initialised uint8 scratch enabling split-K over workgroups for shapes that need it (sx_gemv_args.workspace).
+    RMSNorm fold (sx_gemv_args.x16_out / row_ssq_*; MFMA path, tiled x): ``emit_norm`` (fp32 residual outputs) → returns
+    (y, x16, ssq): y also as 16-bit operand tiles and the rows' sums of squares per workgroup; ``ssq_in`` = (ssq, dim, eps) of
+    the producer → the accumulators are scaled by rsqrt(sum(ssq) / dim + eps) (gamma lives in this launch's weights)."""
     lib = _lib.load()
     xt = isinstance(x, Tiled16)
     if xt:
@@ -225,8 +229,19 @@ def gemv(x, w, residual=None, act=None, glu=False, out_dtype=None, w_tiles=None,
     if w_tiles is not None and (xt or y_tiled or M >= 5) and K % 64 == 0 and K >= 256 and N % 32 == 0:
         assert w_tiles.shape == w.shape and w_tiles.dtype == w.dtype and w_tiles.is_contiguous()
         args.W, args.w_layout = w_tiles.data_ptr(), 1
+    x16 = ssq = None
+    if emit_norm:
+        assert args.w_layout == 1 and out_dtype == torch.float32 and not glu and not y_tiled
+        x16 = Tiled16(M, n_out, w.dtype, dev)
+        ssq = torch.empty((16, lib.sx_gemv_ssq_parts(N, 0)), dtype=torch.float32, device=dev)      # [row][workgroup]
+        args.x16_out, args.row_ssq_out = x16.t.data_ptr(), ssq.data_ptr()
+    if ssq_in is not None:
+        t, dim, eps = ssq_in
+        assert args.w_layout == 1 and t.dtype == torch.float32 and t.is_contiguous() and t.shape[0] == 16
+        args.row_ssq_in, args.ssq_in_parts, args.ssq_dim, args.ssq_eps = t.data_ptr(), t.shape[1], int(dim), float(eps)
     check(lib.sx_gemv(C.byref(args), _stream()), "sx_gemv")
-    return yt if y_tiled else y
+    out = yt if y_tiled else y
+    return (out, x16, ssq) if emit_norm else out
 
 
 def linear(x, w, **kw):

@@ -635,3 +635,54 @@ def test_gemm_fused_groupnorm_statistics(dev, dtype):
     y = ops.groupnorm(out.view(1, 256, 64), torch.ones(64, device=dev), torch.zeros(64, device=dev), G, 1e-5, False, dtype, stats=gs)
     y2 = ops.groupnorm(out.view(1, 256, 64), torch.ones(64, device=dev), torch.zeros(64, device=dev), G, 1e-5, False, dtype)
     assert torch.equal(y, y2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M", [5, 16])
+def test_gemv_rmsnorm_fold(dev, dtype, M):
+    """RMSNorm folded into the decode step's skinny GEMMs (sx_gemv_args.x16_out / row_ssq_*): the residual GEMV (o / down shapes,
+    incl. the split-K one) emits the new residual stream x also as 16-bit operand tiles and its rows' sums of squares per
+    workgroup; the GEMV behind the norm, with gamma folded into its weights, then equals RMSNorm(x) @ W^T — compared with the
+    unfused kernels (norm launch + plain weights) and with fp32 torch."""
+    from seedx_amd import ops
+    g = torch.Generator().manual_seed(23 + M)
+    H, eps = 5120, 1e-5
+    for K in (5120, 13824):                                              # o-proj, down-proj (split-K over workgroups)
+        a = (torch.randn(M, K, generator=g) * 0.5).to(dtype).to(dev)
+        w = (torch.randn(H, K, generator=g) / K ** 0.5).to(dtype).to(dev)
+        res = torch.randn(M, H, generator=g).to(dev)
+        ws = torch.zeros(16384 + 8 * 16 * H * 4, dtype=torch.uint8, device=dev)
+        wt = ops.pack_decode_tiles(w)
+        at = ops.Tiled16(M, K, dtype, dev)                                 # the operand as MFMA tiles [K/32][16][32]
+        pad = torch.zeros(16, K, dtype=dtype, device=dev)
+        pad[:M] = a
+        at.t.copy_(pad.view(16, K // 32, 32).permute(1, 0, 2))
+        y_plain = ops.gemv(at, w, residual=res, out_dtype=torch.float32, w_tiles=wt, workspace=ws)
+        y, x16, ssq = ops.gemv(at, w, residual=res, out_dtype=torch.float32, w_tiles=wt, workspace=ws, emit_norm=True)
+        assert torch.equal(y, y_plain), "emitting the norm inputs must not change the fp32 output"
+        assert torch.equal(x16.dense(), y.to(dtype)), "x16 = the fp32 output rounded once to 16 bits, as operand tiles"
+        ref_ssq = (y.double() ** 2).sum(dim=1)
+        got = ssq.double().sum(dim=1)[:M]
+        assert torch.allclose(got, ref_ssq, rtol=1e-5), (got, ref_ssq)
+        # consumer: qkv-like (plain) and gate|up-like (SiLU-GLU) projections behind the norm
+        gamma = (1.0 + 0.1 * torch.randn(H, generator=g)).to(dev)
+        for N, glu in ((15360, False), (2 * 13824, True)):
+            wn = (torch.randn(N, H, generator=g) / H ** 0.5).to(dev)
+            if glu:
+                from seedx_amd.llama import glu_pack_rows
+                pack = lambda t: glu_pack_rows(t[:N // 2].contiguous(), t[N // 2:].contiguous())
+            else:
+                pack = lambda t: t
+            w_plain = pack(wn.to(dtype))
+            w_fold = pack((wn * gamma[None, :]).to(dtype))
+            kw = dict(act="silu", glu=True) if glu else {}
+            out_f = ops.gemv(x16, w_fold, w_tiles=ops.pack_decode_tiles(w_fold), ssq_in=(ssq, H, eps), **kw)
+            h = ops.rmsnorm(y, gamma, eps, dtype, tiled=True)
+            out_u = ops.gemv(h, w_plain, w_tiles=ops.pack_decode_tiles(w_plain), **kw)
+            hn = y * torch.rsqrt((y * y).mean(dim=1, keepdim=True) + eps) * gamma
+            z = hn @ wn.t()
+            ref = torch.nn.functional.silu(z[:, N // 2:]) * z[:, :N // 2] if glu else z
+            e_f, e_u = relerr(out_f, ref), relerr(out_u, ref)
+            print(f"rmsnorm fold {dtype} M={M} K={K} N={N} glu={glu}: folded {e_f:.2e}, unfused {e_u:.2e} vs fp32")
+            tol = 2e-3 if dtype == torch.float16 else 1.6e-2
+            assert e_f < tol and e_f < 1.5 * e_u + 1e-4
