@@ -114,7 +114,9 @@ typedef struct sx_gemv_args {
   int32_t M, N, K;
   int32_t dtype, out_dtype, act, glu;
   int32_t w_layout;    /* 0: W row-major [N][K]. 1: decode tiles [N/16][K/32][16][32] (each 16-row x 32-k MFMA operand tile
-                        * is 1 KB contiguous, tiles of a row group follow each other along K): MFMA path only (M >= 2) */
+                        * is 1 KB contiguous, tiles of a row group follow each other along K): MFMA path only (M >= 2).
+                        * 2: 20-row decode tiles [N/20][K/32][20][32] (no GLU, N % 20 == 0): one workgroup per 20 rows — for
+                        * N = 5120 that is 256 equal workgroups on the 256 CUs instead of 320 16-row groups (o / down projections) */
   int32_t x_layout;    /* 0: x row-major [M][K]. 1: operand tiles [K/32][16][32] (tile t holds x[0..15][32t .. 32t+31], rows >= M
                         * are padding with ARBITRARY content (uninitialised is fine, NaN bit patterns included): an MFMA output column depends
                         * only on its own operand column and columns >= M are never stored; 16 * K elements in all): MFMA path only */
@@ -130,7 +132,7 @@ typedef struct sx_gemv_args {
    * rsqrt(...) is a per-row scalar, so the norm needs no pass of its own —
    *   producer (a GEMV with an fp32 residual output = the new residual stream x): also stores x as 16-bit operand tiles
    *     [N/32][16][32] (`x16_out`, the next GEMV's x with x_layout = 1) and, per workgroup p, the rows' sums of squares over its own
-   *     columns (`row_ssq_out`[16][parts], parts = the launch's workgroups in x = sx_gemv_ssq_parts(N, glu); the consumer needs parts % 64 == 0: 320 for N = 5120);
+   *     columns (`row_ssq_out`[16][parts], parts = the launch's workgroups in x = sx_gemv_ssq_parts(N, glu, w_layout); the consumer needs parts % 64 == 0: 320 / 256 for N = 5120);
    *   consumer: multiplies its accumulators by rsqrt(sum_p row_ssq_in[m][p] / ssq_dim + ssq_eps) before activation / GLU / store
    *     (the partials are added in the fixed order p = 0, 1, ...: every workgroup computes the same scale). */
   void* x16_out;
@@ -141,7 +143,7 @@ typedef struct sx_gemv_args {
   int32_t reserved;
 } sx_gemv_args;
 /* workgroups in x (= partial rows of row_ssq_out) sx_gemv launches for an M x N x K problem with / without GLU on the MFMA path */
-int sx_gemv_ssq_parts(int N, int glu);
+int sx_gemv_ssq_parts(int N, int glu, int w_layout);
 int sx_gemv(const sx_gemv_args* args, void* stream);
 /* test hook: 1 = always take the VALU path (lets the tests compare both), 0 = automatic */
 int sx_gemv_force_valu(int on);

@@ -76,7 +76,7 @@ SIGNATURES = {
     "sx_gemm_debug_stamps": [c_vp],
     "sx_gemm_pick_tile": [c_i32, c_i32, c_i32, c_i32, c_i32],
     "sx_gemv": [C.POINTER(GemvArgs), c_vp],
-    "sx_gemv_ssq_parts": [c_i32, c_i32],
+    "sx_gemv_ssq_parts": [c_i32, c_i32, c_i32],
     "sx_gemv_force_valu": [c_i32],
     "sx_layernorm": [c_vp, c_i32, c_vp, c_i32, c_vp, c_vp, c_i32, c_i32, c_f32, c_i32, c_vp],
     "sx_softmax_rows": [c_vp, c_i64, c_vp, c_i64, c_i32, c_i32, c_f32, c_i32, c_vp],

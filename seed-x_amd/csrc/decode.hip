@@ -108,17 +108,23 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvP p) {
 // non-temporal loads per lane; each load instruction covers one 64-B half line of 16 rows: lane group g = lane >> 4 reads
 // bytes [16g, 16g + 16) of it, which is exactly the MFMA's k-slot layout, no shuffle). 4 k-steps are in flight per wave
 // (8-16 KB). Partial sums meet in LDS; wave 0 runs the fused epilogue (act / GLU / fp32 residual / store).
-template <typename TT, int R, int NWV, int U>
+// TAIL (w_layout 2, R = 2): the workgroup owns 20 weight rows — MFMA row block 0 = rows 0..15, block 1 = rows 16..19 (its other
+// 12 operand rows read a zero line). N = 5120 is 320 16-row groups on 256 CUs: the 64 CUs that get two of them set the time
+// (o-proj 3.4 TB/s); as 256 groups of 20 every CU streams the same bytes and no cross-workgroup reduction is needed.
+__device__ const unsigned g_zero_line[16] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+
+template <typename TT, int R, int NWV, int U, bool TAIL = false>
 __global__ __launch_bounds__(NWV * 64) void gemm_skinny_kernel(const GemvP p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   typedef typename TT::vec8 vec8;
+  static_assert(!TAIL || R == 2, "the 20-row variant is two MFMA row blocks");
   __shared__ float red[NWV][R][64][4];
   // the wave index as a SCALAR: everything derived from it (k range, round counts) then lives in SGPRs and the guards below
   // are scalar branches. With a VGPR-derived count the compiler predicates the guarded MFMAs through EXEC instead — and
   // MFMA ignores EXEC: the skipped k-steps' (never loaded) registers were multiplied in (found by tools/lab/gemv_lab).
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = lane & 15, g = lane >> 4;
-  const int n0 = blockIdx.x * 16 * R;
+  const int n0 = TAIL ? blockIdx.x * 20 : blockIdx.x * 16 * R;
   const int nks = p.K >> 6;
   const int S = gridDim.y;                                           // split-K workgroups per row group (1 = none)
   const int nsl = NWV * S, sl = blockIdx.y * NWV + wave;             // k slices: split-K workgroups x waves
@@ -132,11 +138,19 @@ __global__ __launch_bounds__(NWV * 64) void gemm_skinny_kernel(const GemvP p) {
   // row-major W: a load instruction covers one 64-B half line of 16 rows (row stride 2K bytes). Decode layout: the same
   // instruction covers one contiguous 1-KB operand tile, a wave's k range is one contiguous stream.
   const unsigned short* wp[R];
-  const size_t kstep = p.packed ? 1024 : 64, khalf = p.packed ? 512 : 32;   // elements per 64-wide k-step / to its 2nd half
+  const size_t kstep = TAIL ? 1280 : (p.packed ? 1024 : 64), khalf = TAIL ? 640 : (p.packed ? 512 : 32);   // elements per 64-wide k-step / to its 2nd half
+  size_t kstep_q[R], khalf_q[R];
 #pragma unroll
-  for (int q = 0; q < R; ++q)
+  for (int q = 0; q < R; ++q) {
+    kstep_q[q] = kstep; khalf_q[q] = khalf;
     wp[q] = p.packed ? p.W + (size_t)(n0 / 16 + q) * (size_t)(p.K >> 5) * 512 + r * 32 + 8 * g
                      : p.W + (size_t)(n0 + q * 16 + r) * p.K + 8 * g;
+  }
+  if (TAIL) {   // [N/20][K/32][20 rows][32 k]: a 32-k slab of the group is 1280 B = rows 0..15 (the 1-KB MFMA tile) + rows 16..19
+    wp[0] = p.W + (size_t)blockIdx.x * (size_t)(p.K >> 5) * 640 + r * 32 + 8 * g;
+    if (r < 4) wp[R - 1] = wp[0] + 512;
+    else { wp[R - 1] = (const unsigned short*)g_zero_line; kstep_q[R - 1] = 0; khalf_q[R - 1] = 0; }   // operand rows 4..15 of block 1 = 0
+  }
   f32x4_t acc[R];
 #pragma unroll
   for (int q = 0; q < R; ++q) acc[q] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
@@ -178,8 +192,8 @@ __global__ __launch_bounds__(NWV * 64) void gemm_skinny_kernel(const GemvP p) {
         const size_t k = (size_t)(ks + u) * xstep;
 #pragma unroll
         for (int q = 0; q < R; ++q) {
-          f.wa[u][q] = __builtin_nontemporal_load((const u32x4_t*)(wp[q] + (size_t)(ks + u) * kstep));
-          f.wb[u][q] = __builtin_nontemporal_load((const u32x4_t*)(wp[q] + (size_t)(ks + u) * kstep + khalf));
+          f.wa[u][q] = __builtin_nontemporal_load((const u32x4_t*)(wp[q] + (size_t)(ks + u) * kstep_q[q]));
+          f.wb[u][q] = __builtin_nontemporal_load((const u32x4_t*)(wp[q] + (size_t)(ks + u) * kstep_q[q] + khalf_q[q]));
         }
         f.xa[u] = *(const u32x4_t*)(xp + k);
         f.xb[u] = *(const u32x4_t*)(xp + k + xhalf);
@@ -260,8 +274,9 @@ __global__ __launch_bounds__(NWV * 64) void gemm_skinny_kernel(const GemvP p) {
     for (int q = 0; q < R; ++q)
 #pragma unroll
       for (int e = 0; e < 4; ++e)
-        __hip_atomic_store(p.ws_part + ((size_t)blockIdx.y * 16 + r) * p.N + n0 + q * 16 + 4 * g + e, v[q][e], __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
+        if (!(TAIL && q == 1 && g != 0))
+          __hip_atomic_store(p.ws_part + ((size_t)blockIdx.y * 16 + r) * p.N + n0 + q * 16 + 4 * g + e, v[q][e], __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
     // No cache-wide fence (an agent-scope release / acquire writes back and invalidates the whole per-XCD L2 — measured 4x
     // slower kernels): the partials themselves move as agent-scope (sc1) atomics, which are performed at the device's
     // coherence point, so ordering them against the counter only needs "my stores are acknowledged" before the count and
@@ -277,9 +292,10 @@ __global__ __launch_bounds__(NWV * 64) void gemm_skinny_kernel(const GemvP p) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         float t = 0.f;
-        for (int sidx = 0; sidx < S; ++sidx)
-          t += __hip_atomic_load(p.ws_part + ((size_t)sidx * 16 + r) * p.N + n0 + q * 16 + 4 * g + e, __ATOMIC_RELAXED,
-                                 __HIP_MEMORY_SCOPE_AGENT);
+        if (!(TAIL && q == 1 && g != 0))
+          for (int sidx = 0; sidx < S; ++sidx)
+            t += __hip_atomic_load(p.ws_part + ((size_t)sidx * 16 + r) * p.N + n0 + q * 16 + 4 * g + e, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
         v[q][e] = t;
       }
     if (lane == 0) __hip_atomic_store(p.ws_cnt + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -295,6 +311,7 @@ __global__ __launch_bounds__(NWV * 64) void gemm_skinny_kernel(const GemvP p) {
 #pragma unroll
   for (int q = 0; q < (R == 2 ? 2 : 1); ++q) {
     if (!mvalid) break;
+    if (TAIL && q == 1 && g != 0) break;           // block 1 holds rows 16..19 only: output columns n0 + 16 .. n0 + 19 (lane group 0)
     f32x4_t o;
     int col;
     if (p.glu) {
@@ -828,7 +845,10 @@ static int g_force_valu_gemv = 0;   // test hook (sx_gemv_force_valu): compare t
 extern "C" int sx_gemv_force_valu(int on) { g_force_valu_gemv = on; return SX_OK; }   // 1 = VALU only, 2 = MFMA whenever legal
 
 // workgroups in x of the MFMA path (must mirror the r2 / gx choice in sx_gemv below)
-extern "C" int sx_gemv_ssq_parts(int N, int glu) { return (glu || N / 32 >= 256) ? N / 32 : N / 16; }
+extern "C" int sx_gemv_ssq_parts(int N, int glu, int w_layout) {
+  if (w_layout == 2) return N / 20;
+  return (glu || N / 32 >= 256) ? N / 32 : N / 16;
+}
 
 extern "C" int sx_gemv(const sx_gemv_args* a, void* stream) {
   SX_CHECK(a && a->x && a->W && a->y, "sx_gemv: null pointer");
@@ -842,7 +862,7 @@ extern "C" int sx_gemv(const sx_gemv_args* a, void* stream) {
   p.y_tiled = (a->out_dtype & SX_TILED16) ? 1 : 0;
   SX_CHECK(!p.y_tiled || ((p.out_dtype == SX_F16 || p.out_dtype == SX_BF16) && (a->glu ? a->N / 2 : a->N) % 32 == 0),
            "sx_gemv: SX_TILED16 needs a 16-bit output with n_out %% 32 == 0");
-  p.packed = a->w_layout;
+  p.packed = a->w_layout == 1 ? 1 : 0;
   p.ws_cnt = nullptr; p.ws_part = nullptr;
   p.x16_out = (unsigned short*)a->x16_out; p.ssq_out = a->row_ssq_out; p.ssq_in = a->row_ssq_in;
   p.ssq_parts = a->ssq_in_parts; p.ssq_inv_dim = a->ssq_dim > 0 ? 1.0f / (float)a->ssq_dim : 0.f; p.ssq_eps = a->ssq_eps;
@@ -853,7 +873,8 @@ extern "C" int sx_gemv(const sx_gemv_args* a, void* stream) {
            "sx_gemv: x16_out needs an fp32, non-GLU output with N %% 32 == 0");
   p.x_tiled = a->x_layout;
   SX_CHECK(a->x_layout == 0 || a->x_layout == 1, "sx_gemv: x_layout must be 0 (row-major) or 1 (operand tiles)");
-  SX_CHECK(a->w_layout == 0 || a->w_layout == 1, "sx_gemv: w_layout must be 0 (row-major) or 1 (decode tiles)");
+  SX_CHECK(a->w_layout >= 0 && a->w_layout <= 2, "sx_gemv: w_layout must be 0 (row-major), 1 (decode tiles) or 2 (20-row decode tiles)");
+  SX_CHECK(a->w_layout != 2 || (!a->glu && a->N % 20 == 0 && a->N % 32 == 0), "sx_gemv: w_layout 2 needs N %% 20 == 0, N %% 32 == 0, no GLU");
   // MI355X (tools/bench_gemv.py, 13B shapes): VALU path 6.5 / 4.7 / 3.0 TB/s at M = 1 / 4 / 8, MFMA path 4.0-4.4 TB/s at any M
   const bool mfma_ok = a->M >= 2 && a->K % 64 == 0 && a->K >= 256 && a->N % 32 == 0;
   SX_CHECK(!a->w_layout || (mfma_ok && a->K % 64 == 0), "sx_gemv: the decode-tile layout needs M >= 2, K %% 64 == 0, K >= 256, N %% 32 == 0");
@@ -862,13 +883,14 @@ extern "C" int sx_gemv(const sx_gemv_args* a, void* stream) {
   SX_CHECK(!a->x_layout || mfma_ok, "sx_gemv: tiled x needs the MFMA path (M >= 2, K %% 64 == 0, K >= 256, N %% 32 == 0)");
   if (mfma_ok && (a->w_layout || a->x_layout || p.y_tiled || (g_force_valu_gemv != 1 && (a->M >= 5 || g_force_valu_gemv == 2)))) {
     // MFMA skinny GEMM: R = 2 row groups per wave for GLU (one packed group) or when that still gives >= 256 blocks
-    const bool r2 = a->glu || a->N / 32 >= 256;
-    const int gx = r2 ? a->N / 32 : a->N / 16;
+    const bool tail20 = a->w_layout == 2;
+    const bool r2 = !tail20 && (a->glu || a->N / 32 >= 256);
+    const int gx = tail20 ? a->N / 20 : (r2 ? a->N / 32 : a->N / 16);
     // split-K over workgroups when the row groups alone do not fill the chip (N = 5120: 320 workgroups on 256 CUs, the CUs
     // with two of them set the time) AND the kernel is long enough to pay for the second pass (publish, count, re-read: ~4 us
     // at the kernel's tail): tools/lab/gemv_lab — down 5120x13824 36.8 -> 33.0 us with S = 4, o 5120x5120 15.4 -> 17.6 (never)
     int S = 1;
-    if (a->workspace) {
+    if (a->workspace && !(tail20 && g_skinny_var[2] <= 0)) {      // 256 balanced 20-row groups: no split unless forced (lab)
       if (g_skinny_var[2] > 0) S = g_skinny_var[2];
       else if (g_skinny_var[2] == 0 && a->K >= 8192) while (S < 8 && gx * S < 1024 && (a->K / 64) / (2 * S * 4) >= 4) S *= 2;
       const uint64_t cnt_bytes = 16384;    // fixed, so launches of different N can share one workspace (their partial regions
@@ -879,7 +901,8 @@ extern "C" int sx_gemv(const sx_gemv_args* a, void* stream) {
     }
     const dim3 grid(gx, S);
 #define SX_SK_GO(TT)                                                                                   \
-    if (r2) hipLaunchKernelGGL((gemm_skinny_kernel<TT, 2, 4, 4>), grid, dim3(256), 0, ST, p);           \
+    if (tail20) hipLaunchKernelGGL((gemm_skinny_kernel<TT, 2, 4, 4, true>), grid, dim3(256), 0, ST, p);  \
+    else if (r2) hipLaunchKernelGGL((gemm_skinny_kernel<TT, 2, 4, 4>), grid, dim3(256), 0, ST, p);      \
     else hipLaunchKernelGGL((gemm_skinny_kernel<TT, 1, 4, 4>), grid, dim3(256), 0, ST, p);
     if (a->dtype == SX_BF16) { SX_SK_GO(BF16) } else { SX_SK_GO(F16) }
 #undef SX_SK_GO

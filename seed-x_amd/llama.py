@@ -191,6 +191,7 @@ class LlamaForCausalLM:
         # wgu of every layer (post_attention_layernorm) and wqkv of layers >= 1 (input_layernorm; layer 0's input comes from the
         # embedding, not from a GEMV). Prefill keeps the row-major, unfolded weights and the norm kernel.
         fold = self.G >= 5 and tp == 1 and os.environ.get("SX_RMS_FOLD", "1") != "0"      # (0: A/B switch, tools/)
+        bal20 = self.G >= 5 and os.environ.get("SX_GEMV_BAL20", "1") != "0"
         for i in range(self.L):
             p = f"model.layers.{i}."
             sh = llama_tp_shard(sd, p, r, tp, self.nh, self.hd)
@@ -202,6 +203,12 @@ class LlamaForCausalLM:
             lw = P["layers"][-1]
             for k in ("wqkv", "wo", "wgu", "wd"):
                 lw[k + "_t"] = tiles(lw[k])
+            # N = 5120 output rows are 320 16-row groups on 256 CUs; as 256 groups of 20 rows every CU streams the same bytes
+            # (sx_gemv w_layout 2) — the o and down projections of the 13B geometry
+            for k in ("wo", "wd"):
+                lw[k + "_t20"] = None
+                if bal20 and lw[k + "_t"] is not None and lw[k].shape[0] % 20 == 0 and lw[k].shape[0] // 20 == 256:
+                    lw[k + "_t20"] = ops.pack_decode_tiles20(lw[k])
             if fold and lw["wgu_t"] is not None and lw["wqkv_t"] is not None:
                 g2 = lw["ln2"][None, :]
                 lw["wgu_t"] = tiles(glu_pack_rows((sh["up"].detach().to(dev, torch.float32) * g2).to(dt),
@@ -330,20 +337,21 @@ class LlamaForCausalLM:
                 att = ops.attn_decode_b(q, P["kc"][li], P["vc"][li], P["ctx"], scale, nsplit=self.decode_nsplit, out_tiled=tl)
             if fold:
                 x, x16, ssq = ops.gemv(att, lw["wo"], residual=x, out_dtype=torch.float32, w_tiles=lw["wo_t"], workspace=ws,
-                                       emit_norm=True)
+                                       emit_norm=True, w_tiles20=lw["wo_t20"])
                 g = ops.gemv(x16, lw["wgu"], act="silu", glu=True, w_tiles=lw["wgu_t"], y_tiled=True, ssq_in=(ssq, self.H, eps))
                 if li + 1 < nl:
                     x, x16, ssq = ops.gemv(g, lw["wd"], residual=x, out_dtype=torch.float32, w_tiles=lw["wd_t"], workspace=ws,
-                                           emit_norm=True)
+                                           emit_norm=True, w_tiles20=lw["wd_t20"])
                 else:                        # the final norm needs fp32 states (hidden-state output): its own launch
-                    x = ops.gemv(g, lw["wd"], residual=x, out_dtype=torch.float32, w_tiles=lw["wd_t"], workspace=ws)
+                    x = ops.gemv(g, lw["wd"], residual=x, out_dtype=torch.float32, w_tiles=lw["wd_t"], workspace=ws,
+                                 w_tiles20=lw["wd_t20"])
                 continue
             x = comm.all_reduce(ops.gemv(att, lw["wo"], residual=x if lead else None, out_dtype=torch.float32,
-                                         w_tiles=lw["wo_t"], workspace=ws))
+                                         w_tiles=lw["wo_t"], workspace=ws, w_tiles20=lw["wo_t20"] if tl else None))
             h = ops.rmsnorm(x, lw["ln2"], eps, dt, tiled=tl)
             g = ops.gemv(h, lw["wgu"], act="silu", glu=True, w_tiles=lw["wgu_t"], y_tiled=tl)
             x = comm.all_reduce(ops.gemv(g, lw["wd"], residual=x if lead else None, out_dtype=torch.float32,
-                                         w_tiles=lw["wd_t"], workspace=ws))
+                                         w_tiles=lw["wd_t"], workspace=ws, w_tiles20=lw["wd_t20"] if tl else None))
         ops.add_i32(P["pos"], 1)
         ops.add_i32(P["ctx"], 1)
         return x

@@ -171,6 +171,14 @@ def pack_decode_tiles(w):
     return w.view(N // 16, 16, K // 32, 32).permute(0, 2, 1, 3).contiguous().view(N, K)
 
 
+def pack_decode_tiles20(w):
+    """Row-major [N, K] 16-bit weight → 20-row decode tiles [N/20][K/32][20][32] (sx_gemv w_layout 2): a 32-k slab of a 20-row
+    group is 1280 contiguous bytes = the 1-KB MFMA operand tile of rows 0..15 followed by rows 16..19."""
+    N, K = w.shape
+    assert N % 20 == 0 and K % 32 == 0
+    return w.view(N // 20, 20, K // 32, 32).permute(0, 2, 1, 3).contiguous().view(N, K)
+
+
 class Tiled16:
     """A [rows <= 16, cols] 16-bit activation of the decode step held as MFMA operand tiles [cols/32][16][32] (SX_TILED16 in
     include/seedx_hip.h): what the skinny GEMM reads with one contiguous 1-KB load per operand. Rows >= `rows` are padding."""
@@ -190,18 +198,19 @@ class Tiled16:
 
 
 def gemv(x, w, residual=None, act=None, glu=False, out_dtype=None, w_tiles=None, y_tiled=False, workspace=None,
-         emit_norm=False, ssq_in=None):
+         emit_norm=False, ssq_in=None, w_tiles20=None):
     """w_tiles: the same weight in the decode layout (pack_decode_tiles); used instead of w when the MFMA path runs.
     x may be a Tiled16 (then w_tiles is required); y_tiled returns the 16-bit result as a Tiled16 for the next gemv.
     workspace: zero-initialised uint8 scratch enabling split-K over workgroups for shapes that need it (sx_gemv_args.workspace).
     RMSNorm fold (sx_gemv_args.x16_out / row_ssq_*; MFMA path, tiled x): ``emit_norm`` (fp32 residual outputs) → returns
     (y, x16, ssq): y also as 16-bit operand tiles and the rows' sums of squares per workgroup; ``ssq_in`` = (ssq, dim, eps) of
-    the producer → the accumulators are scaled by rsqrt(sum(ssq) / dim + eps) (gamma lives in this launch's weights)."""
+    the producer → the accumulators are scaled by rsqrt(sum(ssq) / dim + eps) (gamma lives in this launch's weights).
+    w_tiles20: the weight as 20-row decode tiles (pack_decode_tiles20) instead of w_tiles: one workgroup per 20 rows."""
     lib = _lib.load()
     xt = isinstance(x, Tiled16)
     if xt:
         M, K = x.rows, x.cols
-        assert w_tiles is not None and x.dtype == w.dtype
+        assert (w_tiles is not None or w_tiles20 is not None) and x.dtype == w.dtype
     else:
         assert x.dim() == 2 and x.is_contiguous() and w.is_contiguous() and x.dtype == w.dtype
         M, K = x.shape
@@ -229,11 +238,14 @@ def gemv(x, w, residual=None, act=None, glu=False, out_dtype=None, w_tiles=None,
     if w_tiles is not None and (xt or y_tiled or M >= 5) and K % 64 == 0 and K >= 256 and N % 32 == 0:
         assert w_tiles.shape == w.shape and w_tiles.dtype == w.dtype and w_tiles.is_contiguous()
         args.W, args.w_layout = w_tiles.data_ptr(), 1
+    if w_tiles20 is not None and not glu and (xt or y_tiled or M >= 5) and K % 64 == 0 and K >= 256 and N % 32 == 0 and N % 20 == 0:
+        assert w_tiles20.shape == w.shape and w_tiles20.dtype == w.dtype and w_tiles20.is_contiguous()
+        args.W, args.w_layout = w_tiles20.data_ptr(), 2
     x16 = ssq = None
     if emit_norm:
-        assert args.w_layout == 1 and out_dtype == torch.float32 and not glu and not y_tiled
+        assert args.w_layout in (1, 2) and out_dtype == torch.float32 and not glu and not y_tiled
         x16 = Tiled16(M, n_out, w.dtype, dev)
-        ssq = torch.empty((16, lib.sx_gemv_ssq_parts(N, 0)), dtype=torch.float32, device=dev)      # [row][workgroup]
+        ssq = torch.empty((16, lib.sx_gemv_ssq_parts(N, 0, args.w_layout)), dtype=torch.float32, device=dev)      # [row][workgroup]
         args.x16_out, args.row_ssq_out = x16.t.data_ptr(), ssq.data_ptr()
     if ssq_in is not None:
         t, dim, eps = ssq_in

@@ -664,6 +664,15 @@ def test_gemv_rmsnorm_fold(dev, dtype, M):
         ref_ssq = (y.double() ** 2).sum(dim=1)
         got = ssq.double().sum(dim=1)[:M]
         assert torch.allclose(got, ref_ssq, rtol=1e-5), (got, ref_ssq)
+        # the same launch over 20-row decode tiles (w_layout 2: 256 equal workgroups for N = 5120) gives the same bits
+        w20 = ops.pack_decode_tiles20(w)
+        y20, x16b, ssq20 = ops.gemv(at, w, residual=res, out_dtype=torch.float32, w_tiles20=w20, workspace=ws, emit_norm=True)
+        assert ssq20.shape == (16, 256) and torch.equal(x16b.dense(), y20.to(dtype))
+        # K = 5120: same per-wave k ranges and MFMA order → the same bits; K = 13824: the 16-row path splits K over 4 workgroups
+        # (another summation order), the balanced path does not
+        assert torch.equal(y20, y_plain) if K == 5120 else relerr(y20, y_plain) < 2e-6
+        assert torch.allclose(ssq20.double().sum(dim=1)[:M], (y20.double() ** 2).sum(dim=1), rtol=1e-5)
+        assert torch.equal(ops.gemv(at, w, residual=res, out_dtype=torch.float32, w_tiles20=w20), y20)
         # consumer: qkv-like (plain) and gate|up-like (SiLU-GLU) projections behind the norm
         gamma = (1.0 + 0.1 * torch.randn(H, generator=g)).to(dev)
         for N, glu in ((15360, False), (2 * 13824, True)):
