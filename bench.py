@@ -158,26 +158,32 @@ def preprocess(images, dev):
     return torch.cat(tens, dim=0), torch.cat(pos, dim=0)
 
 
-def requests_for(vit, inp, dev):
-    """Path A for BATCH requests (preprocessing + ViT on all BATCH·n_crops crops at once) → generate_batch requests."""
+def requests_for(vit, inp, dev, vit_comm=None):
+    """Path A for BATCH requests (preprocessing + ViT on all BATCH·n_crops crops at once) → generate_batch requests.
+    vit_comm (latency mode, tools/bench_tp_latency.py): the crops are split over the ranks and the features all-gathered."""
     from seedx_amd import image_ops
     images, ids = inp
     G = BATCH
     T = BenchTokenizer
     crops, ppos = preprocess(images, dev)                                      # identical image per request: preprocess once
     n = crops.shape[0]                                                         # per request … but run the ViT on every crop
-    emb = vit(crops if G == 1 else crops.repeat(G, 1, 1, 1))                   # [G·n, 256, 4096]
+    allc = crops if G == 1 else crops.repeat(G, 1, 1, 1)
+    if vit_comm is not None and vit_comm.world > 1:
+        from seedx_amd.parallel import split_batch_forward
+        emb = split_batch_forward(vit, allc, vit_comm)
+    else:
+        emb = vit(allc)                                                        # [G·n, 256, 4096]
     ids_dev = torch.tensor(ids, dtype=torch.long, device=dev)
     mask = image_ops.marker_mask(ids_dev, T.BOI, T.EOI, T.BOP, T.EOP).view(1, -1)   # eval_img2text_seed_x_i.py:153-160
     return [dict(input_ids=[ids], image_embeds=emb[n * g:n * (g + 1)], embeds_cmp_mask=torch.tensor([True] * n),
                  ids_cmp_mask=mask, patch_positions=ppos) for g in range(G)]
 
 
-def front_half(vit, agent, tok, inp, n_text, dev=None):
+def front_half(vit, agent, tok, inp, n_text, dev=None, vit_comm=None):
     """Paths A + B for BATCH requests: GPU preprocessing, ViT on all crops at once, then the BATCH greedy decodes in lock
     step. Returns the image-generation features [BATCH, 64, 4096]."""
     dev = dev or agent.llm.device
-    reqs = requests_for(vit, inp, dev)
+    reqs = requests_for(vit, inp, dev, vit_comm=vit_comm)
     outs = agent.generate_batch(tok, reqs, max_new_tokens=n_text + 66 + 1, eos_token_id=None,
                                 force_image_at=n_text)                          # path B, G sequences in lock step
     for out in outs:

@@ -407,8 +407,20 @@ typedef struct sx_oneshot_args {
   int32_t n, cap, rank, world;
   uint32_t max_spin;  /* 0 = default (2^22 polls, a few seconds)                                                       */
   int32_t chunk;      /* floats per workgroup, even, divides cap; 0 = SX_ONESHOT_CHUNK. Fixed for the life of the buffers */
+  int32_t mode;       /* 0: all-reduce / all-gather among all ranks. 1: NEIGHBOUR exchange (the row-sharded UNet's conv halo rows,
+                       * seqpar.py): data = [my last row | my first row] (n floats, n even), gather_out[n] receives [last row of rank - 1 |
+                       * first row of rank + 1] (zeros at the ends of the chain); a rank signals and waits for its one or two
+                       * neighbours only. Use a communicator of its own for this mode (its epochs must not interleave with mode 0:
+                       * a slot is reused once the NEIGHBOURS have moved on) */
+  int32_t reserved;
 } sx_oneshot_args;
 int sx_allreduce_oneshot(const sx_oneshot_args* args, void* stream);
+
+/* Row-sharded 3x3 convolution input (seqpar.with_halo): out[B][Hl + 1 (+1 if bottom)][W + left_col][C] 16-bit = the local slab
+ * x[B][Hl][W][C] with the neighbour rows above (prev_row[B][W][C], NULL = zeros: image border) and below (next_row) and, with
+ * left_col, a zero column on the left — one launch instead of torch.zeros + three slice copies. C % 8 == 0. */
+int sx_halo_pack(const void* x, const void* prev_row, const void* next_row, void* out, int B, int Hl, int W, int C, int left_col,
+                 int bottom, void* stream);
 
 #ifdef __cplusplus
 }

@@ -37,7 +37,8 @@ class GemvArgs(C.Structure):
 
 class OneshotArgs(C.Structure):
     _fields_ = [("data", c_vp), ("gather_out", c_vp), ("stage", c_vp), ("flags", c_vp), ("epoch", c_vp), ("status", c_vp),
-                ("n", c_i32), ("cap", c_i32), ("rank", c_i32), ("world", c_i32), ("max_spin", C.c_uint32), ("chunk", c_i32)]
+                ("n", c_i32), ("cap", c_i32), ("rank", c_i32), ("world", c_i32), ("max_spin", C.c_uint32), ("chunk", c_i32),
+                ("mode", c_i32), ("reserved", c_i32)]
 
 
 class AttnDecodeArgs(C.Structure):
@@ -94,6 +95,7 @@ SIGNATURES = {
     "sx_ipc_open": [C.c_char_p, C.POINTER(c_vp)],
     "sx_ipc_close": [c_vp],
     "sx_allreduce_oneshot": [C.POINTER(OneshotArgs), c_vp],
+    "sx_halo_pack": [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp],
     "sx_attention_small": [C.POINTER(AttnSmallArgs), c_vp],
     "sx_attn_decode": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_i32, c_vp],
     "sx_rope_kv_append": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp],

@@ -31,6 +31,7 @@ struct ArP {
   unsigned* status;            // != 0 after a timeout
   int n, cap, rank, world, chunk;
   unsigned max_spin;
+  int nb;                      // neighbour mode: signal / wait for rank - 1 and rank + 1 only; gather_out[n] = [prev's first half | next's second half]
 };
 
 // Cross-rank data moves as 8-byte (two floats) or 4-byte system-scope relaxed atomics: plain global_load/store … sc0 sc1, tracked
@@ -67,7 +68,8 @@ __global__ __launch_bounds__(1024) void oneshot_kernel(const ArP p) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   // 2. signal every peer, 3. wait for every peer (threads 0 .. world-1, one peer each)
-  if (tid < p.world) {
+  const bool is_peer = p.nb ? (tid == p.rank - 1 || tid == p.rank + 1) : true;    // (a rank is its own peer in mode 0: the flag it polls)
+  if (tid < p.world && is_peer) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __hip_atomic_store(p.flags[tid] + (size_t)b * p.world + p.rank, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     const unsigned* f = p.flags[p.rank] + (size_t)b * p.world + tid;
@@ -86,7 +88,18 @@ __global__ __launch_bounds__(1024) void oneshot_kernel(const ArP p) {
     return;
   }
   // 4. reduce in rank order / gather
-  if (p.gather_out) {
+  if (p.nb) {
+    // neighbour exchange: element i < n/2 comes from rank - 1 (its last row), i >= n/2 from rank + 1 (its first row) — the SAME
+    // index in the neighbour's slot, so chunk b only reads what the neighbour's chunk b published
+    const int half = p.n >> 1;
+    float* dst = p.gather_out + lo;
+    for (int i = 2 * tid; i < cnt; i += 2 * T) {
+      const int src_rank = (lo + i < half) ? p.rank - 1 : p.rank + 1;
+      float2 v2 = {0.f, 0.f};
+      if (src_rank >= 0 && src_rank < p.world) v2 = ld_sys2(p.stage[src_rank] + slot + i);
+      *(float2*)(dst + i) = v2;
+    }
+  } else if (p.gather_out) {
     for (int r = 0; r < p.world; ++r) {
       const float* src = p.stage[r] + slot;
       float* dst = p.gather_out + (size_t)r * p.n + lo;
@@ -170,6 +183,10 @@ extern "C" int sx_allreduce_oneshot(const sx_oneshot_args* a, void* stream) {
   p.n = a->n; p.cap = a->cap; p.rank = a->rank; p.world = a->world;
   p.chunk = a->chunk > 0 ? a->chunk : SX_ONESHOT_CHUNK;
   SX_CHECK((p.chunk & 1) == 0 && a->cap % p.chunk == 0, "sx_allreduce_oneshot: chunk %d must be even and divide the capacity %d", p.chunk, a->cap);
+  p.nb = a->mode == 1 ? 1 : 0;
+  SX_CHECK(a->mode == 0 || a->mode == 1, "sx_allreduce_oneshot: mode %d", a->mode);
+  SX_CHECK(!p.nb || (a->gather_out && a->n % 4 == 0 && (((uintptr_t)a->data | (uintptr_t)a->gather_out) & 7) == 0),
+           "sx_allreduce_oneshot: neighbour mode needs gather_out, n %% 4 == 0 and 8-byte aligned buffers");
   p.max_spin = a->max_spin ? a->max_spin : (1u << 24);     // ~16 s of polling: rank skew from lazy module loads is seconds
   hipLaunchKernelGGL(oneshot_kernel, dim3((a->n + p.chunk - 1) / p.chunk), dim3(1024), 0, (hipStream_t)stream, p);
   SX_HIP_LAUNCH_CHECK();

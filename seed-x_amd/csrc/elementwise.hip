@@ -317,3 +317,40 @@ extern "C" int sx_silu_cast(const float* x, void* y, int dtype, int64_t n, void*
   SX_HIP_LAUNCH_CHECK();
   return SX_OK;
 }
+
+
+// ---- row-sharded conv input: slab + neighbour rows + zero borders in one pass (seqpar.with_halo) ---------------------------
+namespace sxk_elem_halo {
+__global__ __launch_bounds__(256) void halo_pack_kernel(const u32x4_t* x, const u32x4_t* prev, const u32x4_t* next, u32x4_t* out, int B,
+                                                        int Hl, int W, int c16, int off, int rows) {
+  // one 16-B piece (8 channels) of the output per thread
+  const long long total = (long long)B * rows * (W + off) * c16;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % c16);
+    long long t = i / c16;
+    const int col = (int)(t % (W + off));
+    t /= (W + off);
+    const int row = (int)(t % rows), b = (int)(t / rows);
+    u32x4_t v = {0u, 0u, 0u, 0u};
+    const int sc = col - off;
+    if (sc >= 0) {
+      if (row == 0) { if (prev) v = prev[((long long)b * W + sc) * c16 + c]; }
+      else if (row <= Hl) v = x[(((long long)b * Hl + (row - 1)) * W + sc) * c16 + c];
+      else if (next) v = next[((long long)b * W + sc) * c16 + c];
+    }
+    out[i] = v;
+  }
+}
+}  // namespace sxk_elem_halo
+
+extern "C" int sx_halo_pack(const void* x, const void* prev_row, const void* next_row, void* out, int B, int Hl, int W, int C,
+                            int left_col, int bottom, void* stream) {
+  SX_CHECK(x && out && B > 0 && Hl > 0 && W > 0 && C > 0 && C % 8 == 0, "sx_halo_pack: bad arguments (C %% 8 == 0)");
+  const int rows = Hl + 1 + (bottom ? 1 : 0), off = left_col ? 1 : 0;
+  const long long total = (long long)B * rows * (W + off) * (C / 8);
+  const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+  hipLaunchKernelGGL(sxk_elem_halo::halo_pack_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const u32x4_t*)x,
+                     (const u32x4_t*)prev_row, (const u32x4_t*)(bottom ? next_row : nullptr), (u32x4_t*)out, B, Hl, W, C / 8, off, rows);
+  SX_HIP_LAUNCH_CHECK();
+  return SX_OK;
+}

@@ -42,6 +42,17 @@ class Comm:
     def barrier(self):
         pass
 
+    def halo_exchange(self, edges):
+        """edges: [2, ...] = (my FIRST row, my LAST row) of a row-sharded slab → [2, ...] = (LAST row of rank - 1, FIRST row of
+        rank + 1); zeros where there is no neighbour. Default: an all-gather of everybody's edge rows (any backend)."""
+        allr = self.all_gather(edges.contiguous())                               # [world, 2, ...]
+        out = torch.zeros_like(edges)
+        if self.rank > 0:
+            out[0] = allr[self.rank - 1, 1]
+        if self.rank < self.world - 1:
+            out[1] = allr[self.rank + 1, 0]
+        return out
+
     def require_capacity(self, n_floats):
         """Called by a model that will CAPTURE collectives of up to n_floats fp32 elements into a HIP graph: a communicator
         that could not run such a payload inside a capture raises here, at load time, instead of failing mid-capture."""
@@ -113,7 +124,7 @@ class IpcComm(Comm):
 
     CHUNK = 4096                               # floats per workgroup (SX_ONESHOT_CHUNK in include/seedx_hip.h)
 
-    def __init__(self, bootstrap=None, cap_floats=131072, device=None, max_spin=0, graph_safe=True):
+    def __init__(self, bootstrap=None, cap_floats=131072, device=None, max_spin=0, graph_safe=True, neighbor_only=False):
         import ctypes as C
         import torch.distributed as dist
         from . import _lib
@@ -121,6 +132,9 @@ class IpcComm(Comm):
         # graph_safe=False: for callers whose payloads also take the bootstrap-group fallback (the row-sharded UNet: halo rows
         # fit the one-shot kernel, the K|V gathers and fp64 GroupNorm sums go to RCCL) — an RCCL call cannot be captured
         self.graph_safe = bool(graph_safe)
+        # neighbor_only: this communicator ONLY runs halo exchanges (sx_oneshot_args.mode 1: a rank signals / waits for rank ± 1);
+        # its epochs must not interleave with all-rank collectives, so halo_exchange() of an ordinary IpcComm builds one lazily
+        self.neighbor_only, self._halo = bool(neighbor_only), None
         self.rank, self.world = dist.get_rank(bootstrap), dist.get_world_size(bootstrap)
         self.cap, self.max_spin = -(-int(cap_floats) // self.CHUNK) * self.CHUNK, int(max_spin)
         nchunk = self.cap // self.CHUNK
@@ -160,10 +174,41 @@ class IpcComm(Comm):
             torch.cuda.synchronize()
         dist.barrier(group=bootstrap)          # every rank has opened every handle before the first collective
 
-    def _launch(self, t, gather_out=None):
+    def halo_exchange(self, edges):
+        """Neighbour-only exchange over the peer-mapped staging buffers: ONE launch, 2 x row bytes in and out, no all-gather of
+        every rank's edge rows (sx_oneshot_args.mode 1). 16-bit rows travel as 32-bit words."""
+        if not self.neighbor_only:
+            if self._halo is None:                       # collective: every rank reaches its first halo exchange together
+                self._halo = IpcComm(self.group, cap_floats=self.cap, device=self.device, max_spin=self.max_spin,
+                                     graph_safe=self.graph_safe, neighbor_only=True)
+            return self._halo.halo_exchange(edges)
+        e = edges.contiguous()
+        assert e.shape[0] == 2 and e.is_cuda
+        send = torch.stack([e[1], e[0]], dim=0).contiguous()                    # [my last row | my first row]
+        nbytes = send.numel() * send.element_size()
+        if nbytes % 16 or nbytes // 4 > self.cap or (send.storage_offset() * send.element_size()) % 8:
+            return self._halo_fallback(edges)
+        out = torch.empty_like(send)
+        self._launch(send.view(-1).view(torch.float32), gather_out=out.view(-1).view(torch.float32), mode=1)
+        return out
+
+    def _halo_fallback(self, edges):
+        self._fallback_guard(edges, "halo_exchange")
+        parts = [torch.empty_like(edges) for _ in range(self.world)]
+        self._dist.all_gather(parts, edges.contiguous(), group=self.group)
+        out = torch.zeros_like(edges)
+        if self.rank > 0:
+            out[0] = parts[self.rank - 1][1]
+        if self.rank < self.world - 1:
+            out[1] = parts[self.rank + 1][0]
+        return out
+
+    def _launch(self, t, gather_out=None, mode=0):
         import ctypes as C
         from . import _lib
+        assert mode == 1 or not self.neighbor_only, "a neighbor_only IpcComm runs halo exchanges only"
         a = _lib.OneshotArgs()
+        a.mode = mode
         a.data, a.gather_out = t.data_ptr(), (gather_out.data_ptr() if gather_out is not None else None)
         a.stage, a.flags = self._stage.data_ptr(), self._flags.data_ptr()
         a.epoch, a.status = self._epoch.data_ptr(), self._status.data_ptr()
@@ -226,6 +271,9 @@ class IpcComm(Comm):
         self._dist.barrier(group=self.group)
 
     def close(self):
+        if getattr(self, "_halo", None) is not None:
+            self._halo.close()
+            self._halo = None
         for p in getattr(self, "_opened", []):
             self._lib.sx_ipc_close(p)
         for p in getattr(self, "_own", []):
@@ -303,6 +351,28 @@ def run_virtual_ranks(world, fn):
         if e is not None:
             raise e
     return out
+
+
+# ---- batch split of an embarrassingly parallel forward (the ViT over an image's crops) --------------------------------------
+def split_batch_forward(fn, x, comm):
+    """y = fn(x) with the leading (batch) dimension of x split over the ranks of `comm` and the results all-gathered back in order:
+    rank r runs fn on items r, r + world, r + 2·world, … — no communication inside fn. SURVEY.md §8(e) "ViT partitioning": the
+    any-res crops of an image are independent (B = 2 … 20, any_res.py:185-189), so in latency mode each GPU encodes its share of
+    the crops instead of every GPU encoding all of them. Every rank must call it (collective); fn sees at least one item on every
+    rank (a rank without work re-encodes item 0 and its result is dropped), so fn never runs on an empty batch."""
+    world, rank = comm.world, comm.rank
+    B = x.shape[0]
+    if world == 1 or B == 1:
+        return fn(x)
+    per = -(-B // world)                                   # items per rank, the last ranks may hold padding
+    idx = [i for i in range(rank, B, world)]
+    pad = per - len(idx)
+    sel = torch.as_tensor(idx + [0] * pad, device=x.device)
+    y = fn(x.index_select(0, sel)).contiguous()            # [per, ...]
+    g = comm.all_gather(y)                                 # [world, per, ...]
+    # item i lives at g[i % world, i // world]
+    out = g.transpose(0, 1).reshape((per * world,) + tuple(y.shape[1:]))[:B]
+    return out.contiguous()
 
 
 # ---- Megatron sharding of the reference Llama state dict (pure tensor slicing; CPU-testable) ------------------------------

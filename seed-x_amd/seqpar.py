@@ -8,7 +8,8 @@ of every sample instead keeps every linear layer, LayerNorm, cross-attention, re
 
   * self-attention: all-gather of the local K | V rows ([Bc, N/tp, 2C] 16-bit per rank, 70 per forward, ≈0.35 GB per
     step at Bc = 2) — issued right after the K|V projection and overlapped with the Q projection
-  * 3x3 convolutions: one halo row above and below the local slab (all-gather of 2 rows per rank)
+  * 3x3 convolutions: one halo row above and below the local slab — a neighbour-only exchange (Comm.halo_exchange: one launch over
+    the hipIpc peer buffers with IpcComm, an all-gather of the edge rows on other backends), packed with the slab by sx_halo_pack
   * GroupNorm: all-reduce of the fp64 per-(sample, group) sum / sum-of-squares ([Bc, 32, 2] doubles)
   * the final eps rows → all-gather in front of the (replicated) CFG + Euler update
 
@@ -40,17 +41,28 @@ def with_halo(x_l, comm, Hl, W, left_col=False, bottom=True):
     zeros at the image border. ``left_col`` adds a zero column on the left (stride-2 convolutions, see unet.py)."""
     B, _, C = x_l.shape
     x4 = x_l.view(B, Hl, W, C)
-    edges = torch.stack([x4[:, 0], x4[:, -1]], dim=1).contiguous()          # [B, 2, W, C]: my first and last row
-    allr = comm.all_gather(edges)                                           # [tp, B, 2, W, C]
+    edges = torch.stack([x4[:, 0], x4[:, -1]], dim=0).contiguous()          # [2, B, W, C]: my first and last row
+    nb = comm.halo_exchange(edges)                                          # [2, B, W, C]: last row of rank - 1, first row of rank + 1
     r, tp = comm.rank, comm.world
     rows = Hl + 1 + (1 if bottom else 0)
     off = 1 if left_col else 0
+    if x_l.is_cuda and x_l.element_size() == 2 and C % 8 == 0:
+        # slab + neighbour rows + zero borders in ONE launch (sx_halo_pack)
+        from . import _lib
+        out = torch.empty((B, rows, W + off, C), dtype=x_l.dtype, device=x_l.device)
+        lib = _lib.load()
+        prev = nb[0].contiguous() if r > 0 else None
+        nxt = nb[1].contiguous() if (bottom and r < tp - 1) else None
+        _lib.check(lib.sx_halo_pack(x4.contiguous().data_ptr(), prev.data_ptr() if prev is not None else None,
+                                    nxt.data_ptr() if nxt is not None else None, out.data_ptr(), B, Hl, W, C, off, 1 if bottom else 0,
+                                    torch.cuda.current_stream().cuda_stream), "sx_halo_pack")
+        return out
     out = torch.zeros((B, rows, W + off, C), dtype=x_l.dtype, device=x_l.device)
     out[:, 1:Hl + 1, off:] = x4
     if r > 0:
-        out[:, 0, off:] = allr[r - 1, :, 1]
+        out[:, 0, off:] = nb[0]
     if bottom and r < tp - 1:
-        out[:, Hl + 1, off:] = allr[r + 1, :, 0]
+        out[:, Hl + 1, off:] = nb[1]
     return out
 
 

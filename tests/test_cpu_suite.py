@@ -504,6 +504,24 @@ def test_seqpar_shard_arithmetic_two_ranks_gloo_and_virtual_ranks():
     assert res == [(0, True), (1, True)]
 
 
+def test_split_batch_forward_virtual_ranks_cpu():
+    """ViT crop split of the latency mode (parallel.split_batch_forward): every rank encodes its share of the batch, the
+    all-gathered result equals the unsplit forward in item order — ragged shares (B not a multiple of the world), B < world."""
+    from seedx_amd.parallel import run_virtual_ranks, split_batch_forward
+    fn = lambda t: torch.cat([t * 2 + 1, t.flip(-1)], dim=-1)
+    for world in (2, 4, 8):
+        for B in (1, 2, 5, 20):                       # 2 crops (one 448 px image), 5 (896 px), 20 (BASELINE config 5)
+            x = torch.arange(B * 6, dtype=torch.float32).view(B, 2, 3)
+            calls = []
+
+            def counted(t):
+                calls.append(t.shape[0])
+                return fn(t)
+            outs = run_virtual_ranks(world, lambda c: split_batch_forward(counted, x, c))
+            assert all(torch.equal(o, fn(x)) for o in outs), (world, B)
+            assert B == 1 or max(calls) == -(-B // world)          # no rank encodes more than its share
+
+
 def test_thread_comm_virtual_ranks_cpu():
     from seedx_amd.parallel import run_virtual_ranks
 

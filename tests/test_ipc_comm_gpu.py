@@ -4,7 +4,9 @@ flags sized by the world, system-scope visibility, HIP-graph capture of the coll
 Multi-GPU timing over xGMI remains unmeasured.
   * all-reduce: bit-identical to the rank-ordered sum (= ThreadComm's `parts[0] + parts[1]`) for payloads from 4 B to the
     staging capacity, 300 back-to-back epochs (slot reuse), then captured into a HIP graph and replayed
-  * all-gather through the same staging (fp32, and 16-bit payloads as 32-bit words: the UNet's conv halo rows)
+  * all-gather through the same staging (fp32, and 16-bit payloads as 32-bit words)
+  * the row-sharded UNet's conv halo rows as a NEIGHBOUR-ONLY exchange (mode 1: a rank signals / waits for rank ± 1) and
+    seqpar.with_halo's one-launch slab packing
   * tensor-parallel Llama (tp = 2 / 4 / 8: 8 heads → 4 / 2 / 1 per rank): prefill + graph-replayed decode steps with their all-reduces INSIDE the graph; logits and
     greedy ids equal the single-rank run's tokens and agree with the oracle"""
 import os
@@ -60,6 +62,37 @@ for it in range(10):
     parts = [payload(r, 8000 + it, 2 * 2 * 64 * 320).view(2, 2, 64, 320).to(torch.bfloat16) for r in range(world)]
     out = comm.all_gather(parts[rank].to(dev))
     assert out.dtype == torch.bfloat16 and out.shape == (world, 2, 2, 64, 320) and torch.equal(out.cpu(), torch.stack(parts))
+
+# ---- neighbour-only halo exchange (sx_oneshot_args.mode 1) + the fused slab packer (sx_halo_pack) ---------------------------
+from seedx_amd import seqpar
+def edge_rows(r, it, B, W, C):
+    g = torch.Generator().manual_seed(50000 + 100 * it + r)
+    return torch.randn(2, B, W, C, generator=g).to(torch.bfloat16)            # (first row, last row) of rank r's slab
+for it in range(40):
+    B, W, C = ((2, 64, 320), (3, 32, 640), (1, 128, 320), (2, 16, 1280))[it % 4]
+    mine = edge_rows(rank, it, B, W, C).to(dev)
+    got = comm.halo_exchange(mine)
+    exp = torch.zeros_like(mine)
+    if rank > 0:
+        exp[0] = edge_rows(rank - 1, it, B, W, C)[1].to(dev)
+    if rank < world - 1:
+        exp[1] = edge_rows(rank + 1, it, B, W, C)[0].to(dev)
+    assert torch.equal(got, exp), f"halo exchange rank {rank} it {it}"
+assert comm._halo is not None and comm._halo.neighbor_only
+comm._halo.check()
+# with_halo: slab [B, Hl*W, C] -> [B, Hl + 2, W (+1), C] with the neighbours' rows / zero borders, in one packing launch
+B, Hl, W, C = 2, 4, 16, 320
+slab = lambda r: torch.randn(B, Hl * W, C, generator=torch.Generator().manual_seed(777 + r)).to(torch.bfloat16)
+for left_col, bottom in ((False, True), (True, False)):
+    out = seqpar.with_halo(slab(rank).to(dev), comm, Hl, W, left_col=left_col, bottom=bottom)
+    off = 1 if left_col else 0
+    exp = torch.zeros(B, Hl + 1 + (1 if bottom else 0), W + off, C, dtype=torch.bfloat16)
+    exp[:, 1:Hl + 1, off:] = slab(rank).view(B, Hl, W, C)
+    if rank > 0:
+        exp[:, 0, off:] = slab(rank - 1).view(B, Hl, W, C)[:, -1]
+    if bottom and rank < world - 1:
+        exp[:, Hl + 1, off:] = slab(rank + 1).view(B, Hl, W, C)[:, 0]
+    assert torch.equal(out.cpu(), exp), f"with_halo rank {rank} left_col={left_col}"
 
 # ---- the collective inside a HIP graph -----------------------------------------------------------------------------------
 buf = torch.zeros(16 * 5120, device=dev)

@@ -76,6 +76,8 @@ def main():
         assert ctx.world >= nb, "CFG-parallel needs one rank per guidance branch"
         grp = dist.new_group(list(range(nb)))                                  # collective call: every rank executes it
         cfg_comm = TorchDistComm(grp) if ctx.rank < nb else None
+    # the image's crops are split over the ranks for the ViT (SURVEY.md §8e "preferred"): features all-gathered on the bootstrap group
+    vit_comm = TorchDistComm() if multi else None
     bench.BATCH = 1
     tok = bench.BenchTokenizer()
     with torch.no_grad():
@@ -86,7 +88,7 @@ def main():
         in_back = a.unet == "rows" or not multi or cfg_comm is not None
 
         def one(seed):
-            feats = bench.front_half(vit, agent, tok, inp, 8 if edit else a.text_tokens, dev)
+            feats = bench.front_half(vit, agent, tok, inp, 8 if edit else a.text_tokens, dev, vit_comm=vit_comm)
             if in_back:
                 bench.back_half(adapter, feats, a.unet_steps, seed, **({"image_latents": src} if edit else {}))
         for i in range(a.warmup):
