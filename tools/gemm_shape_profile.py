@@ -27,15 +27,15 @@ def main():
     dev = torch.device("cuda:0")
     from seedx_amd import _lib
     lib = _lib.load()
-    real = lib.sx_gemm
+    real, real_gn = lib.sx_gemm, lib.sx_gemm_gn
     rec = []
 
     class Hook:
-        def __call__(self, args_ref, stream):
+        def __call__(self, args_ref, *rest):       # sx_gemm(args, stream) | sx_gemm_gn(args, stats, groups, rows, fused, stream)
             g = args_ref._obj
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
-            r = real(args_ref, stream)
+            r = (real if len(rest) == 1 else real_gn)(args_ref, *rest)
             e.record()
             n_out = g.N // 2 if g.glu else g.N
             n_st = g.n_valid if g.n_valid else n_out
@@ -46,17 +46,17 @@ def main():
             rec.append((key, 2.0 * g.M * g.N * g.K, byt, s, e))
             return r
     with torch.no_grad():
-        w = bench.Headline(args, dev, torch.bfloat16)
+        w = bench.Headline(args, dev, torch.float16 if args.dtype == "fp16" else torch.bfloat16)
         w.step(0)                                                               # warm-up (graphs, caches)
         w.agent.use_graph = False
         w.adapter._loop.use_graph = False
         w.adapter._loop.chains = 1          # ONE kernel chain: with two concurrent chains an event pair also contains the other chain's kernels
-        lib.sx_gemm = Hook()
+        lib.sx_gemm = lib.sx_gemm_gn = Hook()
         try:
             w.step(1)
             torch.cuda.synchronize()
         finally:
-            lib.sx_gemm = real
+            lib.sx_gemm, lib.sx_gemm_gn = real, real_gn
     groups = collections.OrderedDict()
     for key, fl, byt, s, e in rec:
         g = groups.setdefault(key, [0, 0.0, 0.0, 0.0])
