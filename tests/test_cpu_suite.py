@@ -504,6 +504,20 @@ def test_seqpar_shard_arithmetic_two_ranks_gloo_and_virtual_ranks():
     assert res == [(0, True), (1, True)]
 
 
+def test_causal_lm_output_access_forms():
+    """The forward() return object offers the access forms of transformers' CausalLMOutputWithPast that reference-side callers
+    use (modeling_llama_xformer.py:736-746): attribute, key, integer index / slice over the non-None fields, tuple form."""
+    from seedx_amd.llama import CausalLMOutputWithPast
+    lg, pkv, hs = torch.zeros(1, 3, 5), ((torch.zeros(1), torch.zeros(1)),), (None, torch.ones(1, 3, 2))
+    out = CausalLMOutputWithPast(loss=None, logits=lg, past_key_values=pkv, hidden_states=hs, attentions=None)
+    assert out.logits is lg and out["logits"] is lg and out[0] is lg
+    assert out.past_key_values is pkv and out[1] is pkv and out.hidden_states[-1] is hs[-1]
+    assert out.to_tuple() == (lg, pkv, hs) and out[:2] == (lg, pkv)
+    assert out.loss is None and out.attentions is None
+    with pytest.raises(AttributeError):
+        out.no_such_field
+
+
 def test_split_batch_forward_virtual_ranks_cpu():
     """ViT crop split of the latency mode (parallel.split_batch_forward): every rank encodes its share of the batch, the
     all-gathered result equals the unsplit forward in item order — ragged shares (B not a multiple of the world), B < world."""
