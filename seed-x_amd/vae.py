@@ -326,12 +326,13 @@ class AutoencoderKL:
         """fp32 activation [..., C] → MFMA operand ([..., C] 16-bit, or [..., 3C] bf16 planes)."""
         return ops.split_bf16(x32, role) if self.split else ops.cast(x32, self.operand_dtype)
 
-    def _gn(self, x, gb, silu, want_raw=False):
-        """GroupNorm(+SiLU) of the fp32 stream → operand (and optionally the un-normalised x as an operand)."""
+    def _gn(self, x, gb, silu, want_raw=False, stats=None):
+        """GroupNorm(+SiLU) of the fp32 stream → operand (and optionally the un-normalised x as an operand).
+        stats: ops.GnStats accumulated by the conv that produced x (its statistics pass is then skipped)."""
         G = self.config.norm_num_groups
         if not self.split:
-            return ops.groupnorm(x, gb[0], gb[1], G, EPS, silu, self.operand_dtype, want_raw=want_raw)
-        return ops.groupnorm(x, gb[0], gb[1], G, EPS, silu, None, want_raw=want_raw, planes=True)
+            return ops.groupnorm(x, gb[0], gb[1], G, EPS, silu, self.operand_dtype, want_raw=want_raw, stats=stats)
+        return ops.groupnorm(x, gb[0], gb[1], G, EPS, silu, None, want_raw=want_raw, planes=True, stats=stats)
 
     def _resnet(self, r, x, H, W):
         """x: fp32 [1, HW, Ci] → fp32 [1, HW, Co]  (ResnetBlock2D with temb=None [ext])."""
@@ -341,8 +342,13 @@ class AutoencoderKL:
             h, raw = self._gn(x, r["n1"], True, want_raw=True)
         else:
             h = self._gn(x, r["n1"], True)
-        h = ops.conv3x3(h.view(1, H, W, -1), r["w1"], bias=r["b1"], out_dtype=f32)
-        h = self._gn(h, r["n2"], True)
+        # norm2's statistics ride on conv1's epilogue where conv1 runs on a ping-pong tile (Cout >= 256; ops.GnStats)
+        st = None
+        if r["w1"].shape[0] >= 256 and (H * W) % 256 == 0:
+            st = ops.GnStats(torch.zeros((1, self.config.norm_num_groups, 2), dtype=torch.float64, device=x.device),
+                             self.config.norm_num_groups, H * W)
+        h = ops.conv3x3(h.view(1, H, W, -1), r["w1"], bias=r["b1"], out_dtype=f32, gn=st)
+        h = self._gn(h, r["n2"], True, stats=st)
         sc = ops.gemm(raw.view(H * W, -1), r["ws"], bias=r["bs"], out_dtype=f32) if "ws" in r else x.view(-1, Ci)
         return ops.conv3x3(h.view(1, H, W, -1), r["w2"], bias=r["b2"], residual=sc, out_dtype=f32)
 
