@@ -804,7 +804,7 @@ def main(argv=None):
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         raise SystemExit(subprocess.run(cmd, env=env).returncode)
     global BATCH, USE_VAE, VAE_PRECISION
-    BATCH = a.batch if a.batch is not None else (4 if a.config == 5 else 16)
+    BATCH = a.batch if a.batch is not None else {5: 4, 2: 32}.get(a.config, 16)      # config 2 (text only): 32 lock-step sequences
     a.batch = BATCH
     USE_VAE = not a.no_vae
     VAE_PRECISION = a.vae_precision

@@ -30,8 +30,8 @@ extern "C" {
 #define SX_BF16 1
 #define SX_F32 2
 #define SX_BF16X3 3 /* sx_groupnorm* outputs only: bf16 planes [hi | hi | lo] per row, 3*C columns (see sx_split_bf16) */
-/* OR-ed into a 16-bit OUTPUT dtype of the decode-step producers (sx_layernorm with rows <= 16, sx_attn_decode_b, sx_gemv):
- * the [rows <= 16][cols] result is written as MFMA operand tiles [cols/32][16][32] — what sx_gemv reads with x_layout = 1
+/* OR-ed into a 16-bit OUTPUT dtype of the decode-step producers (sx_layernorm with rows <= 32, sx_attn_decode_b, sx_gemv):
+ * the [rows <= 32][cols] result is written as MFMA operand tiles [rows/16][cols/32][16][32] — what sx_gemv reads with x_layout = 1
  * (tile t = columns 32t .. 32t+31 of all 16 rows, 1 KB contiguous; rows >= `rows` of a tile are not written). */
 #define SX_TILED16 0x100
 
@@ -101,11 +101,12 @@ int sx_gemm_debug_stamps(void* buf);
 /* host-only query (no launch): tile config 0..8 the cost model picks for an M x N x K problem (glu / conv3x3 flags) */
 int sx_gemm_pick_tile(int M, int N, int K, int glu, int conv);
 
-/* 1..16-row GEMV for single-token decode of up to 16 lock-step sequences (HBM-bound weight streaming).
+/* 1..32-row GEMV for single-token decode of up to 32 lock-step sequences (HBM-bound weight streaming).
  * replaces: the same nn.Linear calls at q_len == 1 (modeling_llama_xformer.py:204-206,239,166-167,707).
  * y[m][n_out] = epi( x[m][K] · W[N][K]^T ), x 16-bit, y out_dtype, residual fp32. glu packing as above.
  * M <= 4 (or K % 64 != 0 / N % 32 != 0, then M <= 8): one wave per 2 rows, VALU dot products.
- * M >= 5: the weight rows feed a 16x16x32 MFMA against x^T padded to 16 columns (cost independent of M). */
+ * M >= 5: the weight rows feed a 16x16x32 MFMA against x^T padded to 16 columns (cost independent of M); M = 17..32: two such
+ * column blocks per weight fragment — the weights still stream once (tiled operands: [2][K/32][16][32], rows 16..31 in block 1). */
 typedef struct sx_gemv_args {
   const void* x;
   const void* W;
@@ -148,7 +149,7 @@ int sx_gemv(const sx_gemv_args* args, void* stream);
 /* test hook: 1 = always take the VALU path (lets the tests compare both), 0 = automatic */
 int sx_gemv_force_valu(int on);
 /* tuning hook (tools/lab/gemv_lab): key 2 = split-K factor of the MFMA skinny GEMM when a workspace is given:
- * 0 automatic, -1 / 1 never, 2 / 4 / 8 forced */
+ * 0 automatic, -1 / 1 never, 2 / 4 / 8 forced; key 1 = 1: the 17..32-row kernels with 4 k-steps per round (default 2) */
 int sx_gemv_tune(int key, int value);
 
 /* ------------------------------------------------------------------------------------------------

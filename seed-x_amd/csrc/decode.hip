@@ -113,12 +113,15 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvP p) {
 // (o-proj 3.4 TB/s); as 256 groups of 20 every CU streams the same bytes and no cross-workgroup reduction is needed.
 __device__ const unsigned g_zero_line[16] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
 
-template <typename TT, int R, int NWV, int U, bool TAIL = false>
+// MB = 2 (17..32 activation rows, lock-step batch 32): the x operand is two 16-row blocks — tiles [2][K/32][16][32] or rows 16..31 of
+// the row-major x — and every weight fragment feeds two MFMAs, so the weights still stream ONCE for all 32 sequences. Outputs, the
+// 16-bit tiled output, x16_out and the sums of squares follow the same block structure (row m = 16 b + r).
+template <typename TT, int R, int NWV, int U, bool TAIL = false, int MB = 1>
 __global__ __launch_bounds__(NWV * 64) void gemm_skinny_kernel(const GemvP p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   typedef typename TT::vec8 vec8;
   static_assert(!TAIL || R == 2, "the 20-row variant is two MFMA row blocks");
-  __shared__ float red[NWV][R][64][4];
+  __shared__ float red[NWV][R * MB][64][4];
   // the wave index as a SCALAR: everything derived from it (k range, round counts) then lives in SGPRs and the guards below
   // are scalar branches. With a VGPR-derived count the compiler predicates the guarded MFMAs through EXEC instead — and
   // MFMA ignores EXEC: the skipped k-steps' (never loaded) registers were multiplied in (found by tools/lab/gemv_lab).
@@ -129,11 +132,16 @@ __global__ __launch_bounds__(NWV * 64) void gemm_skinny_kernel(const GemvP p) {
   const int S = gridDim.y;                                           // split-K workgroups per row group (1 = none)
   const int nsl = NWV * S, sl = blockIdx.y * NWV + wave;             // k slices: split-K workgroups x waves
   const int ks0 = sl * nks / nsl, ks1 = (sl + 1) * nks / nsl;
-  const bool mvalid = r < p.M;
+  bool mvalid[MB];
+#pragma unroll
+  for (int b = 0; b < MB; ++b) mvalid[b] = r + 16 * b < p.M;
   // row-major x: a load instruction touches 16 rows 2K bytes apart — for K = 5120 that stride is a multiple of 16 cache
   // lines, so all 16 rows (and every wave on the chip, in step) hit the same L2 channel. Tiled x: the same instruction reads
   // one contiguous 1-KB tile, consecutive k-steps are consecutive tiles.
-  const unsigned short* xp = p.x_tiled ? p.x + r * 32 + 8 * g : p.x + (size_t)(mvalid ? r : 0) * p.K + 8 * g;
+  const unsigned short* xp[MB];
+#pragma unroll
+  for (int b = 0; b < MB; ++b)
+    xp[b] = p.x_tiled ? p.x + (size_t)b * (size_t)p.K * 16 + r * 32 + 8 * g : p.x + (size_t)(mvalid[b] ? r + 16 * b : 0) * p.K + 8 * g;
   const size_t xstep = p.x_tiled ? 1024 : 64, xhalf = p.x_tiled ? 512 : 32;
   // row-major W: a load instruction covers one 64-B half line of 16 rows (row stride 2K bytes). Decode layout: the same
   // instruction covers one contiguous 1-KB operand tile, a wave's k range is one contiguous stream.
@@ -151,32 +159,42 @@ __global__ __launch_bounds__(NWV * 64) void gemm_skinny_kernel(const GemvP p) {
     if (r < 4) wp[R - 1] = wp[0] + 512;
     else { wp[R - 1] = (const unsigned short*)g_zero_line; kstep_q[R - 1] = 0; khalf_q[R - 1] = 0; }   // operand rows 4..15 of block 1 = 0
   }
-  f32x4_t acc[R];
+  f32x4_t acc[R][MB];
 #pragma unroll
-  for (int q = 0; q < R; ++q) acc[q] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  for (int q = 0; q < R; ++q)
+#pragma unroll
+    for (int b = 0; b < MB; ++b) acc[q][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   // folded RMSNorm, consumer side: rstd of row r from the producer's per-workgroup sums of squares [16][parts]. Done HERE, ahead of
   // the weight stream, by all 256 threads at once: thread (slice = tid >> 4, r) loads its 1/16 of row r's list as independent 16-B
   // loads (a serial chain of 20 dependent L2 round trips per workgroup cost 5.7 us per launch), two shuffles + one LDS hop add the
   // 16 slices in a fixed order: every workgroup computes the same bits.
-  __shared__ float ssq_red[NWV][16];
-  float rstd_fold = 1.f;
+  __shared__ float ssq_red[NWV][16 * MB];
+  float rstd_fold[MB];
+#pragma unroll
+  for (int b = 0; b < MB; ++b) rstd_fold[b] = 1.f;
   if (p.ssq_in) {
     const int per = p.ssq_parts >> 4;                                   // parts % 64 == 0 (host-checked) → per % 4 == 0
-    const f32x4_t* src = (const f32x4_t*)(p.ssq_in + (size_t)r * p.ssq_parts + (size_t)(wave * 4 + g) * per);
-    float s0 = 0.f;
-#pragma unroll 5
-    for (int i = 0; i < (per >> 2); ++i) {
-      const f32x4_t t = src[i];
-      s0 += (t[0] + t[1]) + (t[2] + t[3]);
-    }
-    s0 += __shfl_xor(s0, 16, 64);
-    s0 += __shfl_xor(s0, 32, 64);
-    if (g == 0) ssq_red[wave][r] = s0;
-    __syncthreads();
-    float tot = 0.f;
 #pragma unroll
-    for (int w = 0; w < NWV; ++w) tot += ssq_red[w][r];
-    rstd_fold = __builtin_amdgcn_rsqf(tot * p.ssq_inv_dim + p.ssq_eps);
+    for (int b = 0; b < MB; ++b) {
+      const f32x4_t* src = (const f32x4_t*)(p.ssq_in + (size_t)(r + 16 * b) * p.ssq_parts + (size_t)(wave * 4 + g) * per);
+      float s0 = 0.f;
+#pragma unroll 5
+      for (int i = 0; i < (per >> 2); ++i) {
+        const f32x4_t t = src[i];
+        s0 += (t[0] + t[1]) + (t[2] + t[3]);
+      }
+      s0 += __shfl_xor(s0, 16, 64);
+      s0 += __shfl_xor(s0, 32, 64);
+      if (g == 0) ssq_red[wave][r + 16 * b] = s0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < MB; ++b) {
+      float tot = 0.f;
+#pragma unroll
+      for (int w = 0; w < NWV; ++w) tot += ssq_red[w][r + 16 * b];
+      rstd_fold[b] = __builtin_amdgcn_rsqf(tot * p.ssq_inv_dim + p.ssq_eps);
+    }
   }
   // Rounds of U k-steps through TWO register sets: round i+1's loads are issued before round i is consumed, so 1-2 rounds
   // (U..2U KB per row group and wave) are in flight at every moment. The pipelined loop has no branch inside (the waitcnt
@@ -184,7 +202,7 @@ __global__ __launch_bounds__(NWV * 64) void gemm_skinny_kernel(const GemvP p) {
   // rounds and the < U remainder are peeled. Measured (tools/lab/gemv_lab, profiles/r3_ab_experiments.md §6): the deeper
   // flight alone changes nothing (+-1 %) — the wide shapes already stream at 6.5-6.9 TB/s net of the 3-4 us launch cost;
   // what moved the numbers was the x layout (L2 channel conflicts) and, for K = 13824, split-K.
-  struct Frag { u32x4_t wa[U][R], wb[U][R], xa[U], xb[U]; };
+  struct Frag { u32x4_t wa[U][R], wb[U][R], xa[U][MB], xb[U][MB]; };
   auto load_round = [&](Frag& f, int ks, int cnt) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -195,8 +213,11 @@ __global__ __launch_bounds__(NWV * 64) void gemm_skinny_kernel(const GemvP p) {
           f.wa[u][q] = __builtin_nontemporal_load((const u32x4_t*)(wp[q] + (size_t)(ks + u) * kstep_q[q]));
           f.wb[u][q] = __builtin_nontemporal_load((const u32x4_t*)(wp[q] + (size_t)(ks + u) * kstep_q[q] + khalf_q[q]));
         }
-        f.xa[u] = *(const u32x4_t*)(xp + k);
-        f.xb[u] = *(const u32x4_t*)(xp + k + xhalf);
+#pragma unroll
+        for (int b = 0; b < MB; ++b) {
+          f.xa[u][b] = *(const u32x4_t*)(xp[b] + k);
+          f.xb[u][b] = *(const u32x4_t*)(xp[b] + k + xhalf);
+        }
       }
     }
   };
@@ -207,12 +228,13 @@ __global__ __launch_bounds__(NWV * 64) void gemm_skinny_kernel(const GemvP p) {
         // lanes of rows >= M carry row 0's x: their output columns (m >= M) are never stored, and an MFMA output column depends
         // on its own B column only — no select on the loaded registers (a VALU op on them at the top of the round makes the
         // waitcnt pass drain every load in flight)
-        const vec8 a = __builtin_bit_cast(vec8, f.xa[u]), b = __builtin_bit_cast(vec8, f.xb[u]);
 #pragma unroll
-        for (int q = 0; q < R; ++q) {
-          acc[q] = TT::mfma16(__builtin_bit_cast(vec8, f.wa[u][q]), a, acc[q]);
-          acc[q] = TT::mfma16(__builtin_bit_cast(vec8, f.wb[u][q]), b, acc[q]);
-        }
+        for (int q = 0; q < R; ++q)
+#pragma unroll
+          for (int b = 0; b < MB; ++b) {
+            acc[q][b] = TT::mfma16(__builtin_bit_cast(vec8, f.wa[u][q]), __builtin_bit_cast(vec8, f.xa[u][b]), acc[q][b]);
+            acc[q][b] = TT::mfma16(__builtin_bit_cast(vec8, f.wb[u][q]), __builtin_bit_cast(vec8, f.xb[u][b]), acc[q][b]);
+          }
       }
     }
   };
@@ -253,30 +275,36 @@ __global__ __launch_bounds__(NWV * 64) void gemm_skinny_kernel(const GemvP p) {
 #pragma unroll
   for (int q = 0; q < R; ++q)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) red[wave][q][lane][e] = acc[q][e];
+    for (int b = 0; b < MB; ++b)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) red[wave][q * MB + b][lane][e] = acc[q][b][e];
   __syncthreads();
   if (wave != 0) return;
-  // lane holds y[m = r][n0 + q*16 + 4g + e], e = 0..3
-  f32x4_t v[R];
+  // lane holds y[m = 16 b + r][n0 + q*16 + 4g + e], e = 0..3
+  f32x4_t v[R][MB];
 #pragma unroll
   for (int q = 0; q < R; ++q)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float t = 0.f;
+    for (int b = 0; b < MB; ++b)
 #pragma unroll
-      for (int w = 0; w < NWV; ++w) t += red[w][q][lane][e];
-      v[q][e] = t;
-    }
+      for (int e = 0; e < 4; ++e) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < NWV; ++w) t += red[w][q * MB + b][lane][e];
+        v[q][b][e] = t;
+      }
   if (S > 1) {
     // split-K: every workgroup publishes its partial [16][16R] block; the LAST one to arrive (per row group) adds the S partials
     // in split order — the result does not depend on which workgroup that is — and runs the epilogue. The counter is left at 0.
 #pragma unroll
     for (int q = 0; q < R; ++q)
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (!(TAIL && q == 1 && g != 0))
-          __hip_atomic_store(p.ws_part + ((size_t)blockIdx.y * 16 + r) * p.N + n0 + q * 16 + 4 * g + e, v[q][e], __ATOMIC_RELAXED,
-                             __HIP_MEMORY_SCOPE_AGENT);
+      for (int b = 0; b < MB; ++b)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (!(TAIL && q == 1 && g != 0))
+            __hip_atomic_store(p.ws_part + ((size_t)blockIdx.y * (16 * MB) + 16 * b + r) * p.N + n0 + q * 16 + 4 * g + e, v[q][b][e],
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // No cache-wide fence (an agent-scope release / acquire writes back and invalidates the whole per-XCD L2 — measured 4x
     // slower kernels): the partials themselves move as agent-scope (sc1) atomics, which are performed at the device's
     // coherence point, so ordering them against the counter only needs "my stores are acknowledged" before the count and
@@ -290,67 +318,76 @@ __global__ __launch_bounds__(NWV * 64) void gemm_skinny_kernel(const GemvP p) {
 #pragma unroll
     for (int q = 0; q < R; ++q)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float t = 0.f;
-        if (!(TAIL && q == 1 && g != 0))
-          for (int sidx = 0; sidx < S; ++sidx)
-            t += __hip_atomic_load(p.ws_part + ((size_t)sidx * 16 + r) * p.N + n0 + q * 16 + 4 * g + e, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-        v[q][e] = t;
-      }
+      for (int b = 0; b < MB; ++b)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float t = 0.f;
+          if (!(TAIL && q == 1 && g != 0))
+            for (int sidx = 0; sidx < S; ++sidx)
+              t += __hip_atomic_load(p.ws_part + ((size_t)sidx * (16 * MB) + 16 * b + r) * p.N + n0 + q * 16 + 4 * g + e, __ATOMIC_RELAXED,
+                                     __HIP_MEMORY_SCOPE_AGENT);
+          v[q][b][e] = t;
+        }
     if (lane == 0) __hip_atomic_store(p.ws_cnt + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   if (p.ssq_in) {
 #pragma unroll
     for (int q = 0; q < R; ++q)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[q][e] *= rstd_fold;
+      for (int b = 0; b < MB; ++b)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[q][b][e] *= rstd_fold[b];
   }
-  float ssq_l = 0.f;
   const int ncols = p.glu ? p.N / 2 : p.N;
 #pragma unroll
-  for (int q = 0; q < (R == 2 ? 2 : 1); ++q) {
-    if (!mvalid) break;
-    if (TAIL && q == 1 && g != 0) break;           // block 1 holds rows 16..19 only: output columns n0 + 16 .. n0 + 19 (lane group 0)
-    f32x4_t o;
-    int col;
-    if (p.glu) {
-      if (q == 1) break;
-      col = blockIdx.x * 16 + 4 * g;
+  for (int b = 0; b < MB; ++b) {
+    float ssq_l = 0.f;
+    const int m = r + 16 * b;                               // activation row; 16-bit tiles: block b of [MB][ncols/32][16][32]
+    const size_t tblk = (size_t)b * (size_t)ncols * 16;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = v[0][e] * apply_act(v[R - 1][e], p.act);
-    } else {
-      col = n0 + q * 16 + 4 * g;
+    for (int q = 0; q < (R == 2 ? 2 : 1); ++q) {
+      if (!mvalid[b]) break;
+      if (TAIL && q == 1 && g != 0) break;           // block 1 holds rows 16..19 only: output columns n0 + 16 .. n0 + 19 (lane group 0)
+      f32x4_t o;
+      int col;
+      if (p.glu) {
+        if (q == 1) break;
+        col = blockIdx.x * 16 + 4 * g;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = apply_act(v[q][e], p.act);
-    }
-    const size_t off = (size_t)r * ncols + col;
-    if (p.residual) o += *(const f32x4_t*)(p.residual + off);
-    if (p.y_tiled) {      // 16-bit operand tiles [ncols/32][16][32] for the next skinny GEMM (x_layout = 1)
-      u32x2_t w2;
-      if (p.out_dtype == SX_BF16) { w2[0] = pack2<BF16>(o[0], o[1]); w2[1] = pack2<BF16>(o[2], o[3]); }
-      else { w2[0] = pack2<F16>(o[0], o[1]); w2[1] = pack2<F16>(o[2], o[3]); }
-      *(u32x2_t*)((unsigned short*)p.y + (size_t)(col >> 5) * 512 + (size_t)r * 32 + (col & 31)) = w2;
-    } else if (p.out_dtype == SX_F32) {
-      *(f32x4_t*)((float*)p.y + off) = o;
-      if (p.x16_out) {     // folded RMSNorm, producer side: the new residual stream also as the next GEMV's 16-bit operand tiles
-        u32x2_t w2;
-        if (std::is_same<TT, BF16>::value) { w2[0] = pack2<BF16>(o[0], o[1]); w2[1] = pack2<BF16>(o[2], o[3]); }
-        else { w2[0] = pack2<F16>(o[0], o[1]); w2[1] = pack2<F16>(o[2], o[3]); }
-        *(u32x2_t*)(p.x16_out + (size_t)(col >> 5) * 512 + (size_t)r * 32 + (col & 31)) = w2;
-        ssq_l += o[0] * o[0] + o[1] * o[1] + o[2] * o[2] + o[3] * o[3];
+        for (int e = 0; e < 4; ++e) o[e] = v[0][b][e] * apply_act(v[R - 1][b][e], p.act);
+      } else {
+        col = n0 + q * 16 + 4 * g;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = apply_act(v[q][b][e], p.act);
       }
-    } else {
-      u32x2_t w2;
-      if (p.out_dtype == SX_BF16) { w2[0] = pack2<BF16>(o[0], o[1]); w2[1] = pack2<BF16>(o[2], o[3]); }
-      else { w2[0] = pack2<F16>(o[0], o[1]); w2[1] = pack2<F16>(o[2], o[3]); }
-      *(u32x2_t*)((unsigned short*)p.y + off) = w2;
+      const size_t off = (size_t)m * ncols + col;
+      if (p.residual) o += *(const f32x4_t*)(p.residual + off);
+      if (p.y_tiled) {      // 16-bit operand tiles [ncols/32][16][32] for the next skinny GEMM (x_layout = 1)
+        u32x2_t w2;
+        if (p.out_dtype == SX_BF16) { w2[0] = pack2<BF16>(o[0], o[1]); w2[1] = pack2<BF16>(o[2], o[3]); }
+        else { w2[0] = pack2<F16>(o[0], o[1]); w2[1] = pack2<F16>(o[2], o[3]); }
+        *(u32x2_t*)((unsigned short*)p.y + tblk + (size_t)(col >> 5) * 512 + (size_t)r * 32 + (col & 31)) = w2;
+      } else if (p.out_dtype == SX_F32) {
+        *(f32x4_t*)((float*)p.y + off) = o;
+        if (p.x16_out) {     // folded RMSNorm, producer side: the new residual stream also as the next GEMV's 16-bit operand tiles
+          u32x2_t w2;
+          if (std::is_same<TT, BF16>::value) { w2[0] = pack2<BF16>(o[0], o[1]); w2[1] = pack2<BF16>(o[2], o[3]); }
+          else { w2[0] = pack2<F16>(o[0], o[1]); w2[1] = pack2<F16>(o[2], o[3]); }
+          *(u32x2_t*)(p.x16_out + tblk + (size_t)(col >> 5) * 512 + (size_t)r * 32 + (col & 31)) = w2;
+          ssq_l += o[0] * o[0] + o[1] * o[1] + o[2] * o[2] + o[3] * o[3];
+        }
+      } else {
+        u32x2_t w2;
+        if (p.out_dtype == SX_BF16) { w2[0] = pack2<BF16>(o[0], o[1]); w2[1] = pack2<BF16>(o[2], o[3]); }
+        else { w2[0] = pack2<F16>(o[0], o[1]); w2[1] = pack2<F16>(o[2], o[3]); }
+        *(u32x2_t*)((unsigned short*)p.y + off) = w2;
+      }
     }
-  }
-  if (p.ssq_out) {           // (whole wave: rows >= M contribute zeros and are never read)
-    ssq_l += __shfl_xor(ssq_l, 16, 64);
-    ssq_l += __shfl_xor(ssq_l, 32, 64);
-    if (g == 0) p.ssq_out[(size_t)r * gridDim.x + blockIdx.x] = ssq_l;      // [16][parts]
+    if (p.ssq_out) {           // (whole wave: rows >= M contribute zeros and are never read)
+      ssq_l += __shfl_xor(ssq_l, 16, 64);
+      ssq_l += __shfl_xor(ssq_l, 32, 64);
+      if (g == 0) p.ssq_out[(size_t)m * gridDim.x + blockIdx.x] = ssq_l;      // [16 MB][parts]
+    }
   }
 #endif
 }
@@ -615,7 +652,8 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const AttnDecP p
     a2 += w1 * fin[d];
     l2 += w1 * fin[D + 1];
     const int col1 = h * D + d;
-    const size_t o1 = p.tiled ? (size_t)(col1 >> 5) * 512 + (size_t)g * 32 + (col1 & 31) : (size_t)g * H * D + col1;
+    const size_t o1 = p.tiled ? (size_t)(g >> 4) * (size_t)H * D * 16 + (size_t)(col1 >> 5) * 512 + (size_t)(g & 15) * 32 + (col1 & 31)
+                              : (size_t)g * H * D + col1;
     p.out[o1] = TT::from_f32(l2 > 0.f ? a2 / l2 : 0.f);
     return;
   }
@@ -681,7 +719,8 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const AttnDecP p
     }
   }
   const int col = h * D + d;
-  const size_t oo = p.tiled ? (size_t)(col >> 5) * 512 + (size_t)g * 32 + (col & 31) : (size_t)g * H * D + col;
+  const size_t oo = p.tiled ? (size_t)(g >> 4) * (size_t)H * D * 16 + (size_t)(col >> 5) * 512 + (size_t)(g & 15) * 32 + (col & 31)
+                            : (size_t)g * H * D + col;
   p.out[oo] = TT::from_f32(l > 0.f ? acc / l : 0.f);
 }
 
@@ -701,7 +740,8 @@ __global__ void attn_decode_combine_kernel(const float* scratch, unsigned short*
     l += w * base[(size_t)s * (D + 2) + D + 1];
   }
   const int col = h * D + d;                     // of row g in [G][H*D]; SX_TILED16: tile col/32, row g, column col%32
-  const size_t o = tiled ? (size_t)(col >> 5) * 512 + (size_t)g * 32 + (col & 31) : (size_t)g * H * D + col;
+  const size_t o = tiled ? (size_t)(g >> 4) * (size_t)H * D * 16 + (size_t)(col >> 5) * 512 + (size_t)(g & 15) * 32 + (col & 31)
+                         : (size_t)g * H * D + col;      // sequences 16..31: a second block of tiles behind the first
   out[o] = TT::from_f32(l > 0.f ? acc / l : 0.f);
 }
 
@@ -837,7 +877,8 @@ using namespace sxk_decode;
 #define ST ((hipStream_t)stream)
 static int g_skinny_var[3] = {0, 0, 0};  // tuning hook (sx_gemv_tune): [2] = split-K factor (0 auto, -1 never, 2 / 4 / 8 forced)
 extern "C" int sx_gemv_tune(int key, int value) {
-  SX_CHECK(key == 2 && (value == -1 || value == 0 || value == 1 || value == 2 || value == 4 || value == 8), "sx_gemv_tune: key %d value %d", key, value);
+  SX_CHECK((key == 2 && (value == -1 || value == 0 || value == 1 || value == 2 || value == 4 || value == 8)) || (key == 1 && (value == 0 || value == 1)),
+           "sx_gemv_tune: key %d value %d", key, value);
   g_skinny_var[key] = value;
   return SX_OK;
 }
@@ -853,7 +894,7 @@ extern "C" int sx_gemv_ssq_parts(int N, int glu, int w_layout) {
 extern "C" int sx_gemv(const sx_gemv_args* a, void* stream) {
   SX_CHECK(a && a->x && a->W && a->y, "sx_gemv: null pointer");
   SX_CHECK(a->dtype == SX_F16 || a->dtype == SX_BF16, "sx_gemv: dtype");
-  SX_CHECK(a->M >= 1 && a->M <= 16, "sx_gemv: M=%d must be 1..16", a->M);
+  SX_CHECK(a->M >= 1 && a->M <= 32, "sx_gemv: M=%d must be 1..32", a->M);
   SX_CHECK(a->K % 8 == 0 && a->N > 0, "sx_gemv: K %% 8");
   SX_CHECK(!a->glu || a->N % 32 == 0, "sx_gemv: glu needs N %% 32 == 0");
   GemvP p;
@@ -895,14 +936,22 @@ extern "C" int sx_gemv(const sx_gemv_args* a, void* stream) {
       else if (g_skinny_var[2] == 0 && a->K >= 8192) while (S < 8 && gx * S < 1024 && (a->K / 64) / (2 * S * 4) >= 4) S *= 2;
       const uint64_t cnt_bytes = 16384;    // fixed, so launches of different N can share one workspace (their partial regions
                                            // may overlap — launches are serial — but never reach the counters)
-      if (S > 1 && (gx > 4096 || cnt_bytes + (uint64_t)S * 16 * a->N * 4 > a->workspace_bytes)) S = 1;   // too small: no split
+      if (S > 1 && (gx > 4096 || cnt_bytes + (uint64_t)S * (a->M > 16 ? 32 : 16) * a->N * 4 > a->workspace_bytes)) S = 1;   // too small: no split
       p.ws_cnt = (unsigned*)a->workspace;
       p.ws_part = (float*)((char*)a->workspace + cnt_bytes);
     }
     const dim3 grid(gx, S);
-#define SX_SK_GO(TT)                                                                                   \
-    if (tail20) hipLaunchKernelGGL((gemm_skinny_kernel<TT, 2, 4, 4, true>), grid, dim3(256), 0, ST, p);  \
-    else if (r2) hipLaunchKernelGGL((gemm_skinny_kernel<TT, 2, 4, 4>), grid, dim3(256), 0, ST, p);      \
+#define SX_SK_GO(TT)                                                                                          \
+    if (a->M > 16) {                                                                                           \
+      if (g_skinny_var[1] == 1) {       /* lab: 4 k-steps per round (256 VGPRs + AGPR copies, one wave per SIMD) */ \
+        if (tail20) hipLaunchKernelGGL((gemm_skinny_kernel<TT, 2, 4, 4, true, 2>), grid, dim3(256), 0, ST, p);   \
+        else if (r2) hipLaunchKernelGGL((gemm_skinny_kernel<TT, 2, 4, 4, false, 2>), grid, dim3(256), 0, ST, p); \
+        else hipLaunchKernelGGL((gemm_skinny_kernel<TT, 1, 4, 4, false, 2>), grid, dim3(256), 0, ST, p);         \
+      } else if (tail20) hipLaunchKernelGGL((gemm_skinny_kernel<TT, 2, 4, 2, true, 2>), grid, dim3(256), 0, ST, p); \
+      else if (r2) hipLaunchKernelGGL((gemm_skinny_kernel<TT, 2, 4, 2, false, 2>), grid, dim3(256), 0, ST, p);   \
+      else hipLaunchKernelGGL((gemm_skinny_kernel<TT, 1, 4, 4, false, 2>), grid, dim3(256), 0, ST, p);           \
+    } else if (tail20) hipLaunchKernelGGL((gemm_skinny_kernel<TT, 2, 4, 4, true>), grid, dim3(256), 0, ST, p); \
+    else if (r2) hipLaunchKernelGGL((gemm_skinny_kernel<TT, 2, 4, 4>), grid, dim3(256), 0, ST, p);             \
     else hipLaunchKernelGGL((gemm_skinny_kernel<TT, 1, 4, 4>), grid, dim3(256), 0, ST, p);
     if (a->dtype == SX_BF16) { SX_SK_GO(BF16) } else { SX_SK_GO(F16) }
 #undef SX_SK_GO
@@ -937,7 +986,7 @@ extern "C" int sx_attn_decode_b(const void* q, const void* kcache, const void* v
   SX_CHECK(nsplit >= 1 && nsplit <= 64 && G >= 1, "sx_attn_decode: nsplit/G");
   const int tiled = (dtype & SX_TILED16) ? 1 : 0;   // the OUTPUT as operand tiles [H*D/32][16][32] (q and the caches are as always)
   dtype &= 0xff;
-  SX_CHECK(!tiled || (G <= 16 && (H * D) % 32 == 0), "sx_attn_decode: SX_TILED16 needs G <= 16 and H*D %% 32 == 0");
+  SX_CHECK(!tiled || (G <= 32 && (H * D) % 32 == 0), "sx_attn_decode: SX_TILED16 needs G <= 32 and H*D %% 32 == 0");
   if (dtype == SX_BF16) {
     hipLaunchKernelGGL(attn_decode_kernel<BF16>, dim3(H, nsplit, G), dim3(256), 0, ST, (const unsigned short*)q,
                        (const unsigned short*)kcache, (const unsigned short*)vcache, scratch, ctx_len_dev, D, Tmax,
@@ -961,7 +1010,7 @@ extern "C" int sx_attn_decode_fused(const sx_attn_decode_args* a, void* stream) 
   SX_CHECK(dt == SX_F16 || dt == SX_BF16, "sx_attn_decode_fused: dtype");
   SX_CHECK(a->D % 16 == 0 && a->D <= 128, "sx_attn_decode_fused: head_dim %d (must be a multiple of 16, <= 128)", a->D);
   SX_CHECK(a->nsplit >= 1 && a->nsplit <= 64 && a->G >= 1 && a->H >= 1, "sx_attn_decode_fused: nsplit/G/H");
-  SX_CHECK(!tiled || (a->G <= 16 && (a->H * a->D) % 32 == 0), "sx_attn_decode_fused: SX_TILED16 needs G <= 16 and H*D %% 32 == 0");
+  SX_CHECK(!tiled || (a->G <= 32 && (a->H * a->D) % 32 == 0), "sx_attn_decode_fused: SX_TILED16 needs G <= 32 and H*D %% 32 == 0");
   AttnDecP p;
   p.qkv = (const unsigned short*)a->qkv; p.kc = (unsigned short*)a->kcache; p.vc = (unsigned short*)a->vcache;
   p.out = (unsigned short*)a->out; p.scratch = a->scratch; p.counters = (unsigned*)a->counters;

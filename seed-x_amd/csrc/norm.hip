@@ -123,7 +123,8 @@ __global__ __launch_bounds__(256) void layernorm_block_kernel(const void* x, voi
     const int i = tid + 256 * k;
     if (i < n4) {
       // SX_TILED16: element (row, col) lives at tile col/32, row `row`, column col%32 of [cols/32][16][32]
-      const size_t o4 = (out_dt & SX_TILED16) ? ((size_t)(i >> 3) * 512 + (size_t)row * 32 + (size_t)(i & 7) * 4) >> 2 : base4 + i;
+      // (rows 16..31 form a second block of tiles behind the first: [rows/16][cols/32][16][32])
+      const size_t o4 = (out_dt & SX_TILED16) ? ((size_t)(row >> 4) * (size_t)cols * 16 + (size_t)(i >> 3) * 512 + (size_t)(row & 15) * 32 + (size_t)(i & 7) * 4) >> 2 : base4 + i;
       store4(y, out_dt & 0xff, o4, (v[k] - mean) * rstd * g[k] + b[k]);
     }
   }
@@ -358,8 +359,8 @@ extern "C" int sx_layernorm(const void* x, int in_dtype, void* y, int out_dtype,
   SX_CHECK(x && y && gamma, "sx_layernorm: null pointer");
   SX_CHECK(rows > 0 && cols > 0 && cols % 4 == 0, "sx_layernorm: rows=%d cols=%d (cols %% 4 must be 0)", rows, cols);
   const bool tiled = (out_dtype & SX_TILED16) != 0;
-  SX_CHECK(!tiled || (rows <= 16 && cols % 32 == 0 && ((out_dtype & 0xff) == SX_F16 || (out_dtype & 0xff) == SX_BF16)),
-           "sx_layernorm: SX_TILED16 needs rows <= 16, cols %% 32 == 0 and a 16-bit output (rows=%d cols=%d)", rows, cols);
+  SX_CHECK(!tiled || (rows <= 32 && cols % 32 == 0 && ((out_dtype & 0xff) == SX_F16 || (out_dtype & 0xff) == SX_BF16)),
+           "sx_layernorm: SX_TILED16 needs rows <= 32, cols %% 32 == 0 and a 16-bit output (rows=%d cols=%d)", rows, cols);
   SX_CHECK((out_dtype & 0xff) >= SX_F16 && (out_dtype & 0xff) <= SX_F32 && (out_dtype & ~0x1ff) == 0, "sx_layernorm: bad out dtype");
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((rows + 3) / 4), block(256);
@@ -373,7 +374,7 @@ extern "C" int sx_layernorm(const void* x, int in_dtype, void* y, int out_dtype,
   else if (n4 <= 64 * 8) { SX_LN_GO(DT, 8); }  \
   else if (n4 <= 64 * 16) { SX_LN_GO(DT, 16); } \
   else { SX_LN_GO(DT, 24); }
-  if (rows <= 16) {  // decode-sized: block per row
+  if (rows <= 32) {  // decode-sized: block per row
     const dim3 g1(rows);
     switch (in_dtype) {
       case SX_F32: hipLaunchKernelGGL(layernorm_block_kernel<SX_F32>, g1, block, 0, st, x, y, out_dtype, gamma, beta, rows, cols, eps, rms); break;

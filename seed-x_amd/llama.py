@@ -88,7 +88,7 @@ class LlamaForCausalLM:
         self.H_l = self.nh_l * self.hd
         self.Tmax = max_cache_len or c.max_position_embeddings
         self.G = int(max_batch)
-        assert 1 <= self.G <= 16, "lock-step batch is limited to 16 sequences (sx_gemv rows)"
+        assert 1 <= self.G <= 32, "lock-step batch is limited to 32 sequences (two 16-row operand blocks of sx_gemv)"
         # Decode attention (tools/bench_decode_attention_ab.py, 16 sequences x 40 heads, ms per token of the graph-replayed step):
         # three launches (RoPE + append, split-KV attention, combine) with 8 / 2 / 1 KV splits 6.70 / 6.46 / 6.52; ONE launch
         # (sx_attn_decode_fused, bit-identical) with 8 splits 6.80 — its arrival-counter tail costs more than two graph
@@ -190,8 +190,11 @@ class LlamaForCausalLM:
         # of the projections that FOLLOW a norm carry that norm's gamma (W' = W · diag(gamma), product rounded once to 16 bits) —
         # wgu of every layer (post_attention_layernorm) and wqkv of layers >= 1 (input_layernorm; layer 0's input comes from the
         # embedding, not from a GEMV). Prefill keeps the row-major, unfolded weights and the norm kernel.
-        fold = self.G >= 5 and tp == 1 and os.environ.get("SX_RMS_FOLD", "1") != "0"      # (0: A/B switch, tools/)
         bal20 = self.G >= 5 and os.environ.get("SX_GEMV_BAL20", "1") != "0"
+        # the consumer adds the producer's per-workgroup sums of squares 64 at a time: the o / down launches (N = H) must have a
+        # multiple of 64 workgroups (H = 5120: 256 with 20-row tiles, 320 without)
+        parts = self.H // 20 if (bal20 and self.H % 20 == 0 and self.H // 20 == 256) else (self.H // 32 if self.H // 32 >= 256 else self.H // 16)
+        fold = self.G >= 5 and tp == 1 and parts % 64 == 0 and os.environ.get("SX_RMS_FOLD", "1") != "0"      # (0: A/B switch, tools/)
         for i in range(self.L):
             p = f"model.layers.{i}."
             sh = llama_tp_shard(sd, p, r, tp, self.nh, self.hd)
@@ -222,7 +225,8 @@ class LlamaForCausalLM:
         assert P["rms_fold"] or not fold or not any(lw["wgu_t"] is not None for lw in P["layers"]), \
             "folded decode tiles without the tiled decode path"
         # split-K scratch of the skinny GEMM: counters + 8 partial [16, H] blocks (include/seedx_hip.h: sx_gemv_args.workspace)
-        P["gemv_ws"] = torch.zeros(16384 + 8 * 16 * self.H * 4, dtype=torch.uint8, device=dev) if P["decode_tiled"] else None
+        P["gemv_ws"] = torch.zeros(16384 + 8 * 16 * ((self.G + 15) // 16) * self.H * 4, dtype=torch.uint8, device=dev) \
+            if P["decode_tiled"] else None
         inv = 1.0 / (self.config.rope_base ** (torch.arange(0, self.hd, 2).float() / self.hd))
         fr = torch.outer(torch.arange(self.Tmax).float(), inv)           # [Tmax, hd/2] fp32 (:97-113)
         P["cos"], P["sin"] = fr.cos().to(dev).contiguous(), fr.sin().to(dev).contiguous()

@@ -180,13 +180,14 @@ def pack_decode_tiles20(w):
 
 
 class Tiled16:
-    """A [rows <= 16, cols] 16-bit activation of the decode step held as MFMA operand tiles [cols/32][16][32] (SX_TILED16 in
-    include/seedx_hip.h): what the skinny GEMM reads with one contiguous 1-KB load per operand. Rows >= `rows` are padding."""
+    """A [rows <= 32, cols] 16-bit activation of the decode step held as MFMA operand tiles [rows/16][cols/32][16][32] (SX_TILED16
+    in include/seedx_hip.h): what the skinny GEMM reads with one contiguous 1-KB load per operand. Rows 16..31 (lock-step batches
+    above 16) are a second block of tiles behind the first; rows >= `rows` of the last block are padding."""
     __slots__ = ("t", "rows", "cols")
 
     def __init__(self, rows, cols, dtype, device):
-        assert rows <= 16 and cols % 32 == 0
-        self.t, self.rows, self.cols = torch.empty((cols // 32, 16, 32), dtype=dtype, device=device), rows, cols
+        assert rows <= 32 and cols % 32 == 0
+        self.t, self.rows, self.cols = torch.empty(((rows + 15) // 16, cols // 32, 16, 32), dtype=dtype, device=device), rows, cols
 
     @property
     def dtype(self):
@@ -194,7 +195,8 @@ class Tiled16:
 
     def dense(self):
         """[rows, cols] row-major copy (tests)."""
-        return self.t.permute(1, 0, 2).reshape(16, self.cols)[:self.rows].contiguous()
+        nb = self.t.shape[0]
+        return self.t.permute(0, 2, 1, 3).reshape(nb * 16, self.cols)[:self.rows].contiguous()
 
 
 def gemv(x, w, residual=None, act=None, glu=False, out_dtype=None, w_tiles=None, y_tiled=False, workspace=None,
@@ -245,11 +247,11 @@ def gemv(x, w, residual=None, act=None, glu=False, out_dtype=None, w_tiles=None,
     if emit_norm:
         assert args.w_layout in (1, 2) and out_dtype == torch.float32 and not glu and not y_tiled
         x16 = Tiled16(M, n_out, w.dtype, dev)
-        ssq = torch.empty((16, lib.sx_gemv_ssq_parts(N, 0, args.w_layout)), dtype=torch.float32, device=dev)      # [row][workgroup]
+        ssq = torch.empty((16 * ((M + 15) // 16), lib.sx_gemv_ssq_parts(N, 0, args.w_layout)), dtype=torch.float32, device=dev)   # [row][workgroup]
         args.x16_out, args.row_ssq_out = x16.t.data_ptr(), ssq.data_ptr()
     if ssq_in is not None:
         t, dim, eps = ssq_in
-        assert args.w_layout == 1 and t.dtype == torch.float32 and t.is_contiguous() and t.shape[0] == 16
+        assert args.w_layout == 1 and t.dtype == torch.float32 and t.is_contiguous() and t.shape[0] == 16 * ((M + 15) // 16)
         args.row_ssq_in, args.ssq_in_parts, args.ssq_dim, args.ssq_eps = t.data_ptr(), t.shape[1], int(dim), float(eps)
     check(lib.sx_gemv(C.byref(args), _stream()), "sx_gemv")
     out = yt if y_tiled else y
@@ -275,7 +277,7 @@ def linear(x, w, **kw):
 # Norms
 # ---------------------------------------------------------------------------------------------------------
 def layernorm(x, gamma, beta, eps, out_dtype, rms=False, tiled=False):
-    """tiled (rows <= 16, 16-bit out): the result as a Tiled16 — the decode step's norms feed skinny GEMMs only."""
+    """tiled (rows <= 32, 16-bit out): the result as a Tiled16 — the decode step's norms feed skinny GEMMs only."""
     lib = _lib.load()
     assert x.is_contiguous()
     cols = x.shape[-1]

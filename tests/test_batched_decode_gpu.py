@@ -55,6 +55,42 @@ def test_generate_batch_equals_single_runs(dev):
     assert relerr(batch[1]["last_hidden_states"], ref["last_hidden"]) < 4e-3
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_generate_batch_above_16_sequences(dev, dtype):
+    """20 lock-step sequences: the decode step's skinny GEMMs run two 16-row operand blocks per weight fragment (sx_gemv M = 17..32,
+    tiled activations [2][K/32][16][32]) — same tokens as single-request runs, hidden states within the 16-bit noise (the G >= 5
+    path is MFMA, the single-request path VALU: another summation order)."""
+    cfg, vit_dim = weights.MINI_LLM, 128
+    sd_llm = weights.llama_sd(cfg)
+    sd_agent = weights.agent_sd(cfg, vit_dim, in_grid=4, out_grid=4)
+    g = torch.Generator().manual_seed(77)
+    reqs = []
+    for r in range(20):
+        ids = [1, 10 + r] + [0] * 16 + [20 + r + i for i in range(2 + r % 5)]
+        mask = torch.zeros(1, len(ids), dtype=torch.bool)
+        mask[0, 2:18] = True
+        reqs.append(dict(input_ids=[ids], image_embeds=torch.randn(1, 36, vit_dim, generator=g).to(dev),
+                         embeds_cmp_mask=torch.tensor([True]), ids_cmp_mask=mask, patch_positions=torch.tensor([[0.5, 0.5]])))
+    tok = StubTokenizer()
+    kw = dict(num_img_gen_tokens=16, max_new_tokens=26, eos_token_id=None, force_image_at=3)
+    agent = _agent(dev, dtype, sd_llm, sd_agent, cfg, vit_dim, 20)
+    assert agent.llm._pack()["decode_tiled"]
+    batch = agent.generate_batch(tok, reqs, **kw)
+    single = _agent(dev, dtype, sd_llm, sd_agent, cfg, vit_dim, 1)
+    tol = 3e-3 if dtype == torch.float16 else 2.4e-2
+    same = 0
+    for r in (0, 7, 15, 16, 19):                       # rows of both operand blocks
+        one = single.generate_batch(tok, [reqs[r]], **kw)[0]
+        a, b = batch[r]["generate_ids"].tolist(), one["generate_ids"].tolist()
+        assert a[3:21] == [400] + list(range(401, 417)) + [465] and len(a) == len(b) == 26
+        n = next((i for i, (u, v) in enumerate(zip(a, b)) if u != v), len(a))   # random-weight logits can be near-ties
+        same += n == len(a)
+        assert n >= 21, (r, n, a, b)
+        assert relerr(batch[r]["last_hidden_states"][:n - 1], one["last_hidden_states"][:n - 1]) < tol
+        assert relerr(batch[r]["img_gen_feat"], one["img_gen_feat"]) < tol
+    assert same >= 3
+
+
 def test_uniform_batched_prefill_and_chunk_equal_single_runs(dev):
     """All requests share prompt length and position → the batched RoPE / flash-attention launches (one per layer for the
     whole batch) are taken; the results must still equal separate single-request runs."""

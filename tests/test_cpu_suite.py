@@ -251,21 +251,28 @@ def test_product_path_has_no_cpu_fallback():
 # host logic
 # ---------------------------------------------------------------------------------------------------------
 def test_tiled16_layout_contract():
-    """ops.Tiled16 = the SX_TILED16 layout of include/seedx_hip.h: element (m, k) of a [rows <= 16, cols] activation sits at tile
-    k // 32, row m, column k % 32 of [cols/32][16][32] (what sx_gemv reads with x_layout = 1 and what the decode step's producers
-    write). Host-side index arithmetic only."""
+    """ops.Tiled16 = the SX_TILED16 layout of include/seedx_hip.h: element (m, k) of a [rows <= 32, cols] activation sits in block
+    m // 16, tile k // 32, row m % 16, column k % 32 of [rows/16][cols/32][16][32] (what sx_gemv reads with x_layout = 1 and what the
+    decode step's producers write). Host-side index arithmetic only."""
     from seedx_amd import ops
     t = ops.Tiled16(5, 96, torch.float32, "cpu")
     t.t.zero_()
     dense = torch.arange(5 * 96, dtype=torch.float32).view(5, 96)
-    t.t[:, :5] = dense.view(5, 3, 32).permute(1, 0, 2)
-    assert t.t.shape == (3, 16, 32) and torch.equal(t.dense(), dense)
-    assert t.t[2, 4, 7].item() == dense[4, 2 * 32 + 7].item()
+    t.t[0, :, :5] = dense.view(5, 3, 32).permute(1, 0, 2)
+    assert t.t.shape == (1, 3, 16, 32) and torch.equal(t.dense(), dense)
+    assert t.t[0, 2, 4, 7].item() == dense[4, 2 * 32 + 7].item()
+    t2 = ops.Tiled16(20, 64, torch.float32, "cpu")                   # lock-step batches above 16: a second block of tiles
+    t2.t.zero_()
+    d2 = torch.arange(20 * 64, dtype=torch.float32).view(20, 64)
+    pad = torch.zeros(32, 64)
+    pad[:20] = d2
+    t2.t.copy_(pad.view(2, 16, 2, 32).permute(0, 2, 1, 3))
+    assert t2.t.shape == (2, 2, 16, 32) and torch.equal(t2.dense(), d2) and t2.t[1, 1, 3, 5].item() == d2[19, 37].item()
     hdr = open(os.path.join(ROOT, "include", "seedx_hip.h")).read()
     from seedx_amd import _lib
     assert "#define SX_TILED16 0x100" in hdr and _lib.SX_TILED16 == 0x100
     with pytest.raises(AssertionError):
-        ops.Tiled16(17, 64, torch.float32, "cpu")
+        ops.Tiled16(33, 64, torch.float32, "cpu")
 
 
 def test_decode_attention_policy_is_tp_invariant():

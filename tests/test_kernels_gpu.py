@@ -361,13 +361,13 @@ def test_gemv_tiled_activations_and_split_k(dev, dtype, M, N, K):
     if K <= 6144:                      # the norm kernel's register-resident limit
         h = ops.rmsnorm(x32, gamma, 1e-5, dtype)
         ht = ops.rmsnorm(x32, gamma, 1e-5, dtype, tiled=True)
-        assert ht.t.shape == (K // 32, 16, 32) and torch.equal(ht.dense(), h)
-        assert torch.equal(ht.t[3, M - 1], h[M - 1, 96:128])
+        assert ht.t.shape == (1, K // 32, 16, 32) and torch.equal(ht.dense(), h)
+        assert torch.equal(ht.t[0, 3, M - 1], h[M - 1, 96:128])
     else:                              # tile by hand (what the GLU epilogue produces for the down projection)
         h = x32.to(dtype)
         ht = ops.Tiled16(M, K, dtype, dev)
         ht.t.fill_(float("nan"))       # padding rows may hold anything
-        ht.t[:, :M] = h.view(M, K // 32, 32).permute(1, 0, 2)
+        ht.t[0, :, :M] = h.view(M, K // 32, 32).permute(1, 0, 2)
     # consumer: same bits from tiled and row-major x
     a = ops.gemv(h, w, residual=res, out_dtype=torch.float32, w_tiles=t)
     b = ops.gemv(ht, w, residual=res, out_dtype=torch.float32, w_tiles=t)
@@ -375,7 +375,7 @@ def test_gemv_tiled_activations_and_split_k(dev, dtype, M, N, K):
     assert relerr(a, h.float() @ w.float().t() + res) < 5e-5
     # producer 2: skinny-GEMM epilogue, plain and GLU
     y, yt = ops.gemv(ht, w, w_tiles=t), ops.gemv(ht, w, w_tiles=t, y_tiled=True)
-    assert yt.t.shape == (N // 32, 16, 32) and torch.equal(yt.dense(), y)
+    assert yt.t.shape == (1, N // 32, 16, 32) and torch.equal(yt.dense(), y)
     g, gt = ops.gemv(ht, w, act="silu", glu=True, w_tiles=t), ops.gemv(ht, w, act="silu", glu=True, w_tiles=t, y_tiled=True)
     if (N // 2) % 32 == 0:
         assert torch.equal(gt.dense(), g)
@@ -392,7 +392,7 @@ def test_gemv_tiled_activations_and_split_k(dev, dtype, M, N, K):
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("nsplit", [8, 1, 3])
-@pytest.mark.parametrize("G,H,D,tiled", [(7, 8, 128, True), (1, 5, 128, False), (16, 4, 64, True), (3, 2, 112, False)])
+@pytest.mark.parametrize("G,H,D,tiled", [(7, 8, 128, True), (1, 5, 128, False), (16, 4, 64, True), (3, 2, 112, False), (20, 4, 128, True)])
 def test_attn_decode_fused_equals_three_kernel_form(dev, dtype, G, H, D, tiled, nsplit):
     """sx_attn_decode_fused (RoPE + KV append + split-KV attention + combine in one launch) against sx_rope_kv_append_b +
     sx_attn_decode_b: the SAME bits in the output and in both caches, for positions 0, mid-chunk, chunk boundaries and the last
@@ -430,14 +430,16 @@ def test_attn_decode_fused_equals_three_kernel_form(dev, dtype, G, H, D, tiled, 
 
 def test_attn_decode_b_tiled(dev):
     from seedx_amd import ops
-    G, H, D, T = 7, 8, 128, 96
+    H, D, T = 8, 128, 96
     dt = torch.bfloat16
-    q = rnd((G, H, D), dt, dev, seed=61)
-    kc, vc = rnd((G, H, T, D), dt, dev, seed=62), rnd((G, H, T, D), dt, dev, seed=63)
-    ctx = torch.tensor([1, 5, 96, 40, 17, 64, 33], dtype=torch.int32, device=dev)
-    a = ops.attn_decode_b(q, kc, vc, ctx, 0.088)
-    b = ops.attn_decode_b(q, kc, vc, ctx, 0.088, out_tiled=True)
-    assert b.t.shape == (H * D // 32, 16, 32) and torch.equal(b.dense(), a)
+    for G in (7, 20):                                  # 20: sequences 16..19 land in the second block of tiles
+        q = rnd((G, H, D), dt, dev, seed=61)
+        kc, vc = rnd((G, H, T, D), dt, dev, seed=62), rnd((G, H, T, D), dt, dev, seed=63)
+        ctx = torch.tensor(([1, 5, 96, 40, 17, 64, 33] * 3)[:G], dtype=torch.int32, device=dev)
+        a = ops.attn_decode_b(q, kc, vc, ctx, 0.088)
+        b = ops.attn_decode_b(q, kc, vc, ctx, 0.088, out_tiled=True)
+        assert b.t.shape == ((G + 15) // 16, H * D // 32, 16, 32) and torch.equal(b.dense(), a)
+    G = 7
 
 
 @pytest.mark.parametrize("ctx", [1, 17, 166, 1000])
@@ -638,7 +640,7 @@ def test_gemm_fused_groupnorm_statistics(dev, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("M", [5, 16])
+@pytest.mark.parametrize("M", [5, 16, 32])
 def test_gemv_rmsnorm_fold(dev, dtype, M):
     """RMSNorm folded into the decode step's skinny GEMMs (sx_gemv_args.x16_out / row_ssq_*): the residual GEMV (o / down shapes,
     incl. the split-K one) emits the new residual stream x also as 16-bit operand tiles and its rows' sums of squares per
@@ -651,12 +653,13 @@ def test_gemv_rmsnorm_fold(dev, dtype, M):
         a = (torch.randn(M, K, generator=g) * 0.5).to(dtype).to(dev)
         w = (torch.randn(H, K, generator=g) / K ** 0.5).to(dtype).to(dev)
         res = torch.randn(M, H, generator=g).to(dev)
-        ws = torch.zeros(16384 + 8 * 16 * H * 4, dtype=torch.uint8, device=dev)
+        ws = torch.zeros(16384 + 8 * 32 * H * 4, dtype=torch.uint8, device=dev)
         wt = ops.pack_decode_tiles(w)
         at = ops.Tiled16(M, K, dtype, dev)                                 # the operand as MFMA tiles [K/32][16][32]
-        pad = torch.zeros(16, K, dtype=dtype, device=dev)
+        nb = (M + 15) // 16                                                # M = 32: two 16-row blocks of tiles
+        pad = torch.zeros(16 * nb, K, dtype=dtype, device=dev)
         pad[:M] = a
-        at.t.copy_(pad.view(16, K // 32, 32).permute(1, 0, 2))
+        at.t.copy_(pad.view(nb, 16, K // 32, 32).permute(0, 2, 1, 3))
         y_plain = ops.gemv(at, w, residual=res, out_dtype=torch.float32, w_tiles=wt, workspace=ws)
         y, x16, ssq = ops.gemv(at, w, residual=res, out_dtype=torch.float32, w_tiles=wt, workspace=ws, emit_norm=True)
         assert torch.equal(y, y_plain), "emitting the norm inputs must not change the fp32 output"
@@ -667,7 +670,7 @@ def test_gemv_rmsnorm_fold(dev, dtype, M):
         # the same launch over 20-row decode tiles (w_layout 2: 256 equal workgroups for N = 5120) gives the same bits
         w20 = ops.pack_decode_tiles20(w)
         y20, x16b, ssq20 = ops.gemv(at, w, residual=res, out_dtype=torch.float32, w_tiles20=w20, workspace=ws, emit_norm=True)
-        assert ssq20.shape == (16, 256) and torch.equal(x16b.dense(), y20.to(dtype))
+        assert ssq20.shape == (16 * nb, 256) and torch.equal(x16b.dense(), y20.to(dtype))
         # K = 5120: same per-wave k ranges and MFMA order → the same bits; K = 13824: the 16-row path splits K over 4 workgroups
         # (another summation order), the balanced path does not
         assert torch.equal(y20, y_plain) if K == 5120 else relerr(y20, y_plain) < 2e-6

@@ -1,0 +1,10 @@
+set -x
+timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_batched_decode_gpu.py -q -m gpu -x 2>&1 | tail -4
+timeout 900 python bench.py --config 2 --batch 32 --steps 3 --warmup 1 --also-dtype none --no-cpu-baseline 2>/dev/null > /tmp/line.json
+python - <<PY
+import json
+d = json.load(open("/tmp/line.json"))
+gr = d["roofline_phases"]["decode"]["graph_replay"]
+print("config 2 batch 32 (U=2): %.3f gens/s, %.1f ms per step, decode graph replay %.3f ms per token step = %.0f GB/s (%.3f of HBM peak)" % (d["value"], d["ms_per_step"], gr["ms_per_token"], gr["achieved"], gr["frac"]))
+PY
+cp /tmp/line.json gpurun_out/r4_bench_config2_batch32.json
