@@ -172,6 +172,13 @@ def test_euler_tables():
     s = EulerDiscreteScheduler()
     s.set_timesteps(50)
     assert torch.equal(s.timesteps, ts) and torch.allclose(s.sigmas, sig) and abs(s.init_noise_sigma - init) < 1e-5
+    # known answers of the scaled-linear 0.00085 → 0.012 schedule, published with the Stable Diffusion samplers
+    # (k-diffusion's sigma_min / sigma_max for SD: 0.0292 / 14.6146): the un-interpolated 1000-step table
+    _, full, _ = ru.euler_tables(1000, steps_offset=0)
+    assert abs(float(full[0]) - 14.6146) < 1e-3 and abs(float(full[-2]) - 0.0292) < 1e-4
+    s.config["steps_offset"] = 0
+    s.set_timesteps(1000)
+    assert abs(float(s.sigmas[0]) - 14.6146) < 1e-3 and abs(float(s.sigmas[-2]) - 0.0292) < 1e-4
 
 
 def test_oracle_cfg_loops_are_consistent():
