@@ -426,7 +426,7 @@ def measure_roofline(w):
     Returns (roofline of the dominant kernel family, per-phase dict)."""
     from seedx_amd import _lib, ops
     lib = _lib.load()
-    real = {n: getattr(lib, n) for n in ("sx_gemm", "sx_gemm_gn", "sx_gemv", "sx_attention", "sx_attn_decode_b", "sx_attn_decode_fused")}
+    real = {n: getattr(lib, n) for n in ("sx_gemm", "sx_gemm_gn", "sx_gemm_ln", "sx_gemv", "sx_attention", "sx_attn_decode_b", "sx_attn_decode_fused")}
     rec = []                       # (family, phase, flops, bytes, start, end)
     executed = {}                  # phase -> MFMA FLOPs actually issued (plane-carrying launches counted with their tripled K)
     stack = ["other"]
@@ -443,12 +443,15 @@ def measure_roofline(w):
     def h_gemm(args_ref, *rest):
         # sx_gemm(args, stream) | sx_gemm_gn(args, stats, groups, rows, fused, stream): the same launch, with the next GroupNorm's
         # statistics accumulated in its epilogue
-        fn = real["sx_gemm"] if len(rest) == 1 else real["sx_gemm_gn"]
+        # | sx_gemm_ln(args, ln, stream): the LayerNorm ahead of / behind it folded in (a producer also writes the 16-bit copy)
+        fn = real[{1: "sx_gemm", 2: "sx_gemm_ln"}.get(len(rest), "sx_gemm_gn")]
         a = args_ref._obj
         n_out = a.N // 2 if a.glu else a.N
         n_st = a.n_valid if a.n_valid else n_out
         a_bytes = 2.0 * (a.B * a.Hin * a.Win * a.Cin if a.a_mode == 1 else a.M * a.K)   # operands once + output once
         byt = a_bytes + 2.0 * a.N * a.K + a.M * n_st * (4.0 if a.out_dtype == 2 else 2.0) + (4.0 * a.M * n_st if a.residual else 0.0)
+        if len(rest) == 2 and rest[0]._obj.row_stats_out:
+            byt += 2.0 * a.M * a.N
         executed[stack[-1]] = executed.get(stack[-1], 0.0) + 2.0 * a.M * a.N * a.K
         return timed("gemm", 2.0 * a.M * a.N * a.K / ops.OPERAND_PLANES, byt, fn, args_ref, *rest)
 
@@ -512,7 +515,7 @@ def measure_roofline(w):
         if loop is not None:
             patched.append(phase_wrap(loop, "run", "unet"))
             patched.append(phase_wrap(w.adapter, "_finish", "vae"))
-        lib.sx_gemm, lib.sx_gemm_gn, lib.sx_gemv, lib.sx_attention = h_gemm, h_gemm, h_gemv, h_attn
+        lib.sx_gemm, lib.sx_gemm_gn, lib.sx_gemm_ln, lib.sx_gemv, lib.sx_attention = h_gemm, h_gemm, h_gemm, h_gemv, h_attn
         if agent is not None:
             lib.sx_attn_decode_b = h_attn_decode
             lib.sx_attn_decode_fused = h_attn_decode_fused

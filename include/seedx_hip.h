@@ -90,6 +90,26 @@ int sx_gemm(const sx_gemm_args* args, void* stream);
  * squares) of the stored fp32 output. Only the 256-row ping-pong tiles carry it: *fused_host = 1 if this launch accumulated,
  * 0 if the GEMM ran unchanged (then run sx_groupnorm's own statistics pass). */
 int sx_gemm_gn(const sx_gemm_args* args, double* stats, int groups, int rows_per_sample, int* fused_host, void* stream);
+/* A LayerNorm folded into the GEMMs either side of it (reference: every `norm1/2/3 → to_q / to_k / to_v / ff.net[0]` pair of the SDXL
+ * transformer blocks [ext BasicTransformerBlock], called per step from pipeline_stable_diffusion_xl_t2i_edit.py:915-922).
+ *   PRODUCER launch (row_stats_out != NULL; plain fp32 output, e.g. the attention out-projection + residual): besides C it stores
+ *     x16_out[M][ld_x16] = C rounded to the operand dtype and adds every row's (sum, sum of squares) over this launch's columns to
+ *     row_stats_out[M][2] (fp64 atomics; zero beforehand).
+ *   CONSUMER launch (row_stats_in != NULL; A = that x16 copy, W = the weight with gamma folded in, bias = b + W beta):
+ *     out = epilogue(rstd_m * (A W'^T - mu_m * colsum) + bias), mu / rstd of row m from row_stats_in (complete), colsum[n] = sum_k W'[n][k].
+ * Ping-pong 256-row tiles only: fails (SX_ERR_INVALID) for a shape the cost model gives a lock-step tile — sx_gemm_pick_tile(...) >= 7
+ * says beforehand; such shapes keep the separate sx_layernorm launch. */
+typedef struct sx_gemm_ln_args {
+  void* x16_out;               /* producer */
+  double* row_stats_out;
+  const double* row_stats_in;  /* consumer */
+  const float* colsum;
+  int32_t ld_x16;
+  int32_t dim;                 /* LayerNorm width (= K of the consumer) */
+  float eps;
+  int32_t reserved;
+} sx_gemm_ln_args;
+int sx_gemm_ln(const sx_gemm_args* args, const sx_gemm_ln_args* ln, void* stream);
 /* tuning/test hook: force tile config 0..8 (lock-step 128x128, 128x80, 64x128, 64x64, 256x256, 256x320, 256x160; ping-pong
  * 256x256, 256x320 — the two-wave-group schedule of csrc/gemm_pp.hip); -1 = automatic (cost model); 100/101 = 2-D XCD
  * partition off/on; 200/201 = ping-pong tiles excluded from / offered to the cost model; 300+g = g tile-rows per in-XCD

@@ -26,6 +26,11 @@ class GemmArgs(C.Structure):
                 ("stride", c_i32), ("upsample", c_i32), ("ld_bias2d", c_i32), ("pad_mode", c_i32)]
 
 
+class GemmLnArgs(C.Structure):
+    _fields_ = [("x16_out", c_vp), ("row_stats_out", c_vp), ("row_stats_in", c_vp), ("colsum", c_vp),
+                ("ld_x16", c_i32), ("dim", c_i32), ("eps", c_f32), ("reserved", c_i32)]
+
+
 class GemvArgs(C.Structure):
     _fields_ = [("x", c_vp), ("W", c_vp), ("y", c_vp), ("residual", c_vp),
                 ("M", c_i32), ("N", c_i32), ("K", c_i32),
@@ -73,6 +78,7 @@ SIGNATURES = {
     "sx_version": [],
     "sx_gemm": [C.POINTER(GemmArgs), c_vp],
     "sx_gemm_gn": [C.POINTER(GemmArgs), c_vp, c_i32, c_i32, C.POINTER(c_i32), c_vp],
+    "sx_gemm_ln": [C.POINTER(GemmArgs), C.POINTER(GemmLnArgs), c_vp],
     "sx_gemm_force_tile": [c_i32],
     "sx_gemm_debug_stamps": [c_vp],
     "sx_gemm_pick_tile": [c_i32, c_i32, c_i32, c_i32, c_i32],

@@ -412,9 +412,18 @@ extern "C" int sx_gemm_force_tile(int cfg) {  // tuning / test hook: -1 = automa
   return SX_OK;
 }
 
-static int gemm_impl(const sx_gemm_args* a, double* gn_stats, int gn_groups, int gn_rows, int* gn_fused, void* stream);
+static int gemm_impl(const sx_gemm_args* a, double* gn_stats, int gn_groups, int gn_rows, int* gn_fused, const sx_gemm_ln_args* ln,
+                     void* stream);
 
-extern "C" int sx_gemm(const sx_gemm_args* a, void* stream) { return gemm_impl(a, nullptr, 0, 0, nullptr, stream); }
+extern "C" int sx_gemm(const sx_gemm_args* a, void* stream) { return gemm_impl(a, nullptr, 0, 0, nullptr, nullptr, stream); }
+
+// sx_gemm with a LayerNorm folded into the two GEMMs around it (include/seedx_hip.h sx_gemm_ln_args). Ping-pong tiles only: the call
+// fails when the cost model would run this shape on a lock-step tile — ask sx_gemm_pick_tile first and keep the separate
+// sx_layernorm launch for those shapes.
+extern "C" int sx_gemm_ln(const sx_gemm_args* a, const sx_gemm_ln_args* ln, void* stream) {
+  SX_CHECK(ln && (ln->row_stats_in || ln->row_stats_out), "sx_gemm_ln: neither a producer nor a consumer role");
+  return gemm_impl(a, nullptr, 0, 0, nullptr, ln, stream);
+}
 
 // sx_gemm + GroupNorm statistics of the output it stores (the statistics pass of the NEXT sx_groupnorm, fused into this launch's
 // epilogue): stats[row / rows_per_sample][column / (N / groups)][2] += (sum, sum of squares), fp64, by atomics — `stats` must be
@@ -422,10 +431,11 @@ extern "C" int sx_gemm(const sx_gemm_args* a, void* stream) { return gemm_impl(a
 // reports whether THIS launch accumulated; if 0 the GEMM ran unchanged and the caller runs sx_groupnorm's own statistics pass.
 extern "C" int sx_gemm_gn(const sx_gemm_args* a, double* stats, int groups, int rows_per_sample, int* fused, void* stream) {
   SX_CHECK(stats && fused && groups > 0 && rows_per_sample > 0, "sx_gemm_gn: bad statistics arguments");
-  return gemm_impl(a, stats, groups, rows_per_sample, fused, stream);
+  return gemm_impl(a, stats, groups, rows_per_sample, fused, nullptr, stream);
 }
 
-static int gemm_impl(const sx_gemm_args* a, double* gn_stats, int gn_groups, int gn_rows, int* gn_fused, void* stream) {
+static int gemm_impl(const sx_gemm_args* a, double* gn_stats, int gn_groups, int gn_rows, int* gn_fused, const sx_gemm_ln_args* ln,
+                     void* stream) {
   SX_CHECK(a && a->A && a->W && a->C, "sx_gemm: null pointer");
   if (gn_fused) *gn_fused = 0;
   SX_CHECK(a->dtype == SX_F16 || a->dtype == SX_BF16, "sx_gemm: dtype must be f16/bf16");
@@ -477,11 +487,34 @@ static int gemm_impl(const sx_gemm_args* a, double* gn_stats, int gn_groups, int
   // when its epilogue combination exists (forced 4 / 5 keep the lock-step kernels for A/B runs).
   // tile configs 0..6: lock-step kernels (this file); 7 / 8: ping-pong 256x256 / 256x320 (gemm_pp.hip), offered to the cost
   // model when their epilogue combination is instantiated
+  if (ln) {
+    SX_CHECK(a->a_mode == SX_A_LINEAR && !gn_stats, "sx_gemm_ln: linear GEMMs only");
+    SX_CHECK(!(ln->row_stats_in && ln->row_stats_out), "sx_gemm_ln: a launch is a producer or a consumer, not both");
+    if (ln->row_stats_out) {
+      SX_CHECK(ln->x16_out && a->out_dtype == SX_F32 && !a->glu && a->act == SX_ACT_NONE && p.n_valid == a->N,
+               "sx_gemm_ln producer: needs x16_out and a plain fp32 output of all N columns");
+      SX_CHECK(ln->ld_x16 >= a->N && ln->ld_x16 % 4 == 0 && (((size_t)ln->x16_out) & 7) == 0, "sx_gemm_ln producer: ld_x16=%d", ln->ld_x16);
+      p.ln_x16 = ln->x16_out; p.ln_ldx = ln->ld_x16; p.ln_out = ln->row_stats_out;
+    } else {
+      SX_CHECK(ln->colsum && ln->dim == a->K && ln->eps > 0.f, "sx_gemm_ln consumer: colsum / dim (= K) / eps");
+      SX_CHECK(a->out_dtype == a->dtype && !a->residual && !a->bias2d, "sx_gemm_ln consumer: 16-bit output, no residual / bias2d");
+      p.ln_in = ln->row_stats_in; p.ln_cs = ln->colsum; p.ln_eps = ln->eps; p.ln_inv_dim = 1.0f / (float)ln->dim;
+    }
+  }
   unsigned allow = 0x7f;
+  if (ln) allow = 0;            // ping-pong tiles or nothing
   if (g_use_pp || g_force_tile == 7) allow |= pp_supported(p, a->dtype, 256, a->a_mode) ? 0x80u : 0u;
   if (g_use_pp || g_force_tile == 8) allow |= pp_supported(p, a->dtype, 320, a->a_mode) ? 0x100u : 0u;
   SX_CHECK(!(g_force_tile == 7 || g_force_tile == 8) || ((allow >> g_force_tile) & 1u),
            "sx_gemm: forced ping-pong tile has no kernel for this epilogue");
+  if (ln) {
+    // the fold exists on the tiles the cost model gives this shape without it, or not at all (no silent change of tile)
+    const int plain = pick_tile(a->M, a->N, a->K, a->glu != 0, false, g_force_tile, 0x1ff);
+    SX_CHECK((plain == 7 || plain == 8) && ((allow >> plain) & 1u),
+             "sx_gemm_ln: M=%d N=%d K=%d does not run on a ping-pong tile with this epilogue (tile %d): keep sx_layernorm for it", a->M,
+             a->N, a->K, plain);
+    allow = 1u << plain;
+  }
   const int cfg = pick_tile(a->M, a->N, a->K, a->glu != 0, a->a_mode == SX_A_CONV3X3, g_force_tile, allow);
   if (cfg == 7 || cfg == 8) {
     // fused GroupNorm statistics: fp32 output of all N columns, whole 256-row tiles inside one sample, even channels per group

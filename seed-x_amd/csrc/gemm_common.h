@@ -23,6 +23,17 @@ struct GemmP {
   // squares) over the tile's rows and the group's channels; sample = row / gn_rows, group = column / gn_cpg
   double* gn_stats;
   int gn_cpg, gn_groups, gn_rows;
+  // LayerNorm folded into the GEMMs either side of it (sx_gemm_ln; ping-pong tiles only).
+  //   producer (fp32 output): also store the output rounded to the operand dtype (ln_x16 [M][ln_ldx]) and add this tile's
+  //     per-row (sum, sum of squares) to ln_out[M][2] (fp64 atomics);
+  //   consumer (A = that 16-bit copy, W = weight with gamma folded in): out = rstd_m (acc - mu_m cs_n) + bias'_n, with (mu, rstd)
+  //     of row m from ln_in[M][2], cs_n = sum_k W'[n][k]
+  void* ln_x16;
+  double* ln_out;
+  const double* ln_in;
+  const float* ln_cs;
+  int ln_ldx;
+  float ln_eps, ln_inv_dim;
 };
 
 template <int N>

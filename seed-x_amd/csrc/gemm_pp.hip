@@ -42,10 +42,13 @@ namespace sxk_gemm {
     __builtin_amdgcn_sched_barrier(0);       \
   } while (0)
 
-template <typename TT, int BN, int AMODE, bool OUT32, int ACT, bool GLU, int VAR>
+// LN: 0 = none; 1 = LayerNorm-fold consumer (per-row scale / shift ahead of bias and activation); 2 = producer (fp32 output + its
+// 16-bit copy + per-row sums) — see GemmP::ln_*
+template <typename TT, int BN, int AMODE, bool OUT32, int ACT, bool GLU, int VAR, int LN = 0>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   typedef typename TT::vec8 vec8;
+  static_assert(LN != 2 || (OUT32 && !GLU && ACT == SX_ACT_NONE), "the LayerNorm producer is the plain fp32-output epilogue");
   constexpr int BM = 256, TN = BN / 4, FN = TN / 16, FM = 8, FH = 4;
   constexpr int NB = BN / 64;                 // W DMA slots (8 rows x 128 B) per wave per k-tile
   constexpr int C1 = NB - 3, C2 = 3;          // W slots issued in L3 (beside the two A0 slots) and in L4
@@ -65,6 +68,17 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p) {
   if (!tile_coords(p, blockIdx.x, gridDim.x, tile_m, tile_n)) return;  // padding block (exits before any barrier)
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
+  // LayerNorm fold, consumer: the tile's 256 (sum, sum of squares) pairs are requested HERE, ahead of the DMA prologue, and turned
+  // into (rstd, -rstd mu) in the 2 KB of LDS behind the operand ring once the prologue is issued — at the epilogue's start the same
+  // loads would be an exposed L2 round trip per tile (20 rounds of tiles in the GEGLU projection)
+  double ln_s1 = 0.0, ln_s2 = 0.0;
+  if constexpr (LN == 1) {
+    if (tid < BM) {
+      const int m = m0 + tid < p.M ? m0 + tid : p.M - 1;
+      ln_s1 = p.ln_in[2 * (size_t)m];
+      ln_s2 = p.ln_in[2 * (size_t)m + 1];
+    }
+  }
   __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)p.a_bytes, 0x00020000);
   __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, (int)p.w_bytes, 0x00020000);
 
@@ -204,6 +218,15 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p) {
   issue_x(1, 1, kx);
   issue_y(1, 1);
   tap_next(kx);          // kx → k-tile 2
+  float* ln_lds = (float*)(smem + 2 * STAGE);
+  if constexpr (LN == 1) {
+    if (tid < BM) {
+      const double mu = ln_s1 * (double)p.ln_inv_dim;
+      const double var = ln_s2 * (double)p.ln_inv_dim - mu * mu;
+      const float rstd = __builtin_amdgcn_rsqf((float)(var > 0.0 ? var : 0.0) + p.ln_eps);
+      *(f32x2_t*)(ln_lds + 2 * tid) = (f32x2_t){rstd, -rstd * (float)mu};      // read in the epilogue, many barriers later
+    }
+  }
   wait_vmcnt<WAITN>();   // X(0), Y(0) landed (this wave's share)
   PP_SYNC();
   if (p.dbg) t_first = __builtin_amdgcn_s_memtime();
@@ -324,6 +347,13 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p) {
     o[1] = pack2<TT>(x[2], x[3]);
     return o;
   };
+  // LayerNorm fold, consumer: the row loop reads (rstd, -rstd mu) of its rows from the LDS table written during the prologue
+  f32x4_t lcs[LN == 1 ? FN : 1];
+  if constexpr (LN == 1) {
+#pragma unroll
+    for (int i = 0; i < FN; ++i) lcs[i] = *(const f32x4_t*)(p.ln_cs + ncol[i]);
+  }
+  float lsum[LN == 2 ? FM : 1], lsq[LN == 2 ? FM : 1];
   // fused GroupNorm statistics (fp32-output kernels only): per lane the sums of its two column PAIRS of every n-fragment over its 8
   // rows — a pair never straddles a group (channels per group are even), a quad can (C = 320: 10 channels per group)
   const bool gn = OUT32 && p.gn_stats != nullptr;
@@ -336,8 +366,14 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p) {
     const bool mok = m < p.M;
     const int mc = mok ? m : p.M - 1;
     f32x4_t v[FN];
+    if constexpr (LN == 1) {
+      const f32x2_t ab = *(const f32x2_t*)(ln_lds + 2 * (g * 128 + j * 16 + (lane & 15)));
 #pragma unroll
-    for (int i = 0; i < FN; ++i) v[i] = acc[i][j] + bv[i];
+      for (int i = 0; i < FN; ++i) v[i] = acc[i][j] * ab[0] + (lcs[i] * ab[1] + bv[i]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < FN; ++i) v[i] = acc[i][j] + bv[i];
+    }
     if (b2_rows) {
       const float* b2 = p.bias2d + (size_t)(mc / p.bias2d_rows) * p.ldb2;
 #pragma unroll
@@ -366,6 +402,37 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p) {
 #pragma unroll
       for (int i = 0; i < FN; ++i)
         if (mok && nok[i]) *(f32x4_t*)((float*)p.C + (size_t)m * p.ldc + nout[i]) = v[i];
+      if constexpr (LN == 2) {
+        // the row's 16-bit copy (the operand of the GEMM behind the folded LayerNorm) and this lane's share of its two sums
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < FN; ++i) {
+          if (mok && nok[i]) {
+            s1 += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+            s2 += (v[i][0] * v[i][0] + v[i][1] * v[i][1]) + (v[i][2] * v[i][2] + v[i][3] * v[i][3]);
+          }
+        }
+        lsum[j] = s1;
+        lsq[j] = s2;
+        const bool xwide = (p.ln_ldx & 7) == 0 && (((size_t)p.ln_x16) & 15) == 0;
+#pragma unroll
+        for (int i = 0; i < FN; ++i) {
+          if ((i & 1) == 0 && i + 1 < FN && xwide && pair_ok[i >> 1]) {      // 16-B stores, as in the 16-bit epilogue below
+            const u32x2_t o0 = pack4(v[i]), o1 = pack4(v[i + 1]);
+            const auto w0 = __builtin_amdgcn_permlane16_swap(o0[0], o1[0], false, false);
+            const auto w1 = __builtin_amdgcn_permlane16_swap(o0[1], o1[1], false, false);
+            if (mok) {
+              const u32x4_t w4 = {w0[0], w1[0], w0[1], w1[1]};
+              const int q = lane >> 4;
+              const int col = n0 + wc * TN + i * 16 + (q & 1) * 16 + (q >> 1) * 8;
+              *(u32x4_t*)((unsigned short*)p.ln_x16 + (size_t)m * p.ln_ldx + col) = w4;
+            }
+            continue;
+          }
+          if ((i & 1) && xwide && pair_ok[i >> 1]) continue;                   // stored with its even partner
+          if (mok && nok[i]) *(u32x2_t*)((unsigned short*)p.ln_x16 + (size_t)m * p.ln_ldx + nout[i]) = pack4(v[i]);
+        }
+      }
       if (gn && mok) {
 #pragma unroll
         for (int i = 0; i < FN; ++i) {
@@ -397,6 +464,27 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p) {
         if (!GLU && wide && (i & 1) && pair_ok[i >> 1]) continue;  // stored with its even partner
         if (mok && nok[i]) *(u32x2_t*)((unsigned short*)p.C + (size_t)m * p.ldc + nout[i]) = pack4(v[i]);
       }
+    }
+  }
+  if constexpr (LN == 2) {
+    // per-row sums: the four 16-lane rows of a wave hold different column quads of the same 16 tile rows → two xor shuffles, one
+    // LDS slot per (column wave, row), the four column waves added in a fixed order, one fp64 atomic pair per row and tile
+    float* racc = (float*)smem;                    // [4 wc][256 rows][2]
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < FM; ++j) {
+      float s1 = lsum[j], s2 = lsq[j];
+      s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+      s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+      if (lane < 16) *(f32x2_t*)(racc + ((size_t)(wc * BM + g * 128 + j * 16 + lane)) * 2) = (f32x2_t){s1, s2};
+    }
+    __syncthreads();
+    if (tid < BM && m0 + tid < p.M) {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) { s1 += racc[(w * BM + tid) * 2]; s2 += racc[(w * BM + tid) * 2 + 1]; }
+      atomicAdd(&p.ln_out[2 * (size_t)(m0 + tid)], (double)s1);
+      atomicAdd(&p.ln_out[2 * (size_t)(m0 + tid) + 1], (double)s2);
     }
   }
   if (OUT32 && gn) {
@@ -457,13 +545,13 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p) {
 
 int g_pp_variant = 0;
 
-template <typename TT, int BN, int AMODE, bool OUT32, int ACT, bool GLU, int VAR>
+template <typename TT, int BN, int AMODE, bool OUT32, int ACT, bool GLU, int VAR, int LN = 0>
 static int launch_one(const GemmP& p0, hipStream_t st) {
   GemmP p = p0;
   p.dbg = g_dbg;
   const int grid = plan_grid(p, 256, BN, g_xcd_2d, g_gm);
-  constexpr size_t lds = 2 * (size_t)(256 + BN) * 128;
-  auto k = gemm_pp_kernel<TT, BN, AMODE, OUT32, ACT, GLU, VAR>;
+  constexpr size_t lds = 2 * (size_t)(256 + BN) * 128 + (LN == 1 ? 2048 : 0);      // + the consumer's (rstd, -rstd mu) table
+  auto k = gemm_pp_kernel<TT, BN, AMODE, OUT32, ACT, GLU, VAR, LN>;
   static hipError_t attr[16];
   static bool done[16];
   int dev = 0;
@@ -499,6 +587,9 @@ static int epi_code(const GemmP& p, int dtype) {
 bool pp_supported(const GemmP& p, int dtype, int bn, int a_mode) {
   const int e = epi_code(p, dtype);
   if (e < 0) return false;
+  // LayerNorm fold: consumers = the 16-bit linear epilogues behind a LayerNorm (plain, GELU-GLU), producer = fp32 linear output
+  if (p.ln_in && !(a_mode == SX_A_LINEAR && (e == 0 || e == 2) && !p.ln_out)) return false;
+  if (p.ln_out && !(a_mode == SX_A_LINEAR && e == 4 && !p.gn_stats)) return false;
   if (bn == 320 && (e == 2 || e == 3)) return false;
   if (a_mode == SX_A_CONV3X3 && !(e == 0 || e == 4)) return false;
   if (a_mode == SX_A_CONV3X3 && p.upsample && !(p.stride == 1 && p.pad == 1)) return false;
@@ -509,6 +600,15 @@ template <typename TT>
 static int launch_t(const GemmP& p, int dtype, int bn, int a_mode, hipStream_t st) {
   const int e = epi_code(p, dtype);
 #define PP_CASE(BNV, AM, O32, ACTV, GLUV) return launch_one<TT, BNV, AM, O32, ACTV, GLUV, 0>(p, st)
+  if (p.ln_in) {
+    if (e == 2) return launch_one<TT, 256, SX_A_LINEAR, false, SX_ACT_GELU, true, 0, 1>(p, st);
+    if (bn == 256) return launch_one<TT, 256, SX_A_LINEAR, false, SX_ACT_NONE, false, 0, 1>(p, st);
+    return launch_one<TT, 320, SX_A_LINEAR, false, SX_ACT_NONE, false, 0, 1>(p, st);
+  }
+  if (p.ln_out) {
+    if (bn == 256) return launch_one<TT, 256, SX_A_LINEAR, true, SX_ACT_NONE, false, 0, 2>(p, st);
+    return launch_one<TT, 320, SX_A_LINEAR, true, SX_ACT_NONE, false, 0, 2>(p, st);
+  }
   if (a_mode == SX_A_LINEAR) {
     if (bn == 256) {
       if (std::is_same<TT, BF16>::value && e == 0 && g_pp_variant == 1) return launch_one<BF16, 256, SX_A_LINEAR, false, SX_ACT_NONE, false, 1>(p, st);

@@ -63,6 +63,41 @@ class GnStats:
         return torch.zeros((n, B, groups, 2), dtype=torch.float64, device=device)
 
 
+class LnRows:
+    """A LayerNorm folded into the GEMMs either side of it (sx_gemm_ln): the PRODUCER (``gemm(..., ln_emit=rows)``: fp32 output)
+    also writes ``x16`` = its output rounded to the operand dtype and adds the rows' (sum, sum of squares) to ``stats`` [M, 2]
+    fp64 (zero beforehand); the CONSUMER (``gemm(rows.x16, w_folded, bias=b_folded, ln_apply=(rows, colsum, eps))``) applies
+    (mu, rstd) per row in its epilogue. Both launches must run on ping-pong tiles: ``ln_fold_ok`` says so beforehand."""
+    __slots__ = ("x16", "stats")
+
+    def __init__(self, M, C, dtype, device, stats=None):
+        self.x16 = torch.empty((M, C), dtype=dtype, device=device)
+        self.stats = stats if stats is not None else torch.zeros((M, 2), dtype=torch.float64, device=device)
+        assert self.stats.shape == (M, 2) and self.stats.dtype == torch.float64 and self.stats.is_contiguous()
+
+
+def gemm_tile(M, N, K, glu=False, conv=False):
+    """Tile config 0..8 the cost model gives an M x N x K problem (7 / 8 = the 256-row ping-pong tiles); host-only."""
+    return int(_lib.load().sx_gemm_pick_tile(int(M), int(N), int(K), 1 if glu else 0, 1 if conv else 0))
+
+
+def ln_fold_ok(M, C, consumers, producers):
+    """True when every GEMM around a LayerNorm of width C over M rows runs on a ping-pong tile. consumers: [(N, glu)] of the
+    projections behind the norm (K = C); producers: [K] of the fp32-output projections ahead of it (N = C)."""
+    return all(gemm_tile(M, n, C, glu) >= 7 for n, glu in consumers) and all(gemm_tile(M, C, k) >= 7 for k in producers)
+
+
+def fold_layernorm(w, bias, gamma, beta):
+    """(w', colsum, bias') of a projection behind LayerNorm(gamma, beta): w' = w * gamma in w's dtype, colsum[n] = sum_k w'[n, k]
+    (of the ROUNDED w': what the MFMA multiplies), bias' = bias + w beta. Per output row, so GLU-packed rows fold as they are."""
+    wf = (w.float() * gamma.float()[None, :]).to(w.dtype).contiguous()
+    cs = wf.float().sum(dim=1).contiguous()
+    b = w.float() @ beta.float()
+    if bias is not None:
+        b = b + bias.float()
+    return wf, cs, b.contiguous()
+
+
 GN_FUSE = os.environ.get("SX_GN_FUSE", "1") != "0"     # A/B switch (tools/bench_unet_ab.py): 0 = every GroupNorm runs its own statistics pass
 
 
@@ -78,9 +113,10 @@ def _launch_gemm(lib, args, gn, what):
 
 
 def gemm(a, w, bias=None, bias2d=None, bias2d_rows=0, residual=None, res_mod=0, act=None, glu=False,
-         out_dtype=None, out=None, n_valid=0, ld_bias2d=0, gn=None):
+         out_dtype=None, out=None, n_valid=0, ld_bias2d=0, gn=None, ln_emit=None, ln_apply=None):
     """out[M, N_out] = epilogue(a[M, K] @ w[N, K]^T). a, w: 16-bit contiguous. residual/bias fp32.
-    gn: optional GnStats of the output (the next GroupNorm's statistics pass fused into this launch, see GnStats)."""
+    gn: optional GnStats of the output (the next GroupNorm's statistics pass fused into this launch, see GnStats).
+    ln_emit / ln_apply: the two sides of a folded LayerNorm (see LnRows)."""
     lib = _lib.load()
     assert a.dim() == 2 and w.dim() == 2 and a.is_contiguous() and w.is_contiguous()
     assert a.dtype == w.dtype and a.dtype in (torch.float16, torch.bfloat16)
@@ -114,6 +150,18 @@ def gemm(a, w, bias=None, bias2d=None, bias2d_rows=0, residual=None, res_mod=0, 
     args.act = ACT[act]
     args.glu = 1 if glu else 0
     args.a_mode = SX_A_LINEAR
+    if ln_emit is not None or ln_apply is not None:
+        assert gn is None and not (ln_emit is not None and ln_apply is not None)
+        la = _lib.GemmLnArgs()
+        if ln_emit is not None:
+            assert ln_emit.x16.shape == (M, N) and ln_emit.x16.dtype == a.dtype and ln_emit.stats.shape[0] == M
+            la.x16_out, la.ld_x16, la.row_stats_out = ln_emit.x16.data_ptr(), ln_emit.x16.stride(0), ln_emit.stats.data_ptr()
+        else:
+            rows, colsum, eps = ln_apply
+            assert rows.stats.shape[0] == M and colsum.dtype == torch.float32 and colsum.numel() == N and colsum.is_contiguous()
+            la.row_stats_in, la.colsum, la.dim, la.eps = rows.stats.data_ptr(), colsum.data_ptr(), K, float(eps)
+        check(lib.sx_gemm_ln(C.byref(args), C.byref(la), _stream()), "sx_gemm_ln")
+        return out
     _launch_gemm(lib, args, gn, "sx_gemm")
     return out
 

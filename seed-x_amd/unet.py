@@ -15,12 +15,18 @@ cross-attention K/V of the (step-invariant) conditioning cached across the 50 de
 step in one GEMM.
 """
 import math
+import os
 import types
 
 import torch
 
 from . import ops
 from .llama import glu_pack_rows
+
+# LayerNorms of the transformer blocks folded into the GEMMs around them (ops.LnRows, sx_gemm_ln) wherever all of those GEMMs run on
+# ping-pong tiles (CFG batch >= 16 at 1024 px): - 1.7 % on the 50-step loop, same-process A/B (profiles/r4_ab_experiments.md).
+# SX_LN_FOLD=0 keeps the separate sx_layernorm launches (and saves the second copy of the folded weights, 2.5 GB).
+LN_FOLD = os.environ.get("SX_LN_FOLD", "1") != "0"
 
 SDXL_BASE_CONFIG = dict(in_channels=4, out_channels=4, block_out_channels=(320, 640, 1280), layers_per_block=2,
                         down_attn=(False, True, True), up_attn=(True, True, False), transformer_layers=(1, 2, 10),
@@ -54,6 +60,7 @@ class UNet2DConditionModel:
         self._sd, self._P = None, None
         self._ctx_key, self._ctx = None, None
         self._gn_arena, self._gn_next, self._n_gn_slots = None, 0, 64     # fused GroupNorm statistics slots per forward (47 used by SDXL)
+        self._ln_ok = {}                                                   # (rows, width) → LayerNorm fold usable (ops.ln_fold_ok)
 
     @classmethod
     def from_pretrained(cls, path, subfolder=None, **kw):
@@ -185,6 +192,13 @@ class UNet2DConditionModel:
                     wff1=glu_pack_rows(ffw[:half].contiguous(), ffw[half:].contiguous()),      # hidden * gelu(gate)
                     bff1=glu_pack_rows(ffb[:half].reshape(-1, 1).contiguous(), ffb[half:].reshape(-1, 1).contiguous()).reshape(-1).contiguous(),
                     wff2=lin16(b + ".ff.net.2.weight"), bff2=f32(b + ".ff.net.2.bias")))
+            if LN_FOLD:
+                # LayerNorm folded into the projections behind it (ops.LnRows): gamma into a second copy of the weight, beta
+                # into its bias; used for the shapes whose GEMMs all run on ping-pong tiles (decided per call in _transformer)
+                for blk in t["blocks"]:
+                    blk["f1"] = ops.fold_layernorm(blk["wqkv"], None, *blk["n1"])
+                    blk["f2"] = ops.fold_layernorm(blk["wq2"], None, *blk["n2"])
+                    blk["f3"] = ops.fold_layernorm(blk["wff1"], blk["bff1"], *blk["n3"])
             self._xattn.append(t)
             return t
 
@@ -327,8 +341,40 @@ class UNet2DConditionModel:
         scale = hd ** -0.5
         sp = self.comm.world > 1
         h = self._gn(x, t["norm"], 1e-6, False, Hc, Wc, stats=st_in)
-        hs = ops.gemm(h.view(-1, C), t["pin_w"], bias=t["pin_b"], out_dtype=torch.float32)
         nb = len(t["blocks"])
+        M = B * HW
+        if LN_FOLD and not sp and "f1" in t["blocks"][0] and self._ln_fold_ok(M, C):
+            # every LayerNorm of the blocks rides on its neighbours: the projection ahead of it (proj_in / out-projections / ff2,
+            # fp32 residual stream) also emits the 16-bit copy and the rows' sums, the projection behind it applies (mu, rstd)
+            arena = torch.zeros((3 * nb, M, 2), dtype=torch.float64, device=x.device)      # one fill launch
+
+            def rows(i):
+                return ops.LnRows(M, C, dt, x.device, stats=arena[i])
+            ln = rows(0)
+            hs = ops.gemm(h.view(-1, C), t["pin_w"], bias=t["pin_b"], out_dtype=torch.float32, ln_emit=ln)
+            for k, b in enumerate(t["blocks"]):
+                w, cs, bb = b["f1"]
+                qkv = ops.gemm(ln.x16, w, bias=bb, ln_apply=(ln, cs, 1e-5)).view(B, HW, 3, heads, hd)
+                att = ops.attention(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], scale)
+                ln = rows(3 * k + 1)
+                hs = ops.gemm(att.view(-1, C), b["wo1"], bias=b["bo1"], residual=hs, out_dtype=torch.float32, ln_emit=ln)
+                w, cs, bb = b["f2"]
+                q = ops.gemm(ln.x16, w, bias=bb, ln_apply=(ln, cs, 1e-5)).view(B, HW, heads, hd)
+                kv = ctx_kv[k]
+                att = ops.attention(q, kv[:, :, 0], kv[:, :, 1], scale)
+                ln = rows(3 * k + 2)
+                hs = ops.gemm(att.view(-1, C), b["wo2"], bias=b["bo2"], residual=hs, out_dtype=torch.float32, ln_emit=ln)
+                w, cs, bb = b["f3"]
+                g = ops.gemm(ln.x16, w, bias=bb, act="gelu", glu=True, ln_apply=(ln, cs, 1e-5))
+                if k == nb - 1:
+                    hs = ops.gemm(g, b["wff2"], bias=b["bff2"], residual=hs, out_dtype=dt)
+                else:
+                    ln = rows(3 * k + 3)
+                    hs = ops.gemm(g, b["wff2"], bias=b["bff2"], residual=hs, out_dtype=torch.float32, ln_emit=ln)
+            st_out = self._gn_slot(B, HW)
+            out = ops.gemm(hs, t["pout_w"], bias=t["pout_b"], residual=x.view(-1, C), out_dtype=torch.float32, gn=st_out)
+            return out.view(B, HW, C), st_out
+        hs = ops.gemm(h.view(-1, C), t["pin_w"], bias=t["pin_b"], out_dtype=torch.float32)
         for k, b in enumerate(t["blocks"]):
             n = ops.layernorm(hs, b["n1"][0], b["n1"][1], 1e-5, dt)
             if not sp:
@@ -357,6 +403,12 @@ class UNet2DConditionModel:
         st_out = self._gn_slot(B, HW)
         out = ops.gemm(hs, t["pout_w"], bias=t["pout_b"], residual=x.view(-1, C), out_dtype=torch.float32, gn=st_out)
         return out.view(B, HW, C), st_out
+
+    def _ln_fold_ok(self, M, C):
+        key = (M, C)
+        if key not in self._ln_ok:
+            self._ln_ok[key] = ops.ln_fold_ok(M, C, consumers=[(3 * C, False), (C, False), (8 * C, True)], producers=[C, 4 * C])
+        return self._ln_ok[key]
 
     def prepare_context(self, encoder_hidden_states):
         """Cross-attention K/V of every transformer block for this conditioning (constant over the denoise loop)."""

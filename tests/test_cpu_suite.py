@@ -228,7 +228,7 @@ def test_ctypes_struct_layout_matches_header():
     src = open(os.path.join(ROOT, "include", "seedx_hip.h")).read()
     for cname, cls in (("sx_gemm_args", _lib.GemmArgs), ("sx_gemv_args", _lib.GemvArgs), ("sx_attn_args", _lib.AttnArgs),
                        ("sx_attn_small_args", _lib.AttnSmallArgs), ("sx_oneshot_args", _lib.OneshotArgs),
-                       ("sx_attn_decode_args", _lib.AttnDecodeArgs)):
+                       ("sx_attn_decode_args", _lib.AttnDecodeArgs), ("sx_gemm_ln_args", _lib.GemmLnArgs)):
         body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), src, flags=re.S).group(1)
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
         names = []
@@ -236,7 +236,7 @@ def test_ctypes_struct_layout_matches_header():
             decl = decl.strip()
             if not decl:
                 continue
-            decl = re.sub(r"^(const\s+)?(void|float|int32_t|int64_t|uint32_t|uint64_t)\s*\*?", "", decl)
+            decl = re.sub(r"^(const\s+)?(void|float|double|int32_t|int64_t|uint32_t|uint64_t)\s*\*?", "", decl)
             names += [n.strip().lstrip("*") for n in decl.split(",")]
         assert names == [f[0] for f in cls._fields_], (cname, names)
 
@@ -769,3 +769,37 @@ def test_gemm_tile_picker_host_logic():
     assert pick(32768, 320, 2880, conv=1) == "256x160"
     for M, N, K in [(1, 64, 64), (7, 5120, 5120), (1000000, 128, 1152)]:
         assert 0 <= lib.sx_gemm_pick_tile(M, N, K, 0, 0) <= 8
+
+
+def test_layernorm_fold_host_algebra_and_tile_gate():
+    """ops.fold_layernorm: rstd (x W'^T - mu colsum) + bias' == LayerNorm(x) W^T + bias (fp32 weights: exact algebra up to rounding);
+    GLU-packed rows fold row by row. ops.ln_fold_ok / sx_gemm_ln: the fold exists only where every neighbour GEMM runs on a
+    ping-pong tile — the C-ABI call refuses a lock-step shape before any launch."""
+    import ctypes as C
+    from seedx_amd import _lib, ops
+    g = torch.Generator().manual_seed(8)
+    M, K, N = 64, 96, 48
+    x = torch.randn(M, K, generator=g, dtype=torch.float64) * 2 + 0.7
+    w, b = torch.randn(N, K, generator=g), torch.randn(N, generator=g)
+    gamma, beta = 1 + 0.3 * torch.randn(K, generator=g), 0.3 * torch.randn(K, generator=g)
+    wf, cs, bf = ops.fold_layernorm(w, b, gamma, beta)
+    mu, var = x.mean(1, keepdim=True), x.var(1, unbiased=False, keepdim=True)
+    rstd = (var + 1e-5).rsqrt()
+    ref = ((x - mu) * rstd * gamma.double() + beta.double()) @ w.double().T + b.double()
+    got = rstd * (x @ wf.double().T - mu * cs.double()) + bf.double()
+    assert _rel(got, ref) < 1e-6
+    # the UNet's shapes: folded at the bench batch (32 samples) and at 16, separate LayerNorm launches at batch 1 (2 samples)
+    shapes = lambda C_: dict(consumers=[(3 * C_, False), (C_, False), (8 * C_, True)], producers=[C_, 4 * C_])
+    assert ops.ln_fold_ok(32 * 1024, 1280, **shapes(1280)) and ops.ln_fold_ok(32 * 4096, 640, **shapes(640))
+    assert ops.ln_fold_ok(16 * 1024, 1280, **shapes(1280))
+    assert not ops.ln_fold_ok(2 * 1024, 1280, **shapes(1280))
+    lib = _lib.load()
+    args, la = _lib.GemmArgs(), _lib.GemmLnArgs()
+    dummy = C.create_string_buffer(64)
+    args.A = args.W = args.C = C.addressof(dummy)
+    args.M, args.N, args.K, args.ldc = 2048, 1280, 1280, 1280
+    args.dtype, args.out_dtype = _lib.SX_F16, _lib.SX_F32
+    la.x16_out = la.row_stats_out = C.addressof(dummy)
+    la.ld_x16 = 1280
+    assert lib.sx_gemm_ln(C.byref(args), C.byref(la), None) != 0
+    assert "ping-pong" in lib.sx_last_error().decode()

@@ -161,3 +161,47 @@ def test_vit_b20_and_long_prefill(dev):
     _verdict("Llama-13B dims, 1536-token prefill, fp16: last-position logits", e_l, 1e-3)
     _verdict("Llama-13B dims, 1536-token prefill, fp16: final-norm states", e_h, 1e-3)
     assert e_l < 1e-3 and e_h < 1e-3
+
+
+def test_unet_layernorm_fold_full_size(dev, monkeypatch):
+    """The complete SDXL UNet at 16 samples (the batch where every transformer GEMM runs on a ping-pong tile) with the transformer
+    blocks' LayerNorms folded into their neighbour GEMMs (ops.LnRows, sx_gemm_ln) against the unfolded launches on the same
+    weights, and both against the fp32 oracle on the first two samples (samples are independent through the whole UNet)."""
+    from seedx_amd import unet as U
+    cfg = ru.FULL_UNET
+    sd = ru.unet_sd(cfg, device=dev)
+    g = torch.Generator().manual_seed(5)
+    B = 16
+    x = torch.randn(B, 4, 128, 128, generator=g)
+    ehs = torch.randn(B, 64, 2048, generator=g)
+    te = torch.randn(B, 1280, generator=g)
+    tid = torch.tensor([[1024.0, 1024, 0, 0, 1024, 1024]] * B)
+    with torch.no_grad():
+        ref = ru.unet_forward(sd, cfg, x[:2].to(dev), 981.0, ehs[:2].to(dev), te[:2].to(dev), tid[:2].to(dev))
+    monkeypatch.setattr(U, "LN_FOLD", True)
+    m = U.UNet2DConditionModel(**U.SDXL_BASE_CONFIG)
+    m.load_state_dict(sd)
+    m.to(dev, torch.float16)
+    m._pack()
+    del sd
+    torch.cuda.empty_cache()
+    assert m._ln_fold_ok(B * 1024, 1280) and m._ln_fold_ok(B * 4096, 640)
+    kw = dict(added_cond_kwargs={"text_embeds": te.to(dev), "time_ids": tid.to(dev)}, return_dict=False)
+    from seedx_amd import _lib
+    lib = _lib.load()
+    calls = {"n": 0}
+    real = lib.sx_gemm_ln
+
+    def counted(*a):
+        calls["n"] += 1
+        return real(*a)
+    monkeypatch.setattr(lib, "sx_gemm_ln", counted)
+    out_f = m(x.to(dev), 981.0, ehs.to(dev), **kw)[0]
+    n_fold = calls["n"]
+    monkeypatch.setattr(U, "LN_FOLD", False)
+    out_u = m(x.to(dev), 981.0, ehs.to(dev), **kw)[0]
+    assert calls["n"] == n_fold and n_fold == 2 * 3 * 70     # 70 blocks x 3 norms, a producer and a consumer launch each
+    e_f, e_u, d = relerr(out_f[:2], ref), relerr(out_u[:2], ref), relerr(out_f, out_u)
+    print(f"FULL SDXL UNet, 16 samples, fp16: folded LayerNorms rel-L2 {e_f:.3e}, separate LayerNorm launches {e_u:.3e}, "
+          f"folded vs separate {d:.3e}")
+    assert torch.isfinite(out_f).all() and e_f < 1e-3 and e_u < 1e-3

@@ -1,5 +1,7 @@
-"""Same-process A/B of the graph-replayed 50-step UNet loop at the bench batch: fused GroupNorm statistics on / off
-(ops.GN_FUSE), interleaved rounds. Prints ms per 50-step loop (16 generations, CFG-2, two kernel chains)."""
+"""Same-process A/B of the graph-replayed 50-step UNet loop at the bench batch, interleaved rounds: fused GroupNorm statistics on / off
+(--what gn: ops.GN_FUSE) or LayerNorms folded into their neighbour GEMMs on / off (--what ln: unet.LN_FOLD; the process runs with
+SX_LN_FOLD=1 so that the folded weight copies exist). Prints ms per 50-step loop (16 generations, CFG-2, two kernel chains) and, for ln,
+the rel-L2 difference of the final latents between the two settings."""
 import argparse
 import os
 import sys
@@ -14,9 +16,13 @@ ap.add_argument("--batch", type=int, default=16)
 ap.add_argument("--steps", type=int, default=50)
 ap.add_argument("--rounds", type=int, default=3)
 ap.add_argument("--dtype", default="fp16")
+ap.add_argument("--what", default="gn", choices=("gn", "ln"))
 a = ap.parse_args()
+if a.what == "ln":
+    os.environ["SX_LN_FOLD"] = "1"
 import bench
 from seedx_amd import ops
+from seedx_amd import unet as unet_mod
 bench.BATCH, bench.USE_VAE = a.batch, False
 dt = torch.float16 if a.dtype == "fp16" else torch.bfloat16
 dev = torch.device("cuda:0")
@@ -25,17 +31,25 @@ with torch.no_grad():
     adapter._loop.chains = 2
     feats = torch.randn(a.batch, 64, 4096, device=dev).to(dt)
     res = {0: [], 1: []}
+    last = {}
     for r in range(a.rounds + 1):
         for fuse in (1, 0):
-            ops.GN_FUSE = bool(fuse)
+            if a.what == "gn":
+                ops.GN_FUSE = bool(fuse)
+            else:
+                unet_mod.LN_FOLD = bool(fuse)
             adapter._loop._graph = None                      # re-capture with the other setting
             adapter.generate(image_embeds=feats, num_inference_steps=2, seed=1, output_type="latent")
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            adapter.generate(image_embeds=feats, num_inference_steps=a.steps, seed=1, output_type="latent")
+            lat = adapter.generate(image_embeds=feats, num_inference_steps=a.steps, seed=1, output_type="latent")
             torch.cuda.synchronize()
+            last[fuse] = lat.detach().float().clone()
             if r:
                 res[fuse].append((time.perf_counter() - t0) * 1e3)
     for fuse in (1, 0):
         v = sorted(res[fuse])
-        print(f"GN_FUSE={fuse}: median {v[len(v) // 2]:.1f} ms per {a.steps}-step loop (all: {', '.join('%.1f' % x for x in v)})")
+        print(f"{'GN_FUSE' if a.what == 'gn' else 'LN_FOLD'}={fuse}: median {v[len(v) // 2]:.1f} ms per {a.steps}-step loop (all: {', '.join('%.1f' % x for x in v)})")
+    if a.what == "ln":
+        x, y = [torch.as_tensor(last[k]).float() for k in (1, 0)]
+        print(f"final latents, folded vs separate LayerNorm launches: rel-L2 {((x - y).norm() / y.norm()).item():.3e}")

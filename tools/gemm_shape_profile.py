@@ -27,7 +27,7 @@ def main():
     dev = torch.device("cuda:0")
     from seedx_amd import _lib
     lib = _lib.load()
-    real, real_gn = lib.sx_gemm, lib.sx_gemm_gn
+    real, real_gn, real_ln = lib.sx_gemm, lib.sx_gemm_gn, lib.sx_gemm_ln
     rec = []
 
     class Hook:
@@ -35,7 +35,7 @@ def main():
             g = args_ref._obj
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
-            r = (real if len(rest) == 1 else real_gn)(args_ref, *rest)
+            r = {1: real, 2: real_ln}.get(len(rest), real_gn)(args_ref, *rest)      # sx_gemm_ln(args, ln, stream)
             e.record()
             n_out = g.N // 2 if g.glu else g.N
             n_st = g.n_valid if g.n_valid else n_out
@@ -51,12 +51,12 @@ def main():
         w.agent.use_graph = False
         w.adapter._loop.use_graph = False
         w.adapter._loop.chains = 1          # ONE kernel chain: with two concurrent chains an event pair also contains the other chain's kernels
-        lib.sx_gemm = lib.sx_gemm_gn = Hook()
+        lib.sx_gemm = lib.sx_gemm_gn = lib.sx_gemm_ln = Hook()
         try:
             w.step(1)
             torch.cuda.synchronize()
         finally:
-            lib.sx_gemm, lib.sx_gemm_gn = real, real_gn
+            lib.sx_gemm, lib.sx_gemm_gn, lib.sx_gemm_ln = real, real_gn, real_ln
     groups = collections.OrderedDict()
     for key, fl, byt, s, e in rec:
         g = groups.setdefault(key, [0, 0.0, 0.0, 0.0])

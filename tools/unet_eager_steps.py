@@ -34,7 +34,7 @@ with torch.no_grad():
     if a.alg_json:
         from seedx_amd import _lib
         lib = _lib.load()
-        real_gemm, real_gemm_gn, real_attn = lib.sx_gemm, lib.sx_gemm_gn, lib.sx_attention
+        real_gemm, real_gemm_gn, real_gemm_ln, real_attn = lib.sx_gemm, lib.sx_gemm_gn, lib.sx_gemm_ln, lib.sx_attention
 
         def h_gemm(args_ref, *rest):
             g = args_ref._obj
@@ -47,7 +47,7 @@ with torch.no_grad():
             wr = g.M * n_st * (4.0 if g.out_dtype == 2 else 2.0)
             per_launch.append(["conv" if g.a_mode else "lin", g.M, g.N, g.K, int(g.glu), int(bool(g.residual)), int(g.out_dtype == 2),
                                byt - wr, wr])
-            return (real_gemm if len(rest) == 1 else real_gemm_gn)(args_ref, *rest)
+            return {1: real_gemm, 2: real_gemm_ln}.get(len(rest), real_gemm_gn)(args_ref, *rest)
 
         def h_attn(args_ref, stream):
             g = args_ref._obj
@@ -56,10 +56,10 @@ with torch.no_grad():
             f["bytes"] += 2.0 * g.B * g.H * g.D * (2 * g.Sq + 2 * g.Skv)                           # Q + O, K + V once
             f["flop"] += 4.0 * g.B * g.H * g.Sq * g.Skv * g.D
             return real_attn(args_ref, stream)
-        lib.sx_gemm, lib.sx_gemm_gn, lib.sx_attention = h_gemm, h_gemm, h_attn
+        lib.sx_gemm, lib.sx_gemm_gn, lib.sx_gemm_ln, lib.sx_attention = h_gemm, h_gemm, h_gemm, h_attn
     feats = torch.randn(a.batch, 64, 4096, device=dev).to(dt)
     adapter.generate(image_embeds=feats, num_inference_steps=a.steps, seed=1, output_type="latent")
     torch.cuda.synchronize()
     if a.alg_json:
-        lib.sx_gemm, lib.sx_gemm_gn, lib.sx_attention = real_gemm, real_gemm_gn, real_attn
+        lib.sx_gemm, lib.sx_gemm_gn, lib.sx_gemm_ln, lib.sx_attention = real_gemm, real_gemm_gn, real_gemm_ln, real_attn
         json.dump({"batch": a.batch, "steps": a.steps, "dtype": a.dtype, "families": fam, "gemm_launches": per_launch}, open(a.alg_json, "w"))
