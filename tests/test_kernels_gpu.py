@@ -749,7 +749,7 @@ def test_gemm_layernorm_fold(dev, dtype):
     # the 256 x 256 tile's producer / plain consumer (the UNet shapes above pick 256 x 320 for them): forced
     lib.sx_gemm_force_tile(7)
     try:
-        M, C, N = 4096, 1280, 1280
+        M, C, N = 4096 + 40, 1280, 1280                     # a ragged last row tile on the way
         a = (torch.randn(M, C, generator=g) * 0.5).to(dtype).to(dev)
         wo = (torch.randn(C, C, generator=g) / C ** 0.5).to(dtype).to(dev)
         res = (torch.randn(M, C, generator=g) * 2.0 + 1.0).to(dev)
