@@ -42,9 +42,12 @@ with torch.no_grad():
             n_st = g.n_valid if g.n_valid else n_out
             a_bytes = 2.0 * (g.B * g.Hin * g.Win * g.Cin if g.a_mode == 1 else g.M * g.K)          # operands once + output once
             byt = a_bytes + 2.0 * g.N * g.K + g.M * n_st * (4.0 if g.out_dtype == 2 else 2.0) + (4.0 * g.M * n_st if g.residual else 0.0)
+            wr = g.M * n_st * (4.0 if g.out_dtype == 2 else 2.0)
+            if len(rest) == 2 and rest[0]._obj.row_stats_out:      # sx_gemm_ln producer: the 16-bit copy of the output is written too
+                wr += 2.0 * g.M * n_st
+                byt += 2.0 * g.M * n_st
             f = fam["gemm"]
             f["launches"] += 1; f["bytes"] += byt; f["flop"] += 2.0 * g.M * g.N * g.K
-            wr = g.M * n_st * (4.0 if g.out_dtype == 2 else 2.0)
             per_launch.append(["conv" if g.a_mode else "lin", g.M, g.N, g.K, int(g.glu), int(bool(g.residual)), int(g.out_dtype == 2),
                                byt - wr, wr])
             return {1: real_gemm, 2: real_gemm_ln}.get(len(rest), real_gemm_gn)(args_ref, *rest)
