@@ -69,7 +69,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p) {
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   // LayerNorm fold, consumer: the tile's 256 (sum, sum of squares) pairs are requested HERE, ahead of the DMA prologue, and turned
-  // into (rstd, -rstd mu) in the 2 KB of LDS behind the operand ring once the prologue's first k-tile has landed — at the epilogue's start the same
+  // into (rstd, -rstd mu) in the 2 KB of LDS behind the operand ring once the prologue is issued — at the epilogue's start the same
   // loads would be an exposed L2 round trip per tile (20 rounds of tiles in the GEGLU projection)
   double ln_s1 = 0.0, ln_s2 = 0.0;
   if constexpr (LN == 1) {
@@ -219,7 +219,6 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p) {
   issue_y(1, 1);
   tap_next(kx);          // kx → k-tile 2
   float* ln_lds = (float*)(smem + 2 * STAGE);
-  wait_vmcnt<WAITN>();   // X(0), Y(0) landed (this wave's share) — and with them the older statistics load (vmcnt retires in order)
   if constexpr (LN == 1) {
     if (tid < BM) {
       const double mu = ln_s1 * (double)p.ln_inv_dim;
@@ -228,6 +227,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p) {
       *(f32x2_t*)(ln_lds + 2 * tid) = (f32x2_t){rstd, -rstd * (float)mu};      // read in the epilogue, many barriers later
     }
   }
+  wait_vmcnt<WAITN>();   // X(0), Y(0) landed (this wave's share)
   PP_SYNC();
   if (p.dbg) t_first = __builtin_amdgcn_s_memtime();
   if (g == 1 && VAR != 3) PP_SYNC();   // group 1 runs one barrier interval behind group 0 (VAR 3: lock-step, A/B only)
