@@ -82,6 +82,10 @@ typedef struct sx_gemm_args {
   int32_t ld_bias2d; /* row stride of bias2d in floats (0 = N): lets one GEMM produce every resnet's time add    */
   int32_t pad_mode; /* 0 = zero pad 1 on every side; 1 = pad 0 top/left and 1 bottom/right (diffusers Downsample2D with
                        padding=0 + F.pad(x, (0,1,0,1)): the stride-2 convs of the VAE encoder [ext])                 */
+  int32_t a_planes; /* 0 / 1: A is [M][K]. 2 (SX_A_LINEAR only): A is [M][2K] = [hi(K) | lo(K)], the two 16-bit planes of an
+                       fp32-grade activation x = hi + lo (sx_split16 / sx_rmsnorm_planes / sx_attention_f32 write them); W stays
+                       [N][K] and its k-tiles are walked twice: C = epilogue((hi + lo) W^T), fp32 accumulation, no extra weight
+                       bytes. The Llama decoder's precise mode (modeling_llama_xformer.py:204-206,239,166-167,707 at 1e-3 of fp32) */
 } sx_gemm_args;
 int sx_gemm(const sx_gemm_args* args, void* stream);
 /* sx_gemm + the statistics pass of the GroupNorm that reads its output (diffusers ResnetBlock2D.norm2 / Transformer2DModel.norm /
@@ -161,7 +165,10 @@ typedef struct sx_gemv_args {
   const float* row_ssq_in;
   int32_t ssq_in_parts, ssq_dim;
   float ssq_eps;
-  int32_t reserved;
+  int32_t x_planes;    /* 0 / 1: x is one 16-bit activation. 2 (M <= 16, x_layout 1, MFMA path at any M >= 1): x holds the two planes of an
+                        * fp32-grade activation as two 16-row operand blocks [2][K/32][16][32] (block 0 = hi, block 1 = lo; sx_split16 /
+                        * sx_rmsnorm_planes / sx_attention_f32 with SX_TILED16): every weight fragment feeds two MFMAs and the two
+                        * partial results are added ahead of the epilogue — the weights stream once, y = epi((hi + lo) W^T) */
 } sx_gemv_args;
 /* workgroups in x (= partial rows of row_ssq_out) sx_gemv launches for an M x N x K problem with / without GLU on the MFMA path */
 int sx_gemv_ssq_parts(int N, int glu, int w_layout);
@@ -332,6 +339,41 @@ int sx_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n,
  * stands in for the fp32 VAE the reference's pipeline switches to in upcast_vae()
  * (pipeline_stable_diffusion_xl_t2i_edit.py:509-511, :569-586, :965-977). */
 int sx_split_bf16(const float* x, void* out, int64_t rows, int cols, int role, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * fp32-grade activations of the Llama decoder (LlamaForCausalLM(precise=True); csrc/precise.hip): a 16-bit checkpoint's weights
+ * are exact, so logits within 1e-3 of the fp32 reference at 40 layers only need more mantissa on the ACTIVATION side:
+ * GEMM A operands travel as two 16-bit planes x = hi + lo (hi = rn16(x), lo = rn16(x - hi)), q / k / v and the KV cache stay fp32.
+ * `dtype` below = SX_F16 / SX_BF16 of the planes; | SX_TILED16 → operand tiles [2][cols/32][16][32] (block 0 = hi, block 1 = lo,
+ * rows <= 16: the x operand of sx_gemv with x_planes = 2) instead of rows [rows][2*cols] = [hi | lo] (sx_gemm with a_planes = 2).
+ * ------------------------------------------------------------------------------------------------ */
+/* fp32 x[rows][cols] (row stride ldx) → the two planes. cols % 8 == 0 (tiles: cols % 32 == 0). */
+int sx_split16(const float* x, int64_t ldx, void* out, int rows, int cols, int dtype, void* stream);
+/* LlamaRMSNorm (modeling_llama_xformer.py:95,286,301,595): y = gamma * (x * rsqrt(mean(x^2) + eps)), all fp32; y32 (fp32 [rows][cols],
+ * may be NULL) and / or the planes of y (out16, may be NULL). */
+int sx_rmsnorm_planes(const float* x, const float* gamma, float* y32, void* out16, int rows, int cols, float eps, int dtype,
+                      void* stream);
+/* sx_rope_kv_append_b on fp32 rows and fp32 caches (modeling_llama_xformer.py:141-149,215-220): qkv fp32 [G*T][3*H*D], q rotated in
+ * place, rotated k and v appended to kcache / vcache fp32 [G][H][Tmax][D] at pos0[g] + t. The cos / sin tables are rounded to
+ * table_dtype first (:128-131 casts them to the activation dtype); positions outside [0, Tmax) write nothing. */
+int sx_rope_kv_append_f32(float* qkv, float* kcache, float* vcache, const float* cos_tab, const float* sin_tab,
+                          const int32_t* pos0_dev, int G, int T, int H, int D, int Tmax, int64_t cache_seq_stride,
+                          int table_dtype, void* stream);
+/* Causal attention of a T-token chunk per sequence over the fp32 cache, fp32 FMA arithmetic and softmax
+ * (modeling_llama_xformer.py:204-239: prefill causal, q_len == 1 sees the whole cache): row t sees keys 0 .. pos0[g] + t.
+ * Device-resident positions → graph-capturable for the decode step (T = 1). Output = the planes of the context rows [G*T][H*D]. */
+typedef struct sx_attn_f32_args {
+  const float* q;           /* rotated q: row g*T + t at q + row*q_row_stride, head h at + h*D (e.g. the qkv buffer, stride 3*H*D) */
+  const float* kcache;      /* fp32 [G][H][Tmax][D], sequences cache_seq_stride floats apart                                       */
+  const float* vcache;
+  void* out;                /* planes of [G*T][H*D], layout by dtype (see above)                                                    */
+  const int32_t* pos0_dev;  /* [G] cache position of each sequence's first chunk token                                             */
+  int64_t q_row_stride, cache_seq_stride;
+  int32_t G, T, H, D, Tmax, dtype;
+  float scale;
+  int32_t reserved;
+} sx_attn_f32_args;
+int sx_attention_f32(const sx_attn_f32_args* args, void* stream);
 /* strided 2-D copy of fp32 rows: dst[r][dst_off + c] = src[r][c]  (channel concat of skip connections) */
 int sx_copy2d_f32(const float* src, int64_t src_ld, float* dst, int64_t dst_ld, int64_t rows, int cols,
                   void* stream);

@@ -23,7 +23,7 @@ class GemmArgs(C.Structure):
                 ("res_mod", c_i32), ("bias2d_rows", c_i32), ("dtype", c_i32), ("out_dtype", c_i32),
                 ("act", c_i32), ("glu", c_i32), ("a_mode", c_i32),
                 ("B", c_i32), ("Hin", c_i32), ("Win", c_i32), ("Cin", c_i32), ("Hout", c_i32), ("Wout", c_i32),
-                ("stride", c_i32), ("upsample", c_i32), ("ld_bias2d", c_i32), ("pad_mode", c_i32)]
+                ("stride", c_i32), ("upsample", c_i32), ("ld_bias2d", c_i32), ("pad_mode", c_i32), ("a_planes", c_i32)]
 
 
 class GemmLnArgs(C.Structure):
@@ -37,7 +37,14 @@ class GemvArgs(C.Structure):
                 ("dtype", c_i32), ("out_dtype", c_i32), ("act", c_i32), ("glu", c_i32),
                 ("w_layout", c_i32), ("x_layout", c_i32), ("workspace", c_vp), ("workspace_bytes", C.c_uint64),
                 ("x16_out", c_vp), ("row_ssq_out", c_vp), ("row_ssq_in", c_vp), ("ssq_in_parts", c_i32), ("ssq_dim", c_i32),
-                ("ssq_eps", c_f32), ("reserved", c_i32)]
+                ("ssq_eps", c_f32), ("x_planes", c_i32)]
+
+
+class AttnF32Args(C.Structure):
+    _fields_ = [("q", c_vp), ("kcache", c_vp), ("vcache", c_vp), ("out", c_vp), ("pos0_dev", c_vp),
+                ("q_row_stride", c_i64), ("cache_seq_stride", c_i64),
+                ("G", c_i32), ("T", c_i32), ("H", c_i32), ("D", c_i32), ("Tmax", c_i32), ("dtype", c_i32),
+                ("scale", c_f32), ("reserved", c_i32)]
 
 
 class OneshotArgs(C.Structure):
@@ -116,6 +123,10 @@ SIGNATURES = {
     "sx_greedy_next": [c_vp, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp],
     "sx_cast": [c_vp, c_i32, c_vp, c_i32, c_i64, c_vp],
     "sx_split_bf16": [c_vp, c_vp, c_i64, c_i32, c_i32, c_vp],
+    "sx_split16": [c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_vp],
+    "sx_rmsnorm_planes": [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_i32, c_vp],
+    "sx_rope_kv_append_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64, c_i32, c_vp],
+    "sx_attention_f32": [C.POINTER(AttnF32Args), c_vp],
     "sx_copy2d_f32": [c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_vp],
     "sx_add_f32": [c_vp, c_vp, c_vp, c_i64, c_vp],
     "sx_patchify": [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp],

@@ -12,11 +12,11 @@ BASE="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result"
 FAST="-ffast-math -fno-finite-math-only"
 if [ "$FORCE" = 1 ]; then rm -f "$HERE"/.obj/*.o; fi
 pids=()
-for f in gemm gemm_pp norm attn elementwise decode preproc comm; do
+for f in gemm gemm_pp norm attn elementwise decode preproc comm precise; do
   src="$HERE/$f.hip"; obj="$HERE/.obj/$f.o"
   if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ "$HERE/sx_common.h" -nt "$obj" ] || [ "$HERE/gemm_common.h" -nt "$obj" ] || [ "$HERE/../../include/seedx_hip.h" -nt "$obj" ]; then
     extra="$FAST"
-    if [ "$f" = "preproc" ]; then extra=""; fi   # integer / IEEE-exact float work: no fast-math
+    if [ "$f" = "preproc" ] || [ "$f" = "precise" ]; then extra=""; fi   # integer / IEEE-exact float work, hi + lo operand splits: no fast-math
     # MFMA accumulators in arch VGPRs: the softmax / rescale VALU code touches every accumulator each KV tile, the
     # default AGPR form costs ~200 v_accvgpr_read/write per tile (attention only; the GEMM touches them once)
     if [ "$f" = "attn" ] || [ -n "$SX_VGPR_FORM_ALL" ]; then extra="$extra -mllvm -amdgpu-mfma-vgpr-form=1"; fi

@@ -25,6 +25,8 @@ struct GemvP {
   const float* ssq_in;
   int ssq_parts;
   float ssq_inv_dim, ssq_eps;
+  int planes2;  // MB = 2 kernels with M <= 16: x block 1 is the LO plane of an fp32-grade activation (sx_gemv_args.x_planes = 2) — the two
+                // blocks' results are added ahead of the epilogue
 };
 
 template <typename TT, int MR>
@@ -329,6 +331,10 @@ __global__ __launch_bounds__(NWV * 64) void gemm_skinny_kernel(const GemvP p) {
           v[q][b][e] = t;
         }
     if (lane == 0) __hip_atomic_store(p.ws_cnt + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (MB == 2 && p.planes2) {   // hi-plane + lo-plane products: one activation, rows 0..M-1 (mvalid[1] is false: block 1 stores nothing)
+#pragma unroll
+    for (int q = 0; q < R; ++q) v[q][0] += v[q][MB - 1];
   }
   if (p.ssq_in) {
 #pragma unroll
@@ -914,10 +920,15 @@ extern "C" int sx_gemv(const sx_gemv_args* a, void* stream) {
            "sx_gemv: x16_out needs an fp32, non-GLU output with N %% 32 == 0");
   p.x_tiled = a->x_layout;
   SX_CHECK(a->x_layout == 0 || a->x_layout == 1, "sx_gemv: x_layout must be 0 (row-major) or 1 (operand tiles)");
+  SX_CHECK(a->x_planes >= 0 && a->x_planes <= 2, "sx_gemv: x_planes=%d", a->x_planes);
+  const bool planes2 = a->x_planes == 2;
+  p.planes2 = planes2 ? 1 : 0;
+  SX_CHECK(!planes2 || (a->M <= 16 && a->x_layout == 1 && !a->x16_out && !a->row_ssq_in),
+           "sx_gemv: x_planes = 2 needs M <= 16, tiled x (two blocks: hi, lo) and no RMSNorm fold");
   SX_CHECK(a->w_layout >= 0 && a->w_layout <= 2, "sx_gemv: w_layout must be 0 (row-major), 1 (decode tiles) or 2 (20-row decode tiles)");
   SX_CHECK(a->w_layout != 2 || (!a->glu && a->N % 20 == 0 && a->N % 32 == 0), "sx_gemv: w_layout 2 needs N %% 20 == 0, N %% 32 == 0, no GLU");
   // MI355X (tools/bench_gemv.py, 13B shapes): VALU path 6.5 / 4.7 / 3.0 TB/s at M = 1 / 4 / 8, MFMA path 4.0-4.4 TB/s at any M
-  const bool mfma_ok = a->M >= 2 && a->K % 64 == 0 && a->K >= 256 && a->N % 32 == 0;
+  const bool mfma_ok = (a->M >= 2 || planes2) && a->K % 64 == 0 && a->K >= 256 && a->N % 32 == 0;
   SX_CHECK(!a->w_layout || (mfma_ok && a->K % 64 == 0), "sx_gemv: the decode-tile layout needs M >= 2, K %% 64 == 0, K >= 256, N %% 32 == 0");
   // the decode-tile layout only exists for the MFMA kernel: it overrides the VALU test hook
   SX_CHECK(!p.y_tiled || mfma_ok, "sx_gemv: a tiled output needs the MFMA path (M >= 2, K %% 64 == 0, K >= 256, N %% 32 == 0)");
@@ -936,13 +947,13 @@ extern "C" int sx_gemv(const sx_gemv_args* a, void* stream) {
       else if (g_skinny_var[2] == 0 && a->K >= 8192) while (S < 8 && gx * S < 1024 && (a->K / 64) / (2 * S * 4) >= 4) S *= 2;
       const uint64_t cnt_bytes = 16384;    // fixed, so launches of different N can share one workspace (their partial regions
                                            // may overlap — launches are serial — but never reach the counters)
-      if (S > 1 && (gx > 4096 || cnt_bytes + (uint64_t)S * (a->M > 16 ? 32 : 16) * a->N * 4 > a->workspace_bytes)) S = 1;   // too small: no split
+      if (S > 1 && (gx > 4096 || cnt_bytes + (uint64_t)S * (a->M > 16 || planes2 ? 32 : 16) * a->N * 4 > a->workspace_bytes)) S = 1;   // too small: no split
       p.ws_cnt = (unsigned*)a->workspace;
       p.ws_part = (float*)((char*)a->workspace + cnt_bytes);
     }
     const dim3 grid(gx, S);
 #define SX_SK_GO(TT)                                                                                          \
-    if (a->M > 16) {                                                                                           \
+    if (a->M > 16 || planes2) {                                                                                \
       if (g_skinny_var[1] == 1) {       /* lab: 4 k-steps per round (256 VGPRs + AGPR copies, one wave per SIMD) */ \
         if (tail20) hipLaunchKernelGGL((gemm_skinny_kernel<TT, 2, 4, 4, true, 2>), grid, dim3(256), 0, ST, p);   \
         else if (r2) hipLaunchKernelGGL((gemm_skinny_kernel<TT, 2, 4, 4, false, 2>), grid, dim3(256), 0, ST, p); \

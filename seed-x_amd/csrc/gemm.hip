@@ -81,10 +81,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const GemmP p) {
   for (int i = 0; i < B_PER_WAVE; ++i) {
     const int lrow = (wave * B_PER_WAVE + i) * 8 + rl;   // rows >= BN are padding: fetched as zeros, never read
     const int row = n0 + lrow;
-    w_off[i] = (row < p.N && lrow < BN) ? (unsigned)row * (unsigned)p.K * 2u + gchunk : 0x80000000u;
+    w_off[i] = (row < p.N && lrow < BN) ? (unsigned)row * (unsigned)p.Kw * 2u + gchunk : 0x80000000u;
   }
   const int Hv = p.upsample ? 2 * p.Hin : p.Hin, Wv = p.upsample ? 2 * p.Win : p.Win;
   const int cpt = (AMODE == SX_A_CONV3X3) ? p.Cin / 64 : 1;  // k-tiles per filter tap
+  const int nkw = p.Kw / 64;                                 // k-tiles of W (a_planes = 2: half of the loop's, walked twice)
 
   auto stage = [&](int buf, int kt) {
     unsigned char* sA = smem + buf * STAGE;
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const GemmP p) {
 #pragma unroll
     for (int i = 0; i < B_PER_WAVE; ++i) {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, SX_LDS_PTR(sB + (wave * B_PER_WAVE + i) * 1024), 16,
-                                               w_off[i] + (unsigned)kt * 128u, 0, 0, 0);
+                                               w_off[i] + (unsigned)(kt >= nkw ? kt - nkw : kt) * 128u, 0, 0, 0);
     }
   };
 
@@ -453,7 +454,12 @@ static int gemm_impl(const sx_gemm_args* a, double* gn_stats, int gn_groups, int
   GemmP p;
   memset(&p, 0, sizeof(p));
   p.A = a->A; p.W = a->W; p.C = a->C; p.bias = a->bias; p.bias2d = a->bias2d; p.residual = a->residual;
-  p.M = a->M; p.N = a->N; p.K = a->K; p.ldc = a->ldc; p.ldr = a->ldr; p.res_mod = a->res_mod;
+  // a_planes = 2: A carries the hi and lo planes of an fp32-grade activation side by side; the kernels walk 2K with W wrapped at K
+  SX_CHECK(a->a_planes >= 0 && a->a_planes <= 2, "sx_gemm: a_planes=%d", a->a_planes);
+  const int planes = a->a_planes == 2 ? 2 : 1;
+  SX_CHECK(planes == 1 || (a->a_mode == SX_A_LINEAR && !ln), "sx_gemm: a_planes = 2 is for plain linear GEMMs");
+  const int Kk = a->K * planes;
+  p.M = a->M; p.N = a->N; p.K = Kk; p.Kw = a->K; p.ldc = a->ldc; p.ldr = a->ldr; p.res_mod = a->res_mod;
   p.n_valid = a->n_valid > 0 ? a->n_valid : n_out;
   p.bias2d_rows = a->bias2d_rows; p.out_dtype = a->out_dtype; p.act = a->act; p.glu = a->glu;
   p.ldb2 = a->ld_bias2d > 0 ? a->ld_bias2d : a->N;
@@ -474,7 +480,7 @@ static int gemm_impl(const sx_gemm_args* a, double* gn_stats, int gn_groups, int
     a_bytes = (uint64_t)a->B * a->Hin * a->Win * a->Cin * 2;
   } else {
     SX_CHECK(a->a_mode == SX_A_LINEAR, "sx_gemm: bad a_mode");
-    a_bytes = (uint64_t)a->M * a->K * 2;
+    a_bytes = (uint64_t)a->M * Kk * 2;
   }
   const uint64_t w_bytes = (uint64_t)a->N * a->K * 2;
   SX_CHECK(a_bytes < 0x7fffffffull && w_bytes < 0x7fffffffull, "sx_gemm: operand exceeds 2 GiB descriptor range");
@@ -509,13 +515,13 @@ static int gemm_impl(const sx_gemm_args* a, double* gn_stats, int gn_groups, int
            "sx_gemm: forced ping-pong tile has no kernel for this epilogue");
   if (ln) {
     // the fold exists on the tiles the cost model gives this shape without it, or not at all (no silent change of tile)
-    const int plain = pick_tile(a->M, a->N, a->K, a->glu != 0, false, g_force_tile, 0x1ff);
+    const int plain = pick_tile(a->M, a->N, Kk, a->glu != 0, false, g_force_tile, 0x1ff);
     SX_CHECK((plain == 7 || plain == 8) && ((allow >> plain) & 1u),
              "sx_gemm_ln: M=%d N=%d K=%d does not run on a ping-pong tile with this epilogue (tile %d): keep sx_layernorm for it", a->M,
              a->N, a->K, plain);
     allow = 1u << plain;
   }
-  const int cfg = pick_tile(a->M, a->N, a->K, a->glu != 0, a->a_mode == SX_A_CONV3X3, g_force_tile, allow);
+  const int cfg = pick_tile(a->M, a->N, Kk, a->glu != 0, a->a_mode == SX_A_CONV3X3, g_force_tile, allow);
   if (cfg == 7 || cfg == 8) {
     // fused GroupNorm statistics: fp32 output of all N columns, whole 256-row tiles inside one sample, even channels per group
     if (gn_stats && a->out_dtype == SX_F32 && !a->glu && a->act == SX_ACT_NONE && p.n_valid == a->N && a->N % gn_groups == 0 &&

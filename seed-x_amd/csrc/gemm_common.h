@@ -12,6 +12,7 @@ struct GemmP {
   const float* bias2d;
   const float* residual;
   int M, N, K, ldc, ldr, n_valid, res_mod, bias2d_rows, out_dtype, act, glu;
+  int Kw;                         // row length of W in elements: = K, or K / 2 with sx_gemm_args.a_planes = 2 (A = [hi | lo]: the k loop walks W twice)
   int Hin, Win, Cin, Hout, Wout, stride, upsample, ldb2, pad;
   int tiles_m, tiles_n, xm, xn;   // tile grid and its XCD partition (xm x xn == 8, or 0 = linear remap)
   int gm;                         // tile-rows per group of the in-XCD traversal

@@ -126,10 +126,11 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p) {
 #pragma unroll
   for (int i = 0; i < NB; ++i) {
     const int row = n0 + (wave * NB + i) * 8 + rl;
-    w_off[i] = (row < p.N) ? (unsigned)row * (unsigned)p.K * 2u + gchunk : 0xC0000000u;
+    w_off[i] = (row < p.N) ? (unsigned)row * (unsigned)p.Kw * 2u + gchunk : 0xC0000000u;
   }
   const int cpt = (AMODE != SX_A_LINEAR) ? p.Cin / 64 : 1;  // k-tiles per filter tap
   const int nkt = p.K / 64;
+  const int nkw = p.Kw / 64;   // k-tiles of W: = nkt, or nkt / 2 when A is [hi | lo] planes (sx_gemm_args.a_planes = 2: W walked twice)
 
   // filter-tap walkers of the two A streams (conv only): kx = state of the k-tile whose A0 rows are issued next (u + 2),
   // kz = state of the k-tile whose A1 rows are issued next (u + 1). Advanced incrementally: no division in the loop.
@@ -140,6 +141,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p) {
 
   // k-tile offset shared by every DMA of a k-tile: kt * 128 B, or 2 GiB for k-tiles past the end (zero fill, never read)
   auto koff_of = [&](int kt) -> unsigned { return (kt < nkt) ? (unsigned)kt * 128u : 0x80000000u; };
+  auto koff_w = [&](int kt) -> unsigned { return (kt < nkt) ? (unsigned)(kt >= nkw ? kt - nkw : kt) * 128u : 0x80000000u; };
   auto dma_a = [&](int s, int buf, int kt, const Tap& t) {
     unsigned voff;
     if (AMODE == SX_A_LINEAR) {
@@ -160,7 +162,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p) {
   };
   auto dma_w = [&](int i, int buf, int kt) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, SX_LDS_PTR(smem + buf * STAGE + A_BYTES + (wave * NB + i) * 1024), 16,
-                                             w_off[i] + koff_of(kt), 0, 0, 0);
+                                             w_off[i] + koff_w(kt), 0, 0, 0);
   };
   // X(kt): A0 slots + first C1 W slots; Y(kt): remaining W slots; Za / Zb(kt): the two A1 slots
   auto issue_x = [&](int buf, int kt, const Tap& t) {

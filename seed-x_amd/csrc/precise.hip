@@ -1,0 +1,327 @@
+// fp32-grade activations for the Llama decoder (LlamaForCausalLM(precise=True)): north_star asks for logits within 1e-3 of the
+// reference; at 40 layers one 16-bit rounding per MFMA operand adds up to 2.2e-3 (tools/llm_error_budget.py: RMSNorm output 1.0e-3,
+// q / k before and after RoPE 1.2e-3, v, attention output, GLU output 0.3-0.6e-3 each). The weights of a 16-bit checkpoint are exact,
+// so only the ACTIVATION side needs more mantissa:
+//   * every GEMM A operand travels as two 16-bit planes x = hi + lo (hi = rn16(x), lo = rn16(x - hi)): sx_gemm a_planes = 2 walks
+//     K twice over the same weight tiles, sx_gemv x_planes = 2 feeds every weight fragment to two MFMAs — no extra weight bytes;
+//   * q, k, v never become 16-bit: the qkv GEMM stores fp32, RoPE runs in fp32 into an fp32 KV cache (rope_kv_f32_kernel), and
+//     attention (attn_f32_kernel) is fp32 FMA work — T <= a few hundred keys per head on this path, 1 % of the LLM's FLOPs.
+// This file holds the kernels that only exist for that mode. It is compiled WITHOUT -ffast-math (csrc/build.sh): x - float(rn16(x))
+// and the softmax bookkeeping must not be re-associated.
+// Reference being matched: modeling_llama_xformer.py:95 (RMSNorm), :141-149 (RoPE), :204-239 (attention), run by the fp32 oracle.
+#include "sx_common.h"
+
+namespace sxk_precise {
+
+template <typename TT>
+__device__ __forceinline__ void split1(float x, unsigned short& hi, unsigned short& lo) {
+  hi = TT::from_f32(x);
+  lo = TT::from_f32(x - TT::to_f32(hi));
+}
+
+// 8 consecutive columns c8 .. c8+7 of activation row `row` → the two planes.
+//   tiled == 0: out[row][2*cols] = [hi(cols) | lo(cols)]                                   (A operand of sx_gemm, a_planes = 2)
+//   tiled == 1: operand tiles [2][cols/32][16][32], block 0 = hi, block 1 = lo, row < 16  (x operand of sx_gemv, x_planes = 2)
+template <typename TT>
+__device__ __forceinline__ void store_planes8(unsigned short* out, int tiled, int row, int cols, int c8, const float* v) {
+  u32x4_t h, l;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    unsigned short h0, l0, h1, l1;
+    split1<TT>(v[2 * e], h0, l0);
+    split1<TT>(v[2 * e + 1], h1, l1);
+    h[e] = (unsigned)h0 | ((unsigned)h1 << 16);
+    l[e] = (unsigned)l0 | ((unsigned)l1 << 16);
+  }
+  if (tiled) {
+    unsigned short* b = out + (size_t)(c8 >> 5) * 512 + (size_t)row * 32 + (c8 & 31);
+    *(u32x4_t*)b = h;
+    *(u32x4_t*)(b + (size_t)cols * 16) = l;
+  } else {
+    unsigned short* b = out + (size_t)row * 2 * cols + c8;
+    *(u32x4_t*)b = h;
+    *(u32x4_t*)(b + cols) = l;
+  }
+}
+
+template <typename TT>
+__global__ __launch_bounds__(256) void split16_kernel(const float* x, long long ldx, unsigned short* out, int rows, int cols, int tiled) {
+  const int cpr = cols >> 3;
+  const long long total = (long long)rows * cpr;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int row = (int)(i / cpr), c8 = (int)(i - (long long)row * cpr) * 8;
+    const float* src = x + (size_t)row * ldx + c8;
+    const f32x4_t a = *(const f32x4_t*)src, b = *(const f32x4_t*)(src + 4);
+    const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    store_planes8<TT>(out, tiled, row, cols, c8, v);
+  }
+}
+
+// LlamaRMSNorm (modeling_llama_xformer.py:95 → transformers 4.30.2: w * (x * rsqrt(mean(x^2) + eps)), fp32). One workgroup per row.
+// Outputs: y32 (fp32, optional: the final norm's hidden states) and / or the two operand planes.
+template <typename TT>
+__global__ __launch_bounds__(256) void rmsnorm_planes_kernel(const float* x, const float* gamma, float* y32, unsigned short* out, int cols,
+                                                             float eps, int tiled) {
+  __shared__ float red[4];
+  const int row = blockIdx.x, tid = threadIdx.x;
+  const float* xr = x + (size_t)row * cols;
+  float ss = 0.f;
+  for (int c8 = tid * 8; c8 < cols; c8 += 2048) {
+    const f32x4_t a = *(const f32x4_t*)(xr + c8), b = *(const f32x4_t*)(xr + c8 + 4);
+    ss += (a[0] * a[0] + a[1] * a[1]) + (a[2] * a[2] + a[3] * a[3]) + (b[0] * b[0] + b[1] * b[1]) + (b[2] * b[2] + b[3] * b[3]);
+  }
+  ss = wave_sum(ss);
+  if ((tid & 63) == 0) red[tid >> 6] = ss;
+  __syncthreads();
+  const float tot = (red[0] + red[1]) + (red[2] + red[3]);
+  const float rstd = 1.0f / sqrtf(tot / (float)cols + eps);
+  for (int c8 = tid * 8; c8 < cols; c8 += 2048) {
+    const f32x4_t a = *(const f32x4_t*)(xr + c8), b = *(const f32x4_t*)(xr + c8 + 4);
+    const f32x4_t g0 = *(const f32x4_t*)(gamma + c8), g1 = *(const f32x4_t*)(gamma + c8 + 4);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v[e] = g0[e] * (a[e] * rstd);
+      v[4 + e] = g1[e] * (b[e] * rstd);
+    }
+    if (y32) {
+      *(f32x4_t*)(y32 + (size_t)row * cols + c8) = (f32x4_t){v[0], v[1], v[2], v[3]};
+      *(f32x4_t*)(y32 + (size_t)row * cols + c8 + 4) = (f32x4_t){v[4], v[5], v[6], v[7]};
+    }
+    if (out) store_planes8<TT>(out, tiled, row, cols, c8, v);
+  }
+}
+
+// RoPE (modeling_llama_xformer.py:141-149) of the q and k heads of fp32 qkv rows [G*T][3*H*D] (q rotated in place) + append of the
+// rotated k and of v to the fp32 caches [G][H][Tmax][D] at position pos0[g] + t. The tables are rounded to the model dtype first
+// (:128-131 casts them to x.dtype), the products stay fp32.
+template <typename TT>
+__global__ void rope_kv_f32_kernel(float* qkv, float* kc, float* vc, const float* cos_t, const float* sin_t, const int* pos0_dev, int T,
+                                   int H, int D, int Tmax, int G, long long seq_stride) {
+  const int half = D / 2;
+  const int64_t total = (int64_t)G * T * H * half;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int j = (int)(i % half);
+    const int h = (int)((i / half) % H);
+    const int r = (int)(i / ((int64_t)half * H));
+    const int g = r / T, t = r - g * T;
+    int pos = pos0_dev[g] + t;
+    const bool pos_ok = pos >= 0 && pos < Tmax;
+    if (!pos_ok) pos = 0;
+    const float c = TT::to_f32(TT::from_f32(cos_t[(size_t)pos * half + j]));
+    const float s = TT::to_f32(TT::from_f32(sin_t[(size_t)pos * half + j]));
+    float* row = qkv + (size_t)r * 3 * H * D;
+    float* qh = row + (size_t)h * D;
+    const float* kh = row + (size_t)(H + h) * D;
+    const float* vh = row + (size_t)(2 * H + h) * D;
+    const float q1 = qh[j], q2 = qh[j + half];
+    qh[j] = q1 * c - q2 * s;
+    qh[j + half] = q2 * c + q1 * s;
+    if (!pos_ok) continue;                  // a device-resident position past the cache never writes outside it
+    const float k1 = kh[j], k2 = kh[j + half];
+    float* kd = kc + (size_t)g * seq_stride + ((size_t)h * Tmax + pos) * D;
+    float* vd = vc + (size_t)g * seq_stride + ((size_t)h * Tmax + pos) * D;
+    kd[j] = k1 * c - k2 * s;
+    kd[j + half] = k2 * c + k1 * s;
+    vd[j] = vh[j];
+    vd[j + half] = vh[j + half];
+  }
+}
+
+// Causal attention over the fp32 cache, fp32 FMA arithmetic (modeling_llama_xformer.py:204-239: prefill is causal, a q_len == 1 step
+// sees the whole cache — both are "row t of the chunk sees keys 0 .. pos0 + t"). Workgroup = (QB query rows of the chunk, head,
+// sequence), 16 groups of 16 lanes: a group owns keys grp, grp + 16, ...; a lane owns 8 of the D <= 128 head dims; every key row is
+// loaded once for the QB query rows. Online softmax per (group, row), the 16 groups meet in LDS in group order (deterministic).
+// Output: the two 16-bit planes of the context rows (the o-projection's A operand), row-major or tiled (store_planes8's layouts,
+// one element at a time).
+constexpr int QB = 4;
+struct AttnF32P {
+  const float* q;          // row r = g*T + t at q + r*q_stride, head h at + h*D (already rotated)
+  const float* kc;
+  const float* vc;
+  unsigned short* out;
+  const int* pos0_dev;     // [G] cache position of the chunk's first token
+  long long q_stride, seq_stride;
+  int T, H, D, Tmax, tiled;
+  float scale;
+};
+
+template <typename TT>
+__global__ __launch_bounds__(256) void attn_f32_kernel(const AttnF32P p) {
+  __shared__ float red[16][QB][132];
+  const int q0 = blockIdx.x * QB, h = blockIdx.y, g = blockIdx.z, D = p.D;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int grp = wave * 4 + (lane >> 4), dl = lane & 15;
+  const bool dvalid = dl * 8 < D;
+  int pos0 = p.pos0_dev[g];
+  if (pos0 < 0) pos0 = 0;
+  const int nq = min(QB, p.T - q0);
+  float qv[QB][8], o[QB][8], m_run[QB], l_run[QB];
+#pragma unroll
+  for (int i = 0; i < QB; ++i) {
+    m_run[i] = -INFINITY;
+    l_run[i] = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { qv[i][e] = 0.f; o[i][e] = 0.f; }
+    if (i < nq && dvalid) {
+      const float* qr = p.q + (size_t)((size_t)g * p.T + q0 + i) * p.q_stride + (size_t)h * D + dl * 8;
+      const f32x4_t a = *(const f32x4_t*)qr, b = *(const f32x4_t*)(qr + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { qv[i][e] = a[e] * p.scale; qv[i][4 + e] = b[e] * p.scale; }
+    }
+  }
+  const float* kh = p.kc + (size_t)g * p.seq_stride + (size_t)h * p.Tmax * D;
+  const float* vh = p.vc + (size_t)g * p.seq_stride + (size_t)h * p.Tmax * D;
+  const int kend = min(p.Tmax, pos0 + q0 + nq);       // keys 0 .. kend-1 are visible to the block's last row
+  for (int t = grp; t < kend; t += 16) {
+    float kf[8], vf[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { kf[e] = 0.f; vf[e] = 0.f; }
+    if (dvalid) {
+      const float* kr = kh + (size_t)t * D + dl * 8;
+      const float* vr = vh + (size_t)t * D + dl * 8;
+      const f32x4_t k0 = *(const f32x4_t*)kr, k1 = *(const f32x4_t*)(kr + 4);
+      const f32x4_t v0 = *(const f32x4_t*)vr, v1 = *(const f32x4_t*)(vr + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { kf[e] = k0[e]; kf[4 + e] = k1[e]; vf[e] = v0[e]; vf[4 + e] = v1[e]; }
+    }
+#pragma unroll
+    for (int i = 0; i < QB; ++i) {
+      float s = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s = fmaf(kf[e], qv[i][e], s);
+      s += __shfl_xor(s, 1, 64);
+      s += __shfl_xor(s, 2, 64);
+      s += __shfl_xor(s, 4, 64);
+      s += __shfl_xor(s, 8, 64);
+      if (i < nq && t <= pos0 + q0 + i) {               // uniform over the 16-lane group
+        const float m_new = fmaxf(m_run[i], s);
+        const float alpha = __expf(m_run[i] - m_new);   // exp(-inf) = 0 on the first key
+        const float pr = __expf(s - m_new);
+        l_run[i] = l_run[i] * alpha + pr;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[i][e] = fmaf(pr, vf[e], o[i][e] * alpha);
+        m_run[i] = m_new;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < QB; ++i) {
+    if (dvalid) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) red[grp][i][dl * 8 + e] = o[i][e];
+    }
+    if (dl == 0) {
+      red[grp][i][128] = m_run[i];
+      red[grp][i][129] = l_run[i];
+    }
+  }
+  __syncthreads();
+  // thread → (row i, dim d): 256 threads cover QB * 128 outputs in QB * 128 / 256 passes
+  for (int idx = threadIdx.x; idx < QB * 128; idx += 256) {
+    const int i = idx >> 7, d = idx & 127;
+    if (i >= nq || d >= D) continue;
+    float mg = -INFINITY;
+#pragma unroll
+    for (int gg = 0; gg < 16; ++gg) mg = fmaxf(mg, red[gg][i][128]);
+    float acc = 0.f, lsum = 0.f;
+#pragma unroll
+    for (int gg = 0; gg < 16; ++gg) {
+      const float mgk = red[gg][i][128];
+      const float w = (mgk == -INFINITY) ? 0.f : __expf(mgk - mg);
+      acc = fmaf(w, red[gg][i][d], acc);
+      lsum = fmaf(w, red[gg][i][129], lsum);
+    }
+    const float val = lsum > 0.f ? acc / lsum : 0.f;
+    unsigned short hi, lo;
+    split1<TT>(val, hi, lo);
+    const int cols = p.H * D, col = h * D + d;
+    if (p.tiled) {
+      unsigned short* b = p.out + (size_t)(col >> 5) * 512 + (size_t)(g * p.T + q0 + i) * 32 + (col & 31);
+      b[0] = hi;
+      b[(size_t)cols * 16] = lo;
+    } else {
+      unsigned short* b = p.out + (size_t)((size_t)g * p.T + q0 + i) * 2 * cols + col;
+      b[0] = hi;
+      b[cols] = lo;
+    }
+  }
+}
+
+static dim3 gs_grid(int64_t n) {
+  int64_t b = (n + 255) / 256;
+  if (b > 65535 * 4) b = 65535 * 4;
+  if (b < 1) b = 1;
+  return dim3((unsigned)b);
+}
+
+}  // namespace sxk_precise
+using namespace sxk_precise;
+
+#define ST ((hipStream_t)stream)
+
+extern "C" int sx_split16(const float* x, int64_t ldx, void* out, int rows, int cols, int dtype, void* stream) {
+  SX_CHECK(x && out, "sx_split16: null pointer");
+  const int tiled = (dtype & SX_TILED16) ? 1 : 0, dt = dtype & 0xff;
+  SX_CHECK(dt == SX_F16 || dt == SX_BF16, "sx_split16: dtype");
+  SX_CHECK(rows >= 1 && cols >= 8 && cols % 8 == 0 && ldx >= cols && ldx % 4 == 0 && (((uintptr_t)x) & 15) == 0 && (((uintptr_t)out) & 15) == 0,
+           "sx_split16: rows=%d cols=%d ldx=%lld (cols %% 8, 16-B aligned rows)", rows, cols, (long long)ldx);
+  SX_CHECK(!tiled || (rows <= 16 && cols % 32 == 0), "sx_split16: operand tiles hold <= 16 rows of cols %% 32 == 0");
+  const int64_t n = (int64_t)rows * (cols / 8);
+  if (dt == SX_BF16) hipLaunchKernelGGL(split16_kernel<BF16>, gs_grid(n), dim3(256), 0, ST, x, (long long)ldx, (unsigned short*)out, rows, cols, tiled);
+  else hipLaunchKernelGGL(split16_kernel<F16>, gs_grid(n), dim3(256), 0, ST, x, (long long)ldx, (unsigned short*)out, rows, cols, tiled);
+  SX_HIP_LAUNCH_CHECK();
+  return SX_OK;
+}
+
+extern "C" int sx_rmsnorm_planes(const float* x, const float* gamma, float* y32, void* out16, int rows, int cols, float eps, int dtype,
+                                 void* stream) {
+  SX_CHECK(x && gamma && (y32 || out16), "sx_rmsnorm_planes: null pointer");
+  const int tiled = (dtype & SX_TILED16) ? 1 : 0, dt = dtype & 0xff;
+  SX_CHECK(dt == SX_F16 || dt == SX_BF16, "sx_rmsnorm_planes: dtype");
+  SX_CHECK(rows >= 1 && cols >= 8 && cols % 8 == 0 && (((uintptr_t)x) & 15) == 0 && (((uintptr_t)gamma) & 15) == 0,
+           "sx_rmsnorm_planes: rows=%d cols=%d (cols %% 8, 16-B aligned)", rows, cols);
+  SX_CHECK(!tiled || !out16 || (rows <= 16 && cols % 32 == 0), "sx_rmsnorm_planes: operand tiles hold <= 16 rows of cols %% 32 == 0");
+  if (dt == SX_BF16)
+    hipLaunchKernelGGL(rmsnorm_planes_kernel<BF16>, dim3(rows), dim3(256), 0, ST, x, gamma, y32, (unsigned short*)out16, cols, eps, tiled);
+  else
+    hipLaunchKernelGGL(rmsnorm_planes_kernel<F16>, dim3(rows), dim3(256), 0, ST, x, gamma, y32, (unsigned short*)out16, cols, eps, tiled);
+  SX_HIP_LAUNCH_CHECK();
+  return SX_OK;
+}
+
+extern "C" int sx_rope_kv_append_f32(float* qkv, float* kcache, float* vcache, const float* cos_tab, const float* sin_tab,
+                                     const int32_t* pos0_dev, int G, int T, int H, int D, int Tmax, int64_t cache_seq_stride,
+                                     int table_dtype, void* stream) {
+  SX_CHECK(qkv && kcache && vcache && cos_tab && sin_tab && pos0_dev, "sx_rope_kv_append_f32: null pointer");
+  SX_CHECK(D % 2 == 0 && G >= 1 && T >= 1 && H >= 1, "sx_rope_kv_append_f32: D/G/T/H");
+  SX_CHECK(table_dtype == SX_F16 || table_dtype == SX_BF16, "sx_rope_kv_append_f32: table_dtype");
+  const int64_t n = (int64_t)G * T * H * (D / 2);
+  if (table_dtype == SX_BF16)
+    hipLaunchKernelGGL(rope_kv_f32_kernel<BF16>, gs_grid(n), dim3(256), 0, ST, qkv, kcache, vcache, cos_tab, sin_tab, pos0_dev, T, H, D, Tmax,
+                       G, (long long)cache_seq_stride);
+  else
+    hipLaunchKernelGGL(rope_kv_f32_kernel<F16>, gs_grid(n), dim3(256), 0, ST, qkv, kcache, vcache, cos_tab, sin_tab, pos0_dev, T, H, D, Tmax,
+                       G, (long long)cache_seq_stride);
+  SX_HIP_LAUNCH_CHECK();
+  return SX_OK;
+}
+
+extern "C" int sx_attention_f32(const sx_attn_f32_args* a, void* stream) {
+  SX_CHECK(a && a->q && a->kcache && a->vcache && a->out && a->pos0_dev, "sx_attention_f32: null pointer");
+  const int tiled = (a->dtype & SX_TILED16) ? 1 : 0, dt = a->dtype & 0xff;
+  SX_CHECK(dt == SX_F16 || dt == SX_BF16, "sx_attention_f32: dtype (of the output planes)");
+  SX_CHECK(a->D % 8 == 0 && a->D >= 8 && a->D <= 128, "sx_attention_f32: head_dim %d", a->D);
+  SX_CHECK(a->G >= 1 && a->T >= 1 && a->H >= 1 && a->Tmax >= 1, "sx_attention_f32: G/T/H/Tmax");
+  SX_CHECK(a->q_row_stride >= (int64_t)a->H * a->D && a->q_row_stride % 4 == 0 && (((uintptr_t)a->q) & 15) == 0, "sx_attention_f32: q_row_stride");
+  SX_CHECK(!tiled || ((int64_t)a->G * a->T <= 16 && (a->H * a->D) % 32 == 0), "sx_attention_f32: operand tiles hold <= 16 rows, H*D %% 32 == 0");
+  AttnF32P p;
+  p.q = a->q; p.kc = a->kcache; p.vc = a->vcache; p.out = (unsigned short*)a->out; p.pos0_dev = a->pos0_dev;
+  p.q_stride = a->q_row_stride; p.seq_stride = a->cache_seq_stride;
+  p.T = a->T; p.H = a->H; p.D = a->D; p.Tmax = a->Tmax; p.tiled = tiled; p.scale = a->scale;
+  const dim3 grid((a->T + QB - 1) / QB, a->H, a->G);
+  if (dt == SX_BF16) hipLaunchKernelGGL(attn_f32_kernel<BF16>, grid, dim3(256), 0, ST, p);
+  else hipLaunchKernelGGL(attn_f32_kernel<F16>, grid, dim3(256), 0, ST, p);
+  SX_HIP_LAUNCH_CHECK();
+  return SX_OK;
+}

@@ -12,6 +12,11 @@ logits, past_key_values, hidden_states with the LAST entry = post-final-norm sta
   * the generate loop only produces the last position's logits (``forward`` returns all positions like the reference)
   * ``max_batch`` > 1: G independent sequences (separate KV caches / positions) decode in lock step, so the 25.7 GB of
     weights are streamed from HBM once per step for all G tokens (the reference is batch 1 only, seed_x.py:191)
+  * ``precise`` (default on; ``SX_LLM_PRECISE=0`` or ``precise=False`` for the plain 16-bit flow): fp32-grade activations — every GEMM
+    A operand travels as two 16-bit planes x = hi + lo (the 16-bit checkpoint weights are exact and stream once), q / k / v, RoPE, the
+    KV cache and attention stay fp32 (csrc/precise.hip). 40 layers at 13B dims: logits within 1e-3 of the reference evaluated in fp32 (2.3e-3 without;
+    the per-site budget is tools/llm_error_budget.py); costs < 1 % of a generation (the LLM is 1 % of its FLOPs and
+    the decode step is bound by the weight bytes, which do not change)
   * ``comm`` with world > 1: Megatron tensor parallelism (parallel.py) — this rank owns nh/tp heads (their q/k/v rows, KV
     cache and o_proj columns), I/tp FFN rows (gate/up rows, down_proj columns) and Vpad/tp lm_head rows; the fp32
     residual stream is all-reduced after o_proj and down_proj (rank 0's GEMM epilogue adds the residual), the logits are
@@ -74,7 +79,7 @@ class CausalLMOutputWithPast(dict):
 
 
 class LlamaForCausalLM:
-    def __init__(self, config, max_cache_len=None, max_batch=1, comm=None):
+    def __init__(self, config, max_cache_len=None, max_batch=1, comm=None, precise=None):
         self.config = config if not isinstance(config, dict) else LlamaConfigLite(**config)
         c = self.config
         self.H, self.nh, self.L = c.hidden_size, c.num_attention_heads, c.num_hidden_layers
@@ -89,6 +94,12 @@ class LlamaForCausalLM:
         self.Tmax = max_cache_len or c.max_position_embeddings
         self.G = int(max_batch)
         assert 1 <= self.G <= 32, "lock-step batch is limited to 32 sequences (two 16-row operand blocks of sx_gemv)"
+        # fp32-grade activations (module docstring). The skinny GEMM's second operand block carries the lo plane, so the lock-step
+        # batch of the precise mode ends at 16 sequences; larger batches (config 2's 32) run the plain 16-bit flow.
+        if precise is None:
+            precise = os.environ.get("SX_LLM_PRECISE", "1") != "0" and self.G <= 16
+        self.precise = bool(precise)
+        assert not self.precise or self.G <= 16, "precise mode: at most 16 lock-step sequences (the second operand block is the lo plane)"
         # Decode attention (tools/bench_decode_attention_ab.py, 16 sequences x 40 heads, ms per token of the graph-replayed step):
         # three launches (RoPE + append, split-KV attention, combine) with 8 / 2 / 1 KV splits 6.70 / 6.46 / 6.52; ONE launch
         # (sx_attn_decode_fused, bit-identical) with 8 splits 6.80 — its arrival-counter tail costs more than two graph
@@ -194,7 +205,8 @@ class LlamaForCausalLM:
         # the consumer adds the producer's per-workgroup sums of squares 64 at a time: the o / down launches (N = H) must have a
         # multiple of 64 workgroups (H = 5120: 256 with 20-row tiles, 320 without)
         parts = self.H // 20 if (bal20 and self.H % 20 == 0 and self.H // 20 == 256) else (self.H // 32 if self.H // 32 >= 256 else self.H // 16)
-        fold = self.G >= 5 and tp == 1 and parts % 64 == 0 and os.environ.get("SX_RMS_FOLD", "1") != "0"      # (0: A/B switch, tools/)
+        fold = self.G >= 5 and tp == 1 and parts % 64 == 0 and os.environ.get("SX_RMS_FOLD", "1") != "0" \
+            and not self.precise      # (SX_RMS_FOLD=0: A/B switch, tools/; the precise mode norms in fp32 with its own kernel)
         for i in range(self.L):
             p = f"model.layers.{i}."
             sh = llama_tp_shard(sd, p, r, tp, self.nh, self.hd)
@@ -225,13 +237,17 @@ class LlamaForCausalLM:
         assert P["rms_fold"] or not fold or not any(lw["wgu_t"] is not None for lw in P["layers"]), \
             "folded decode tiles without the tiled decode path"
         # split-K scratch of the skinny GEMM: counters + 8 partial [16, H] blocks (include/seedx_hip.h: sx_gemv_args.workspace)
-        P["gemv_ws"] = torch.zeros(16384 + 8 * 16 * ((self.G + 15) // 16) * self.H * 4, dtype=torch.uint8, device=dev) \
-            if P["decode_tiled"] else None
+        P["gemv_ws"] = torch.zeros(16384 + 8 * 16 * (2 if self.precise else (self.G + 15) // 16) * self.H * 4, dtype=torch.uint8,
+                                   device=dev) if P["decode_tiled"] else None
+        # precise decode step on the skinny GEMM (operand tiles, two planes): every projection shape must satisfy its MFMA path
+        P["precise_tiled"] = all(k % 64 == 0 and k >= 256 for k in (self.H, self.H_l, self.I_l)) and \
+            all(n % 32 == 0 for n in (3 * self.H_l, self.H, 2 * self.I_l, self.V_l))
         inv = 1.0 / (self.config.rope_base ** (torch.arange(0, self.hd, 2).float() / self.hd))
         fr = torch.outer(torch.arange(self.Tmax).float(), inv)           # [Tmax, hd/2] fp32 (:97-113)
         P["cos"], P["sin"] = fr.cos().to(dev).contiguous(), fr.sin().to(dev).contiguous()
         G = self.G
-        P["kc"] = torch.zeros((self.L, G, self.nh_l, self.Tmax, self.hd), dtype=dt, device=dev)   # this rank's heads
+        P["kc"] = torch.zeros((self.L, G, self.nh_l, self.Tmax, self.hd), dtype=torch.float32 if self.precise else dt,
+                              device=dev)                                                          # this rank's heads
         P["vc"] = torch.zeros_like(P["kc"])
         # device-resident loop state, one entry per sequence
         P["pos"] = torch.zeros(G, dtype=torch.int32, device=dev)         # position of the next input token
@@ -261,6 +277,7 @@ class LlamaForCausalLM:
         stream, rows ordered like seqs. Returns the final residual stream."""
         P, dt, H, nh, hd = self._P, self.dtype, self.H_l, self.nh_l, self.hd     # local heads under tensor parallelism
         comm, lead = self.comm, self.comm.rank == 0
+        pr = self.precise
         n = len(seqs)
         pos_all = P["pos"].tolist()                                              # one host read per pass
         pos0 = [pos_all[g] for g in seqs]
@@ -276,6 +293,27 @@ class LlamaForCausalLM:
         g0 = seqs[0]
         for li, lw in enumerate(P["layers"]):
             kc_l, vc_l = P["kc"][li], P["vc"][li]
+            if pr:
+                # fp32-grade activations: operand planes into a_planes = 2 GEMMs with fp32 outputs, fp32 RoPE / cache / attention
+                h, _ = ops.rmsnorm_planes(x, lw["ln1"], eps, dt)
+                qkv = ops.gemm(h, lw["wqkv"], a_planes=2, out_dtype=torch.float32)    # [M, 3H] fp32
+                if uniform:
+                    ops.rope_kv_append_f32(qkv, kc_l[g0:g0 + n], vc_l[g0:g0 + n], P["cos"], P["sin"], P["pos"][g0:g0 + n], n, Ts[0],
+                                           nh, hd, dt)
+                    att = ops.attention_f32(qkv, kc_l[g0:g0 + n], vc_l[g0:g0 + n], P["pos"][g0:g0 + n], n, Ts[0], nh, hd, scale, dt)
+                else:
+                    att = torch.empty((M, 2 * H), dtype=dt, device=x.device)
+                    for i, g in enumerate(seqs):
+                        rows = qkv[offs[i]:offs[i + 1]]
+                        ops.rope_kv_append_f32(rows, kc_l[g:g + 1], vc_l[g:g + 1], P["cos"], P["sin"], P["pos"][g:g + 1], 1, Ts[i], nh,
+                                               hd, dt)
+                        att[offs[i]:offs[i + 1]] = ops.attention_f32(rows, kc_l[g:g + 1], vc_l[g:g + 1], P["pos"][g:g + 1], 1, Ts[i],
+                                                                     nh, hd, scale, dt)
+                x = comm.all_reduce(ops.gemm(att, lw["wo"], a_planes=2, residual=x if lead else None, out_dtype=torch.float32))
+                h, _ = ops.rmsnorm_planes(x, lw["ln2"], eps, dt)
+                g_ = ops.split16(ops.gemm(h, lw["wgu"], a_planes=2, act="silu", glu=True, out_dtype=torch.float32), dt)
+                x = comm.all_reduce(ops.gemm(g_, lw["wd"], a_planes=2, residual=x if lead else None, out_dtype=torch.float32))
+                continue
             h = ops.rmsnorm(x, lw["ln1"], eps, dt)
             qkv = ops.gemm(h, lw["wqkv"])                                             # [M, 3H]
             if uniform:
@@ -320,6 +358,8 @@ class LlamaForCausalLM:
         # kernel that produces them (norm, attention combine, GLU epilogue) — one contiguous 1-KB load per operand instead of
         # 16 rows that all sit on the same L2 channel — and the down projection may split K over workgroups (workspace)
         tl, ws = P["decode_tiled"] and G >= 5, P["gemv_ws"]
+        if self.precise:
+            return self._layers_single_precise(x)
         # folded RMSNorm: the residual GEMVs (o, down) also emit the new residual stream as 16-bit operand tiles (x16) and its rows'
         # sums of squares (ssq); the projection behind the norm reads x16 with gamma-folded weights and scales by rstd — no norm launch
         fold = tl and P["rms_fold"]
@@ -360,6 +400,49 @@ class LlamaForCausalLM:
         ops.add_i32(P["ctx"], 1)
         return x
 
+    def _layers_single_precise(self, x):
+        """_layers_single with fp32-grade activations: the x operand of every skinny GEMM is a two-block Tiled16 (hi plane, lo plane;
+        sx_gemv x_planes = 2 — each weight fragment feeds two MFMAs, the weights stream once), its outputs are fp32; RoPE, the KV
+        cache and attention are fp32 (sx_rope_kv_append_f32, sx_attention_f32 at T = 1). Shapes outside the skinny GEMM's MFMA path
+        (miniature test dims) take the a_planes = 2 GEMM instead. No host reads → graph-capturable."""
+        P, dt, nh, hd, G = self._P, self.dtype, self.nh_l, self.hd, self.G
+        comm, lead = self.comm, self.comm.rank == 0
+        eps, scale = self.config.rms_norm_eps, 1.0 / math.sqrt(hd)
+        tl, ws, f32 = P["precise_tiled"], P["gemv_ws"], torch.float32
+        dtl = tl and P["decode_tiled"] and G >= 5            # decode-tile weight copies exist and pay off
+
+        def lin(xp, lw, k, **kw):
+            if tl:
+                return ops.gemv(xp, lw[k], w_tiles=lw[k + "_t"] if dtl else None, workspace=ws if dtl else None,
+                                w_tiles20=lw.get(k + "_t20") if dtl else None, out_dtype=f32, **kw)
+            return ops.gemm(xp, lw[k], a_planes=2, out_dtype=f32, **kw)
+        for li, lw in enumerate(P["layers"]):
+            h, _ = ops.rmsnorm_planes(x, lw["ln1"], eps, dt, tiled=tl)
+            qkv = lin(h, lw, "wqkv")                                                  # [G, 3H] fp32
+            ops.rope_kv_append_f32(qkv, P["kc"][li], P["vc"][li], P["cos"], P["sin"], P["pos"], G, 1, nh, hd, dt)
+            att = ops.attention_f32(qkv, P["kc"][li], P["vc"][li], P["pos"], G, 1, nh, hd, scale, dt, tiled=tl)
+            x = comm.all_reduce(lin(att, lw, "wo", residual=x if lead else None))
+            h, _ = ops.rmsnorm_planes(x, lw["ln2"], eps, dt, tiled=tl)
+            g = ops.split16(lin(h, lw, "wgu", act="silu", glu=True), dt, tiled=tl)
+            x = comm.all_reduce(lin(g, lw, "wd", residual=x if lead else None))
+        ops.add_i32(P["pos"], 1)
+        ops.add_i32(P["ctx"], 1)
+        return x
+
+    def _final_norm(self, x):
+        """model.norm (modeling_llama_xformer.py:595) → fp32 hidden states."""
+        if self.precise:
+            return ops.rmsnorm_planes(x.contiguous(), self._P["norm"], self.config.rms_norm_eps, self.dtype, want_f32=True,
+                                      want_planes=False)[1]
+        return ops.rmsnorm(x, self._P["norm"], self.config.rms_norm_eps, torch.float32)
+
+    def _lm_head(self, hn_rows):
+        """lm_head (:707) on fp32 post-norm rows → fp32 logits [rows, Vpad / tp]."""
+        P = self._P
+        if self.precise:
+            return ops.linear_planes(hn_rows.contiguous(), P["lm_head"], w_tiles=P["lm_head_t"], out_dtype=torch.float32)
+        return ops.linear(ops.cast(hn_rows.contiguous(), self.dtype), P["lm_head"], out_dtype=torch.float32)
+
     def forward_embeds(self, inputs_embeds, need_logits=True, seq=0):
         """inputs_embeds: fp32 [T, H] on the GPU, appended to sequence `seq` at its current cache position.
         Returns (logits fp32 [Vpad] of the LAST position or None, final-norm hidden states fp32 [T, H])."""
@@ -371,10 +454,10 @@ class LlamaForCausalLM:
             x = self._layers_single(x)
         else:
             x = self._layers_multi(x, [T], [seq])
-        hn = ops.rmsnorm(x, P["norm"], self.config.rms_norm_eps, torch.float32)      # :595
+        hn = self._final_norm(x)                                                     # :595
         logits = None
         if need_logits:
-            logits = ops.linear(ops.cast(hn[-1:].contiguous(), self.dtype), P["lm_head"], out_dtype=torch.float32)[0]
+            logits = self._lm_head(hn[-1:])[0]
             if self.tp > 1:
                 logits = self.comm.all_gather(logits).reshape(-1)                     # [tp, V/tp] → [Vpad], vocab order
         return logits, hn
@@ -386,12 +469,11 @@ class LlamaForCausalLM:
         Ts = [int(x.shape[0]) for x in xs]
         x = torch.cat([x.to(device=self.device, dtype=torch.float32) for x in xs], dim=0).contiguous()   # plumbing
         x = self._layers_multi(x, Ts, list(seqs))
-        hn = ops.rmsnorm(x, P["norm"], self.config.rms_norm_eps, torch.float32)
+        hn = self._final_norm(x)
         ends = torch.tensor([sum(Ts[:i + 1]) - 1 for i in range(len(Ts))], device=self.device)
         logits = None
         if need_logits:
-            last = ops.cast(hn[ends].contiguous(), self.dtype)                         # [n, H]
-            logits = ops.linear(last, P["lm_head"], out_dtype=torch.float32)
+            logits = self._lm_head(hn[ends])                                           # [n, Vpad / tp]
             if self.tp > 1:
                 logits = self.comm.all_gather(logits).permute(1, 0, 2).reshape(len(Ts), self.Vpad).contiguous()
         return logits, list(torch.split(hn, Ts, dim=0))
@@ -444,7 +526,7 @@ class LlamaForCausalLM:
             logits = logits[: self.V].view(1, 1, -1)
         else:
             _, hn = self.forward_embeds(x, need_logits=False, seq=0)
-            logits = ops.linear(ops.cast(hn.contiguous(), self.dtype), P["lm_head"], out_dtype=torch.float32)   # [T, Vpad / tp]
+            logits = self._lm_head(hn)                                                                           # [T, Vpad / tp]
             if self.tp > 1:
                 logits = self.comm.all_gather(logits).permute(1, 0, 2).reshape(T, self.Vpad)
             logits = logits[:, : self.V].unsqueeze(0)
@@ -465,10 +547,18 @@ class LlamaForCausalLM:
         P = self._P
         x = ops.embedding(P["cur"], P["embed"])                                        # [G, H] fp32
         x = self._layers_single(x)
-        hn = ops.rmsnorm(x, P["norm"], self.config.rms_norm_eps, torch.float32)
-        ops.scatter_rows_step(hn, P["step"], hid_buf)
-        logits = ops.gemv(ops.cast(hn, self.dtype), P["lm_head"], out_dtype=torch.float32,
-                          w_tiles=P["lm_head_t"])                                      # [G, Vpad / tp]
+        if self.precise:
+            hp, hn = ops.rmsnorm_planes(x, P["norm"], self.config.rms_norm_eps, self.dtype, tiled=P["precise_tiled"], want_f32=True)
+            ops.scatter_rows_step(hn, P["step"], hid_buf)
+            if P["precise_tiled"]:
+                logits = ops.gemv(hp, P["lm_head"], out_dtype=torch.float32, w_tiles=P["lm_head_t"])
+            else:
+                logits = ops.gemm(hp, P["lm_head"], a_planes=2, out_dtype=torch.float32)
+        else:
+            hn = ops.rmsnorm(x, P["norm"], self.config.rms_norm_eps, torch.float32)
+            ops.scatter_rows_step(hn, P["step"], hid_buf)
+            logits = ops.gemv(ops.cast(hn, self.dtype), P["lm_head"], out_dtype=torch.float32,
+                              w_tiles=P["lm_head_t"])                                  # [G, Vpad / tp]
         if self.tp > 1:
             logits = self.comm.all_gather(logits).permute(1, 0, 2).reshape(self.G, self.Vpad).contiguous()
         ops.greedy_next_b(logits, self.V, img_ids_dev, P["cur"], out_ids, P["step"])

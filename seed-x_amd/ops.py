@@ -113,16 +113,19 @@ def _launch_gemm(lib, args, gn, what):
 
 
 def gemm(a, w, bias=None, bias2d=None, bias2d_rows=0, residual=None, res_mod=0, act=None, glu=False,
-         out_dtype=None, out=None, n_valid=0, ld_bias2d=0, gn=None, ln_emit=None, ln_apply=None):
+         out_dtype=None, out=None, n_valid=0, ld_bias2d=0, gn=None, ln_emit=None, ln_apply=None, a_planes=1):
     """out[M, N_out] = epilogue(a[M, K] @ w[N, K]^T). a, w: 16-bit contiguous. residual/bias fp32.
     gn: optional GnStats of the output (the next GroupNorm's statistics pass fused into this launch, see GnStats).
-    ln_emit / ln_apply: the two sides of a folded LayerNorm (see LnRows)."""
+    ln_emit / ln_apply: the two sides of a folded LayerNorm (see LnRows).
+    a_planes = 2: a is [M, 2K] = [hi | lo], the planes of an fp32-grade activation (split16 / rmsnorm_planes / attention_f32)."""
     lib = _lib.load()
     assert a.dim() == 2 and w.dim() == 2 and a.is_contiguous() and w.is_contiguous()
     assert a.dtype == w.dtype and a.dtype in (torch.float16, torch.bfloat16)
     M, K = a.shape
     N = w.shape[0]
-    assert w.shape[1] == K, f"K mismatch {a.shape} vs {w.shape}"
+    assert a_planes in (1, 2) and K % a_planes == 0
+    K //= a_planes
+    assert w.shape[1] == K, f"K mismatch {a.shape} vs {w.shape} (a_planes {a_planes})"
     n_out = N // 2 if glu else N
     n_store = n_valid if n_valid else n_out
     out_dtype = out_dtype or a.dtype
@@ -150,6 +153,7 @@ def gemm(a, w, bias=None, bias2d=None, bias2d_rows=0, residual=None, res_mod=0, 
     args.act = ACT[act]
     args.glu = 1 if glu else 0
     args.a_mode = SX_A_LINEAR
+    args.a_planes = a_planes
     if ln_emit is not None or ln_apply is not None:
         assert gn is None and not (ln_emit is not None and ln_apply is not None)
         la = _lib.GemmLnArgs()
@@ -231,20 +235,25 @@ class Tiled16:
     """A [rows <= 32, cols] 16-bit activation of the decode step held as MFMA operand tiles [rows/16][cols/32][16][32] (SX_TILED16
     in include/seedx_hip.h): what the skinny GEMM reads with one contiguous 1-KB load per operand. Rows 16..31 (lock-step batches
     above 16) are a second block of tiles behind the first; rows >= `rows` of the last block are padding."""
-    __slots__ = ("t", "rows", "cols")
+    __slots__ = ("t", "rows", "cols", "planes")
 
-    def __init__(self, rows, cols, dtype, device):
-        assert rows <= 32 and cols % 32 == 0
-        self.t, self.rows, self.cols = torch.empty(((rows + 15) // 16, cols // 32, 16, 32), dtype=dtype, device=device), rows, cols
+    def __init__(self, rows, cols, dtype, device, planes=1):
+        """planes = 2 (rows <= 16): block 0 = hi plane, block 1 = lo plane of an fp32-grade activation (sx_gemv x_planes = 2)."""
+        assert rows <= 32 and cols % 32 == 0 and planes in (1, 2) and (planes == 1 or rows <= 16)
+        nb = 2 if planes == 2 else (rows + 15) // 16
+        self.t, self.rows, self.cols, self.planes = torch.empty((nb, cols // 32, 16, 32), dtype=dtype, device=device), rows, cols, planes
 
     @property
     def dtype(self):
         return self.t.dtype
 
     def dense(self):
-        """[rows, cols] row-major copy (tests)."""
+        """[rows, cols] row-major copy (tests); planes = 2: fp32 hi + lo."""
         nb = self.t.shape[0]
-        return self.t.permute(0, 2, 1, 3).reshape(nb * 16, self.cols)[:self.rows].contiguous()
+        d = self.t.permute(0, 2, 1, 3).reshape(nb * 16, self.cols)
+        if self.planes == 2:
+            return d[:self.rows].float() + d[16:16 + self.rows].float()
+        return d[:self.rows].contiguous()
 
 
 def gemv(x, w, residual=None, act=None, glu=False, out_dtype=None, w_tiles=None, y_tiled=False, workspace=None,
@@ -260,7 +269,7 @@ def gemv(x, w, residual=None, act=None, glu=False, out_dtype=None, w_tiles=None,
     xt = isinstance(x, Tiled16)
     if xt:
         M, K = x.rows, x.cols
-        assert (w_tiles is not None or w_tiles20 is not None) and x.dtype == w.dtype
+        assert x.dtype == w.dtype and (x.planes == 2 or w_tiles is not None or w_tiles20 is not None)
     else:
         assert x.dim() == 2 and x.is_contiguous() and w.is_contiguous() and x.dtype == w.dtype
         M, K = x.shape
@@ -276,6 +285,7 @@ def gemv(x, w, residual=None, act=None, glu=False, out_dtype=None, w_tiles=None,
     args = GemvArgs()
     args.x, args.W, args.y = (x.t if xt else x).data_ptr(), w.data_ptr(), y.data_ptr()
     args.x_layout = 1 if xt else 0
+    args.x_planes = x.planes if xt else 1
     if workspace is not None:
         args.workspace, args.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
     if residual is not None:
@@ -454,6 +464,73 @@ def attn_decode(q, kcache, vcache, ctx_len_dev, scale, nsplit=8):
     check(lib.sx_attn_decode(_p(q), _p(kcache), _p(vcache), _p(out), _p(scratch), _p(ctx_len_dev), H, D, Tmax, nsplit,
                              float(scale), _DT[q.dtype], _stream()), "sx_attn_decode")
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------
+# fp32-grade activations of the Llama decoder (LlamaForCausalLM(precise=True); csrc/precise.hip)
+# ---------------------------------------------------------------------------------------------------------
+def _planes_out(rows, cols, dtype, device, tiled):
+    if tiled:
+        t = Tiled16(rows, cols, dtype, device, planes=2)
+        return t, t.t, _DT[dtype] | _lib.SX_TILED16
+    y = torch.empty((rows, 2 * cols), dtype=dtype, device=device)
+    return y, y, _DT[dtype]
+
+
+def split16(x, dtype, tiled=False):
+    """fp32 [rows, cols] → its two 16-bit planes x = hi + lo: [rows, 2*cols] = [hi | lo] (gemm a_planes = 2), or with ``tiled`` a
+    two-block Tiled16 (gemv)."""
+    assert x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
+    rows, cols = x.shape
+    ret, buf, code = _planes_out(rows, cols, dtype, x.device, tiled)
+    check(_lib.load().sx_split16(_p(x), x.stride(0), _p(buf), rows, cols, code, _stream()), "sx_split16")
+    return ret
+
+
+def rmsnorm_planes(x, gamma, eps, dtype, tiled=False, want_f32=False, want_planes=True):
+    """LlamaRMSNorm in fp32 → (planes of y or None, y fp32 or None)."""
+    assert x.dtype == torch.float32 and x.dim() == 2 and x.is_contiguous()
+    rows, cols = x.shape
+    ret = buf = None
+    code = _DT[dtype]
+    if want_planes:
+        ret, buf, code = _planes_out(rows, cols, dtype, x.device, tiled)
+    y32 = torch.empty_like(x) if want_f32 else None
+    check(_lib.load().sx_rmsnorm_planes(_p(x), _p(_f32c(gamma)), _p(y32), _p(buf), rows, cols, float(eps), code, _stream()),
+          "sx_rmsnorm_planes")
+    return ret, y32
+
+
+def rope_kv_append_f32(qkv, kcache, vcache, cos_tab, sin_tab, pos_dev, G, T, H, D, table_dtype):
+    """qkv fp32 [G*T, 3HD] (q rotated in place); fp32 caches [G, H, Tmax, D]; pos_dev int32 [G]."""
+    assert qkv.dtype == torch.float32 and qkv.is_contiguous() and qkv.shape == (G * T, 3 * H * D)
+    assert kcache.dtype == torch.float32 and vcache.dtype == torch.float32 and kcache.dim() == 4 and kcache.shape[0] == G \
+        and kcache[0].is_contiguous() and vcache.stride() == kcache.stride()
+    check(_lib.load().sx_rope_kv_append_f32(_p(qkv), _p(kcache), _p(vcache), _p(cos_tab), _p(sin_tab), _p(pos_dev), G, T, H, D,
+                                            kcache.shape[2], kcache.stride(0), _DT[table_dtype], _stream()), "sx_rope_kv_append_f32")
+
+
+def attention_f32(qkv, kcache, vcache, pos_dev, G, T, H, D, scale, dtype, tiled=False):
+    """Causal fp32 attention of a T-token chunk per sequence over the fp32 cache (row t sees keys 0 .. pos[g] + t); q = the rotated
+    head rows at the front of qkv's rows. Returns the planes of the context [G*T, H*D] (see split16)."""
+    assert qkv.dtype == torch.float32 and qkv.is_contiguous() and qkv.shape[0] == G * T and qkv.shape[1] >= H * D
+    assert kcache.dtype == torch.float32 and kcache.shape[0] == G and kcache.shape[1] == H and kcache.shape[3] == D
+    ret, buf, code = _planes_out(G * T, H * D, dtype, qkv.device, tiled)
+    a = _lib.AttnF32Args()
+    a.q, a.kcache, a.vcache, a.out, a.pos0_dev = _p(qkv), _p(kcache), _p(vcache), _p(buf), _p(pos_dev)
+    a.q_row_stride, a.cache_seq_stride = qkv.stride(0), kcache.stride(0)
+    a.G, a.T, a.H, a.D, a.Tmax, a.dtype, a.scale = G, T, H, D, kcache.shape[2], code, float(scale)
+    check(_lib.load().sx_attention_f32(C.byref(a), _stream()), "sx_attention_f32")
+    return ret
+
+
+def linear_planes(x32, w, w_tiles=None, **kw):
+    """epilogue(x32 @ w^T) with x32 fp32 carried as two 16-bit planes: <= 16 rows on the weight-streaming skinny GEMM, else the MFMA GEMM."""
+    M, K = x32.shape
+    N = w.shape[0]
+    if M <= 16 and K % 64 == 0 and K >= 256 and N % 32 == 0:
+        return gemv(split16(x32, w.dtype, tiled=True), w, w_tiles=w_tiles, **kw)
+    return gemm(split16(x32, w.dtype), w, a_planes=2, **kw)
 
 
 # ---------------------------------------------------------------------------------------------------------

@@ -228,7 +228,8 @@ def test_ctypes_struct_layout_matches_header():
     src = open(os.path.join(ROOT, "include", "seedx_hip.h")).read()
     for cname, cls in (("sx_gemm_args", _lib.GemmArgs), ("sx_gemv_args", _lib.GemvArgs), ("sx_attn_args", _lib.AttnArgs),
                        ("sx_attn_small_args", _lib.AttnSmallArgs), ("sx_oneshot_args", _lib.OneshotArgs),
-                       ("sx_attn_decode_args", _lib.AttnDecodeArgs), ("sx_gemm_ln_args", _lib.GemmLnArgs)):
+                       ("sx_attn_decode_args", _lib.AttnDecodeArgs), ("sx_gemm_ln_args", _lib.GemmLnArgs),
+                       ("sx_attn_f32_args", _lib.AttnF32Args)):
         body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), src, flags=re.S).group(1)
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
         names = []

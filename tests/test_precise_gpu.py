@@ -1,0 +1,285 @@
+"""fp32-grade activations of the Llama decoder (LlamaForCausalLM(precise=True), csrc/precise.hip).
+
+Kernel level: the operand-plane split (bit-exact vs torch), sx_gemm a_planes = 2 and sx_gemv x_planes = 2 against fp64 products of the SAME
+planes (what is left is fp32 accumulation: 1e-6), fp32 RMSNorm / RoPE / attention against torch fp32-on-fp64 references.
+Model level: the miniature decoder against the fp32 oracle (oracle/restated.py, pinned on the reference's modeling_llama_xformer.py) at 2e-4 —
+ten times below the plain 16-bit flow's bound —, prefill == prefill + decode steps == lock-step batch, graph replay == eager, and the plain
+flow (precise=False) still inside its own bound. Reference: modeling_llama_xformer.py:95 (RMSNorm), :141-149 (RoPE), :204-239 (attention)."""
+import math
+
+import pytest
+import torch
+
+from oracle import restated, weights
+
+pytestmark = pytest.mark.gpu
+DTS = [torch.float16, torch.bfloat16]
+
+
+def relerr(x, ref):
+    x, ref = x.double().cpu(), ref.double().cpu()
+    return ((x - ref).norm() / ref.norm()).item()
+
+
+def _planes_ref(x, dt):
+    hi = x.to(dt)
+    lo = (x - hi.float()).to(dt)
+    return hi, lo
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_split16_bit_exact_both_layouts(dev, dt):
+    from seedx_amd import ops
+    g = torch.Generator().manual_seed(0)
+    x = (torch.randn(37, 256, generator=g) * torch.logspace(-3, 2, 256)[None, :]).to(dev)
+    hi, lo = _planes_ref(x, dt)
+    y = ops.split16(x, dt)
+    assert y.shape == (37, 512) and torch.equal(y[:, :256], hi) and torch.equal(y[:, 256:], lo)
+    xs = x[:11]
+    t = ops.split16(xs, dt, tiled=True)
+    assert t.planes == 2 and tuple(t.t.shape) == (2, 8, 16, 32)
+    d = t.t.permute(0, 2, 1, 3).reshape(32, 256)
+    assert torch.equal(d[:11], hi[:11]) and torch.equal(d[16:27], lo[:11])
+    assert torch.equal(t.dense(), hi[:11].float() + lo[:11].float())
+    # a strided source (columns of a wider buffer)
+    wide = torch.randn(9, 512, generator=g).to(dev)
+    y2 = ops.split16(wide[:, 128:384], dt)
+    h2, l2 = _planes_ref(wide[:, 128:384].contiguous(), dt)
+    assert torch.equal(y2[:, :256], h2) and torch.equal(y2[:, 256:], l2)
+    # the planes carry >= 19 (fp16: 21) bits of the fp32 value
+    assert relerr(y[:, :256].float() + y[:, 256:].float(), x) < (3e-6 if dt == torch.float16 else 2e-5)
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("rows,cols", [(5, 256), (16, 5120), (300, 1024)])
+def test_rmsnorm_planes(dev, dt, rows, cols):
+    from seedx_amd import ops
+    g = torch.Generator().manual_seed(1)
+    x = (torch.randn(rows, cols, generator=g) * 3.0).to(dev)
+    gam = (1.0 + 0.1 * torch.randn(cols, generator=g)).to(dev)
+    xd = x.double()
+    ref = gam.double() * (xd * torch.rsqrt(xd.pow(2).mean(-1, keepdim=True) + 1e-5))
+    tiled = rows <= 16
+    p, y32 = ops.rmsnorm_planes(x, gam, 1e-5, dt, tiled=tiled, want_f32=True)
+    assert relerr(y32, ref) < 2e-7
+    dense = p.dense() if tiled else p[:, :cols].float() + p[:, cols:].float()
+    hi, lo = _planes_ref(y32, dt)
+    assert torch.equal(dense, hi.float() + lo.float())               # the planes are the split of the fp32 result
+    _, y_only = ops.rmsnorm_planes(x, gam, 1e-5, dt, want_f32=True, want_planes=False)
+    assert torch.equal(y_only, y32)
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("M,N,K,kw", [
+    (2640, 1536, 1024, {}),                                   # ping-pong tiles, fp32 out
+    (2640, 1024, 1024, {"res": True}),                        # fp32 residual as the accumulators' initial value
+    (333, 1408, 256, {"glu": True}),                          # SiLU-GLU, fp32 out, ragged M
+    (64, 512, 704, {}),                                       # small lock-step tile, K = 11 k-tiles
+    (1040, 5120, 5120, {"res": True}),
+])
+def test_gemm_two_planes(dev, dt, M, N, K, kw):
+    from seedx_amd import ops
+    from seedx_amd.llama import glu_pack_rows
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(M, K, generator=g).to(dev)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(dev, dt)
+    res = torch.randn(M, N, generator=g).to(dev) if kw.get("res") else None
+    a2 = ops.split16(x, dt)
+    xr = (a2[:, :K].double() + a2[:, K:].double())
+    if kw.get("glu"):
+        lin, gate = w[: N // 2], w[N // 2:]
+        y = ops.gemm(a2, glu_pack_rows(lin, gate), a_planes=2, act="silu", glu=True, out_dtype=torch.float32)
+        ref = (xr @ lin.double().T) * torch.nn.functional.silu(xr @ gate.double().T)
+        tol = 3e-6
+    else:
+        y = ops.gemm(a2, w, a_planes=2, residual=res, out_dtype=torch.float32)
+        ref = xr @ w.double().T + (res.double() if res is not None else 0.0)
+        tol = 2e-6
+    e = relerr(y, ref)
+    # vs the fp32 x itself: the planes' own rounding (2^-22 fp16 / 2^-17 bf16) is all that is added
+    print(f"gemm a_planes=2 {dt} {M}x{N}x{K} {kw}: vs the planes' exact product {e:.2e}")
+    assert e < tol
+    # one plane only (a_planes = 1 on the hi plane) must differ: the lo plane is really read
+    if not kw.get("glu"):
+        y1 = ops.gemm(a2[:, :K].contiguous(), w, residual=res, out_dtype=torch.float32)
+        assert relerr(y1, ref) > 20 * e
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("M", [1, 3, 16])
+def test_gemv_two_planes(dev, dt, M):
+    from seedx_amd import ops
+    from seedx_amd.llama import glu_pack_rows
+    g = torch.Generator().manual_seed(3 + M)
+    for (N, K, glu, res, layout) in [(1536, 512, False, False, "rm"), (5120, 1024, False, True, "t20"), (5120, 5120, False, True, "t"),
+                                     (2816, 512, True, False, "t"), (640, 13824, False, True, "t")]:
+        x = torch.randn(M, K, generator=g).to(dev)
+        w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(dev, dt)
+        r = torch.randn(M, N, generator=g).to(dev) if res else None
+        xt = ops.split16(x, dt, tiled=True)
+        xr = xt.dense().double()
+        wk = glu_pack_rows(w[: N // 2], w[N // 2:]) if glu else w
+        kw = dict(w_tiles=ops.pack_decode_tiles(wk) if layout != "rm" else None,
+                  w_tiles20=ops.pack_decode_tiles20(wk) if layout == "t20" else None)
+        ws = torch.zeros(16384 + 8 * 32 * N * 4, dtype=torch.uint8, device=dev)
+        y = ops.gemv(xt, wk, residual=r, act="silu" if glu else None, glu=glu, out_dtype=torch.float32, workspace=ws, **kw)
+        if glu:
+            ref = (xr @ w[: N // 2].double().T) * torch.nn.functional.silu(xr @ w[N // 2:].double().T)
+        else:
+            ref = xr @ w.double().T + (r.double() if res else 0.0)
+        e = relerr(y, ref)
+        print(f"gemv x_planes=2 {dt} M={M} {N}x{K} glu={glu} {layout}: {e:.2e}")
+        assert tuple(y.shape) == (M, N // 2 if glu else N) and e < 3e-6
+        assert int(ws[:16384].view(torch.int32).abs().sum()) == 0                 # split-K counters left at zero
+        # the same product through the two-plane GEMM
+        y2 = ops.gemm(ops.split16(x, dt), wk, a_planes=2, residual=r, act="silu" if glu else None, glu=glu, out_dtype=torch.float32)
+        assert relerr(y2, ref) < 3e-6
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_rope_kv_append_f32(dev, dt):
+    from seedx_amd import ops
+    G, T, H, D, Tmax = 3, 5, 2, 128, 64
+    g = torch.Generator().manual_seed(4)
+    qkv = torch.randn(G * T, 3 * H * D, generator=g).to(dev)
+    q0 = qkv.clone()
+    kc = torch.zeros(G, H, Tmax, D, device=dev)
+    vc = torch.zeros_like(kc)
+    pos = torch.tensor([0, 7, 59], dtype=torch.int32, device=dev)           # the last sequence runs into the end of the cache
+    inv = 1.0 / (10000.0 ** (torch.arange(0, D, 2).float() / D))
+    fr = torch.outer(torch.arange(Tmax).float(), inv)
+    cos, sin = fr.cos().to(dev).contiguous(), fr.sin().to(dev).contiguous()
+    ops.rope_kv_append_f32(qkv, kc, vc, cos, sin, pos, G, T, H, D, dt)
+    c16, s16 = cos.to(dt).double(), sin.to(dt).double()
+    for gi in range(G):
+        for t in range(T):
+            p = int(pos[gi]) + t
+            row, new = q0[gi * T + t].double().view(3, H, D), qkv[gi * T + t].view(3, H, D)
+            pc = min(p, Tmax - 1) if p < Tmax else 0
+            c, s = c16[pc], s16[pc]
+            rot = lambda x: torch.cat([x[:, :D // 2] * c - x[:, D // 2:] * s, x[:, D // 2:] * c + x[:, :D // 2] * s], -1)
+            if p < Tmax:
+                assert relerr(new[0], rot(row[0])) < 2e-7
+                assert relerr(kc[gi, :, p], rot(row[1])) < 2e-7 and torch.equal(vc[gi, :, p], q0[gi * T + t].view(3, H, D)[2])
+            assert torch.equal(new[1:], q0[gi * T + t].view(3, H, D)[1:])      # k / v rows of qkv stay as they were
+    assert float(kc[2, :, :59].abs().sum()) == 0 and float(kc[0, :, 5:].abs().sum()) == 0       # nothing outside the appended rows
+
+
+def _attn_ref(q, kc, vc, pos, T, scale):
+    """q [G*T, H, D] fp64; caches [G, H, Tmax, D]; row t of sequence g sees keys 0 .. pos[g] + t."""
+    G, H = kc.shape[0], kc.shape[1]
+    out = torch.zeros(G * T, H, q.shape[-1], dtype=torch.float64)
+    for g in range(G):
+        for t in range(T):
+            n = int(pos[g]) + t + 1
+            s = torch.einsum("hd,hkd->hk", q[g * T + t], kc[g, :, :n].double()) * scale
+            out[g * T + t] = torch.einsum("hk,hkd->hd", torch.softmax(s, -1), vc[g, :, :n].double())
+    return out
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("G,T,H,D,pos", [(3, 1, 4, 128, [0, 17, 130]), (2, 37, 2, 128, [0, 0]), (2, 9, 3, 64, [20, 3]), (1, 70, 2, 104, [5])])
+def test_attention_f32(dev, dt, G, T, H, D, pos):
+    from seedx_amd import ops
+    Tmax = 256
+    g = torch.Generator().manual_seed(5)
+    qkv = (torch.randn(G * T, 3 * H * D, generator=g) * 1.5).to(dev)
+    kc = torch.randn(G, H, Tmax, D, generator=g).to(dev) * 1.5
+    vc = torch.randn(G, H, Tmax, D, generator=g).to(dev)
+    posd = torch.tensor(pos, dtype=torch.int32, device=dev)
+    scale = 1.0 / math.sqrt(D)
+    ref = _attn_ref(qkv.cpu().double()[:, :H * D].reshape(G * T, H, D), kc.cpu(), vc.cpu(), pos, T, scale).reshape(G * T, H * D)
+    y = ops.attention_f32(qkv, kc, vc, posd, G, T, H, D, scale, dt)
+    dense = y[:, :H * D].float() + y[:, H * D:].float()
+    e = relerr(dense, ref)
+    print(f"attention_f32 {dt} G={G} T={T} H={H} D={D}: {e:.2e}")
+    assert e < (2e-6 if dt == torch.float16 else 2e-5)
+    if G * T <= 16 and (H * D) % 32 == 0:
+        yt = ops.attention_f32(qkv, kc, vc, posd, G, T, H, D, scale, dt, tiled=True)
+        assert torch.equal(yt.dense(), dense)
+
+
+# ---- model level ------------------------------------------------------------------------------------------------------
+def _llm(dev, dt, sd, cfg, **kw):
+    from seedx_amd.llama import LlamaForCausalLM
+    llm = LlamaForCausalLM(dict(cfg), max_cache_len=128, **kw)
+    llm.load_state_dict(dict(sd))
+    llm.eval().to(dev, dtype=dt)
+    return llm
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_llm_precise_vs_fp32_oracle_and_paths_agree(dev, dt):
+    """The miniature decoder: (a) precise prefill logits / states within 2e-4 (fp16) of the fp32 oracle evaluated on the weights the 16-bit
+    checkpoint holds — the plain flow's bound is 2e-3; (b) prefill of T tokens == prefill of T - 6 + 6 single-token steps (the skinny-GEMM
+    path) to fp32 accumulation noise; (c) a lock-step batch of 16 equals the single-sequence run bit for bit; (d) the graph-replayed
+    decode step equals the eager one bit for bit; (e) the plain 16-bit flow is still there and inside ITS bound."""
+    cfg = weights.MINI_LLM
+    sd = {k: v.to(dt).float() for k, v in weights.llama_sd(cfg).items()}          # what a 16-bit checkpoint stores
+    x = torch.randn(1, 37, cfg["hidden_size"], generator=torch.Generator().manual_seed(6)) * 0.5
+    logits_ref, _, hn_ref = restated.llama_forward(sd, cfg, x, table_dtype=dt)
+    tol = 2e-4 if dt == torch.float16 else 1.5e-3
+    llm = _llm(dev, dt, sd, cfg)
+    assert llm.precise and llm._pack()["kc"].dtype == torch.float32 and llm._P["precise_tiled"]
+    out = llm(inputs_embeds=x.to(dev), output_hidden_states=True)
+    e_l, e_h = relerr(out["logits"][0], logits_ref[0]), relerr(out["hidden_states"][-1], hn_ref)
+    print(f"precise mini llm {dt}: logits (all positions) {e_l:.2e}, states {e_h:.2e}")
+    assert e_l < tol and e_h < tol
+    # (b) 31-token prefill + 6 cached steps
+    o1 = llm(inputs_embeds=x[:, :31].to(dev), use_cache=True)
+    pkv, last = o1.past_key_values, []
+    for t in range(31, 37):
+        o = llm(inputs_embeds=x[:, t:t + 1].to(dev), past_key_values=pkv, use_cache=True, logits_positions="last")
+        pkv = o.past_key_values
+        last.append(o.logits[0, -1])
+    assert pkv[0][0].dtype == torch.float32 and tuple(pkv[0][0].shape) == (1, cfg["num_attention_heads"], 37, 128)
+    for i, t in enumerate(range(31, 37)):
+        assert relerr(last[i], out["logits"][0, t]) < 2e-5
+        assert relerr(last[i], logits_ref[0, t]) < tol
+    # (c) + (d): lock-step batch of 16, eager and graph-replayed, against the single sequence
+    img_ids = torch.arange(400, 466, dtype=torch.int32, device=dev)
+    runs = {}
+    for name, G, use_graph in (("single", 1, False), ("batch eager", 16, False), ("batch graph", 16, True)):
+        m = llm if G == 1 else _llm(dev, dt, sd, cfg, max_batch=16)
+        assert m.precise
+        m.reset()
+        xs = [x[0, :20 + (0 if G == 1 else (g % 3))].to(dev) for g in range(G)]      # ragged prompts in the batch
+        if G == 1:
+            m.forward_embeds(xs[0], seq=0)
+        else:
+            m.forward_embeds_batch(xs, list(range(G)))
+        m._P["cur"].fill_(7)
+        m._P["step"].fill_(0)
+        out_ids = torch.full((G, 8), -1, dtype=torch.int32, device=dev)
+        hid = torch.zeros((G, 8, cfg["hidden_size"]), device=dev)
+        for _ in range(6):
+            m.decode_step(img_ids, out_ids, hid, use_graph=use_graph)
+        runs[name] = (out_ids.clone(), hid.clone())
+    assert (runs["single"][0][0, :6] >= 0).all()
+    assert torch.equal(runs["batch eager"][0], runs["batch graph"][0]) and torch.equal(runs["batch eager"][1], runs["batch graph"][1])
+    assert torch.equal(runs["batch eager"][0][0], runs["single"][0][0]) and torch.equal(runs["batch eager"][0][3], runs["single"][0][0])
+    assert torch.equal(runs["batch eager"][1][0], runs["single"][1][0])
+    # (e) the plain 16-bit flow
+    plain = _llm(dev, dt, sd, cfg, precise=False)
+    assert not plain.precise and plain._pack()["kc"].dtype == dt
+    o16 = plain(inputs_embeds=x.to(dev))
+    e16 = relerr(o16["logits"][0], logits_ref[0])
+    print(f"plain 16-bit mini llm {dt}: logits {e16:.2e} ({e16 / e_l:.0f}x the precise mode's)")
+    assert e16 < (2e-3 if dt == torch.float16 else 1.6e-2) and e16 > 3 * e_l
+
+
+def test_llm_precise_non_tiled_shapes_take_the_gemm(dev):
+    """Projection shapes outside the skinny GEMM's MFMA path (K < 256) run the decode step on the two-plane GEMM instead — same numbers."""
+    cfg = dict(weights.MINI_LLM, hidden_size=128, num_attention_heads=2, intermediate_size=320)
+    dt = torch.float16
+    sd = {k: v.to(dt).float() for k, v in weights.llama_sd(cfg).items()}
+    x = torch.randn(1, 12, 128, generator=torch.Generator().manual_seed(8)) * 0.5
+    logits_ref, _, _ = restated.llama_forward(sd, cfg, x, table_dtype=dt)
+    llm = _llm(dev, dt, sd, cfg)
+    assert llm.precise and not llm._pack()["precise_tiled"]
+    o1 = llm(inputs_embeds=x[:, :8].to(dev), use_cache=True)
+    pkv = o1.past_key_values
+    for t in range(8, 12):
+        o = llm(inputs_embeds=x[:, t:t + 1].to(dev), past_key_values=pkv, use_cache=True, logits_positions="last")
+        pkv = o.past_key_values
+        assert relerr(o.logits[0, -1], logits_ref[0, t]) < 3e-4
