@@ -820,6 +820,7 @@ def main(argv=None):
     if gpu:
         torch.cuda.set_device(local)
     dev = torch.device("cuda", local) if gpu else torch.device("cpu")
+    seen = du.ranks_seen(ctx, strict_devices=bool(os.environ.get("SX_BENCH_STRICT_DEVICES")))   # every rank, its device: in the JSON line
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float16
     sync = torch.cuda.synchronize if gpu else (lambda: None)
     with torch.no_grad():
@@ -850,7 +851,11 @@ def main(argv=None):
         sync()
         du.barrier(ctx)
         sync()
-        dt = du.max_over_ranks(ctx, time.perf_counter() - t0)
+        dt_local = time.perf_counter() - t0
+        dt = du.max_over_ranks(ctx, dt_local)
+        # per-rank line on stderr (the driver's log shows every rank's own clock next to the max that the JSON line uses)
+        print(f"[bench rank {rank}/{world}] device {seen[rank].get('device')} {seen[rank].get('device_id')}: {a.steps} steps x {a.batch} "
+              f"generations in {dt_local:.3f} s (max over ranks {dt:.3f} s)", file=sys.stderr, flush=True)
         roof = phases = None
         if rank == 0 and gpu and not a.no_roofline:
             try:
@@ -888,6 +893,8 @@ def main(argv=None):
         rec = {"metric": "end-to-end generations/sec (img-in -> txt + 1024px-img-out)" if a.config == 0 else
                "generations/sec of BASELINE config %d" % a.config, "value": total / dt,
                "unit": "gens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+               "ranks_seen": [{k: g.get(k) for k in ("rank", "local_rank", "host", "device", "device_id", "shared_device") if k in g}
+                              for g in seen],
                "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": a.dtype if gpu else "none",
                "data": "synthetic (seeded random uint8 image / prompt ids, random-init weights of the real dims)",
@@ -915,6 +922,19 @@ def main(argv=None):
         if gpu and not a.no_cpu_baseline and world == 1:
             try:
                 rec["cpu_baseline"] = cpu_baseline(a.config, full_config1=(a.cpu_baseline == "full" and a.config == 1))
+                # the un-extrapolated CPU figure (BASELINE config 1 end to end on the host cores) is measured once per
+                # round by `bench.py --config 1 --cpu-baseline full` (≈ 1-2 min of CPU) and quoted here from its committed line
+                f1 = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r5_bench_config1_cpu_full.json")
+                if a.config == 0 and "error" not in rec["cpu_baseline"] and os.path.exists(f1):
+                    c1 = json.load(open(f1))
+                    cb = c1.get("cpu_baseline", {})
+                    if "value" in cb:
+                        rec["cpu_baseline"]["config1_unextrapolated"] = {
+                            "cpu_value": cb["value"], "unit": cb.get("unit"), "cores": cb.get("cores"), "gpu_value": c1.get("value"),
+                            "sample": cb.get("sample"), "file": "profiles/r5_bench_config1_cpu_full.json"}
+                        rec["cpu_baseline"]["sample"] += ("; un-extrapolated companion (BASELINE config 1, ViT-G forward of 2 crops + ONE "
+                                                          "UNet CFG-2 step, %s cores): CPU %.4g vs GPU %.4g gens/s"
+                                                          % (cb.get("cores"), cb["value"], c1.get("value") or float("nan")))
             except Exception as ex:  # the oracle is optional infrastructure; never fail the measurement on it
                 rec["cpu_baseline"] = {"error": repr(ex)}
         print(json.dumps(rec), flush=True)

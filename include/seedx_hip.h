@@ -361,17 +361,21 @@ int sx_rope_kv_append_f32(float* qkv, float* kcache, float* vcache, const float*
                           int table_dtype, void* stream);
 /* Causal attention of a T-token chunk per sequence over the fp32 cache, fp32 FMA arithmetic and softmax
  * (modeling_llama_xformer.py:204-239: prefill causal, q_len == 1 sees the whole cache): row t sees keys 0 .. pos0[g] + t.
- * Device-resident positions → graph-capturable for the decode step (T = 1). Output = the planes of the context rows [G*T][H*D]. */
+ * Device-resident positions → graph-capturable for the decode step (T = 1). Output = the planes of the context rows [G*T][H*D].
+ * causal = 0: every row sees all Tmax keys (pos0_dev unused) — with the K / V strides below this is also the small fp32 attention of
+ * ResamplerXLV2's precise mode (PerceiverAttention / AttentionPool2d, resampler.py:42-87,89-116: fp32 softmax over <= 129 keys). */
 typedef struct sx_attn_f32_args {
   const float* q;           /* rotated q: row g*T + t at q + row*q_row_stride, head h at + h*D (e.g. the qkv buffer, stride 3*H*D) */
   const float* kcache;      /* fp32 [G][H][Tmax][D], sequences cache_seq_stride floats apart                                       */
   const float* vcache;
   void* out;                /* planes of [G*T][H*D], layout by dtype (see above)                                                    */
-  const int32_t* pos0_dev;  /* [G] cache position of each sequence's first chunk token                                             */
+  const int32_t* pos0_dev;  /* [G] cache position of each sequence's first chunk token (causal)                                    */
   int64_t q_row_stride, cache_seq_stride;
+  int64_t kv_row_stride;    /* floats between consecutive keys of a head (0 = D)                                                   */
+  int64_t kv_head_stride;   /* floats between heads (0 = Tmax*D: the cache layout)                                                  */
   int32_t G, T, H, D, Tmax, dtype;
   float scale;
-  int32_t reserved;
+  int32_t causal;           /* 1: row t sees keys 0 .. pos0[g] + t; 0: all Tmax keys                                               */
 } sx_attn_f32_args;
 int sx_attention_f32(const sx_attn_f32_args* args, void* stream);
 /* strided 2-D copy of fp32 rows: dst[r][dst_off + c] = src[r][c]  (channel concat of skip connections) */

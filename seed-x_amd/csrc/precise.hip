@@ -140,9 +140,9 @@ struct AttnF32P {
   const float* kc;
   const float* vc;
   unsigned short* out;
-  const int* pos0_dev;     // [G] cache position of the chunk's first token
-  long long q_stride, seq_stride;
-  int T, H, D, Tmax, tiled;
+  const int* pos0_dev;     // [G] cache position of the chunk's first token (causal only)
+  long long q_stride, seq_stride, row_stride, head_stride;   // K / V element strides: sequence, key row, head
+  int T, H, D, Tmax, tiled, causal;
   float scale;
 };
 
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const AttnF32P p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int grp = wave * 4 + (lane >> 4), dl = lane & 15;
   const bool dvalid = dl * 8 < D;
-  int pos0 = p.pos0_dev[g];
+  int pos0 = p.causal ? p.pos0_dev[g] : p.Tmax;   // not causal: every row sees all Tmax keys
   if (pos0 < 0) pos0 = 0;
   const int nq = min(QB, p.T - q0);
   float qv[QB][8], o[QB][8], m_run[QB], l_run[QB];
@@ -170,16 +170,16 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const AttnF32P p) {
       for (int e = 0; e < 4; ++e) { qv[i][e] = a[e] * p.scale; qv[i][4 + e] = b[e] * p.scale; }
     }
   }
-  const float* kh = p.kc + (size_t)g * p.seq_stride + (size_t)h * p.Tmax * D;
-  const float* vh = p.vc + (size_t)g * p.seq_stride + (size_t)h * p.Tmax * D;
+  const float* kh = p.kc + (size_t)g * p.seq_stride + (size_t)h * p.head_stride;
+  const float* vh = p.vc + (size_t)g * p.seq_stride + (size_t)h * p.head_stride;
   const int kend = min(p.Tmax, pos0 + q0 + nq);       // keys 0 .. kend-1 are visible to the block's last row
   for (int t = grp; t < kend; t += 16) {
     float kf[8], vf[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { kf[e] = 0.f; vf[e] = 0.f; }
     if (dvalid) {
-      const float* kr = kh + (size_t)t * D + dl * 8;
-      const float* vr = vh + (size_t)t * D + dl * 8;
+      const float* kr = kh + (size_t)t * p.row_stride + dl * 8;
+      const float* vr = vh + (size_t)t * p.row_stride + dl * 8;
       const f32x4_t k0 = *(const f32x4_t*)kr, k1 = *(const f32x4_t*)(kr + 4);
       const f32x4_t v0 = *(const f32x4_t*)vr, v1 = *(const f32x4_t*)(vr + 4);
 #pragma unroll
@@ -308,7 +308,7 @@ extern "C" int sx_rope_kv_append_f32(float* qkv, float* kcache, float* vcache, c
 }
 
 extern "C" int sx_attention_f32(const sx_attn_f32_args* a, void* stream) {
-  SX_CHECK(a && a->q && a->kcache && a->vcache && a->out && a->pos0_dev, "sx_attention_f32: null pointer");
+  SX_CHECK(a && a->q && a->kcache && a->vcache && a->out && (a->pos0_dev || !a->causal), "sx_attention_f32: null pointer");
   const int tiled = (a->dtype & SX_TILED16) ? 1 : 0, dt = a->dtype & 0xff;
   SX_CHECK(dt == SX_F16 || dt == SX_BF16, "sx_attention_f32: dtype (of the output planes)");
   SX_CHECK(a->D % 8 == 0 && a->D >= 8 && a->D <= 128, "sx_attention_f32: head_dim %d", a->D);
@@ -318,7 +318,11 @@ extern "C" int sx_attention_f32(const sx_attn_f32_args* a, void* stream) {
   AttnF32P p;
   p.q = a->q; p.kc = a->kcache; p.vc = a->vcache; p.out = (unsigned short*)a->out; p.pos0_dev = a->pos0_dev;
   p.q_stride = a->q_row_stride; p.seq_stride = a->cache_seq_stride;
-  p.T = a->T; p.H = a->H; p.D = a->D; p.Tmax = a->Tmax; p.tiled = tiled; p.scale = a->scale;
+  p.row_stride = a->kv_row_stride > 0 ? a->kv_row_stride : a->D;
+  p.head_stride = a->kv_head_stride > 0 ? a->kv_head_stride : (int64_t)a->Tmax * a->D;
+  SX_CHECK(p.row_stride % 4 == 0 && p.head_stride % 4 == 0 && p.seq_stride % 4 == 0 && (((uintptr_t)a->kcache) & 15) == 0 &&
+           (((uintptr_t)a->vcache) & 15) == 0, "sx_attention_f32: K / V strides and pointers must keep 16-B alignment");
+  p.T = a->T; p.H = a->H; p.D = a->D; p.Tmax = a->Tmax; p.tiled = tiled; p.scale = a->scale; p.causal = a->causal ? 1 : 0;
   const dim3 grid((a->T + QB - 1) / QB, a->H, a->G);
   if (dt == SX_BF16) hipLaunchKernelGGL(attn_f32_kernel<BF16>, grid, dim3(256), 0, ST, p);
   else hipLaunchKernelGGL(attn_f32_kernel<F16>, grid, dim3(256), 0, ST, p);

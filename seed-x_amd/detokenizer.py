@@ -18,6 +18,7 @@ device-resident (step counter, sigma table and timestep table live in HBM) and c
 replayed ``num_inference_steps`` times.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -36,6 +37,11 @@ class ResamplerXLV2:
         self.in_dim, self.out_dim = dim, output1_dim + output2_dim
         self.device, self.dtype = None, torch.float16
         self._sd, self._P = None, None
+        # fp32-grade activations (default): its two outputs condition every UNet step through classifier-free guidance, which multiplies
+        # the difference of two conditionings by 7.5 — at one 16-bit rounding per operand (9e-4 / 1.2e-3 on prompt / pooled embeds) the
+        # 5-step latents of a full-size generation sat at 1.6e-3 of the fp32 chain on the SAME image features. Operand planes
+        # x = hi + lo into sx_gemm a_planes = 2, fp32 q / k / v and attention (csrc/precise.hip); 9 GFLOP per sample, < 0.1 ms more.
+        self.precise = os.environ.get("SX_XLV2_PRECISE", "1") != "0"
 
     def load_state_dict(self, sd, prefix="", strict=True):
         need = ["latents", "proj_in.weight", "norm_out.weight", "unet_proj_1.weight", "unet_attnpool.c_proj.weight"]
@@ -93,6 +99,8 @@ class ResamplerXLV2:
         P, dt, dim, heads, hd = self._pack(), self.dtype, self.dim, self.heads, self.dim_head
         B, n, _ = x.shape
         nq, inner = self.num_queries, self.heads * self.dim_head
+        if self.precise:
+            return self._forward_precise(x)
         x16 = x.to(self.device)
         if self.normalize:
             from .image_ops import l2norm_dim1
@@ -129,6 +137,48 @@ class ResamplerXLV2:
         qp = ops.gemm(t16[:, 0].contiguous(), P["pool_q"][0], bias=P["pool_q"][1]).view(B, 1, heads, dim // heads)
         o = ops.attention_small(qp, kvp[:, :, 0], kvp[:, :, 1], 1.0 / math.sqrt(dim // heads))
         pooled = ops.gemm(o.view(B, dim), P["pool_c"][0], bias=P["pool_c"][1], out_dtype=torch.float32)
+        return prompt, pooled
+
+    def _forward_precise(self, x):
+        """forward() with fp32-grade activations: LayerNorms emit fp32, every GEMM reads its A operand as two 16-bit planes
+        (ops.split16 → sx_gemm a_planes = 2, fp32 out), both attentions are fp32 (sx_attention_f32, causal = 0)."""
+        P, dt, dim, heads, hd = self._pack(), self.dtype, self.dim, self.heads, self.dim_head
+        B, n, _ = x.shape
+        nq, inner, f32 = self.num_queries, self.heads * self.dim_head, torch.float32
+        xf = x.to(self.device, f32)
+        if self.normalize:
+            from .image_ops import l2norm_dim1
+            xf = l2norm_dim1(xf)
+        lin = lambda a32, w, **kw: ops.gemm(ops.split16(a32, dt), w, a_planes=2, out_dtype=f32, **kw)
+        xs = lin(xf.contiguous().view(B * n, -1), P["pin"][0], bias=P["pin"][1])                             # proj_in
+        lat = P["latents"].unsqueeze(0).expand(B, nq, dim).contiguous().view(B * nq, dim)
+        scale = 1.0 / math.sqrt(hd)
+        for lw in P["layers"]:
+            xn = ops.layernorm(xs, lw["n1"][0], lw["n1"][1], 1e-5, f32)
+            ln = ops.layernorm(lat, lw["n2"][0], lw["n2"][1], 1e-5, f32)
+            q = lin(ln, lw["wq"]).view(B, nq, heads, hd)
+            kv = torch.empty((B, n + nq, 2 * inner), dtype=f32, device=self.device)                           # cat(x, latents)
+            xn2, ln2 = ops.split16(xn, dt), ops.split16(ln, dt)
+            for b in range(B):
+                ops.gemm(xn2[b * n:(b + 1) * n], lw["wkv"], a_planes=2, out=kv[b, :n], out_dtype=f32)
+                ops.gemm(ln2[b * nq:(b + 1) * nq], lw["wkv"], a_planes=2, out=kv[b, n:], out_dtype=f32)
+            kv5 = kv.view(B, n + nq, 2, heads, hd)
+            att = ops.attention_f32_full(q, kv5[:, :, 0], kv5[:, :, 1], scale, dt)                            # planes [B*nq, 2*inner]
+            lat = ops.gemm(att, lw["wo"], a_planes=2, residual=lat, out_dtype=f32)
+            h = lin(ops.layernorm(lat, lw["fn"][0], lw["fn"][1], 1e-5, f32), lw["w1"], act="gelu")
+            lat = lin(h, lw["w3"], residual=lat)
+        hid = ops.layernorm(lat, P["nout"][0], P["nout"][1], 1e-5, f32)                                       # norm_out
+        prompt = lin(hid, P["proj"][0], bias=P["proj"][1]).view(B, nq, -1)
+        mean = ops.avgpool_tokens(hid.view(B, nq, dim), nq)                                                   # AttentionPool2d
+        t = torch.empty((B, nq + 1, dim), dtype=f32, device=self.device)
+        t[:, 0:1] = mean
+        t[:, 1:] = hid.view(B, nq, dim)
+        t = ops.add(t, P["pool_pos"].unsqueeze(0).expand(B, nq + 1, dim).contiguous())
+        hp = dim // heads
+        kvp = lin(t.view(B * (nq + 1), dim), P["pool_kv"][0], bias=P["pool_kv"][1]).view(B, nq + 1, 2, heads, hp)
+        qp = lin(t[:, 0].contiguous(), P["pool_q"][0], bias=P["pool_q"][1]).view(B, 1, heads, hp)
+        o = ops.attention_f32_full(qp, kvp[:, :, 0], kvp[:, :, 1], 1.0 / math.sqrt(hp), dt)                   # planes [B, 2*dim]
+        pooled = ops.gemm(o, P["pool_c"][0], a_planes=2, bias=P["pool_c"][1], out_dtype=f32)
         return prompt, pooled
 
     __call__ = forward

@@ -204,7 +204,9 @@ class LlamaForCausalLM:
         bal20 = self.G >= 5 and os.environ.get("SX_GEMV_BAL20", "1") != "0"
         # the consumer adds the producer's per-workgroup sums of squares 64 at a time: the o / down launches (N = H) must have a
         # multiple of 64 workgroups (H = 5120: 256 with 20-row tiles, 320 without)
-        parts = self.H // 20 if (bal20 and self.H % 20 == 0 and self.H // 20 == 256) else (self.H // 32 if self.H // 32 >= 256 else self.H // 16)
+        # (asked from the library, not re-derived here: sx_gemv's own workgroup count for an N = H launch in that weight layout)
+        from . import _lib
+        parts = _lib.load().sx_gemv_ssq_parts(self.H, 0, 2 if (bal20 and self.H % 20 == 0 and self.H // 20 == 256) else 1)
         fold = self.G >= 5 and tp == 1 and parts % 64 == 0 and os.environ.get("SX_RMS_FOLD", "1") != "0" \
             and not self.precise      # (SX_RMS_FOLD=0: A/B switch, tools/; the precise mode norms in fp32 with its own kernel)
         for i in range(self.L):
@@ -503,6 +505,10 @@ class LlamaForCausalLM:
         prepare_inputs_for_generation :759-765 produces for an all-ones mask). Training inputs (``labels``) are out of scope."""
         if labels is not None:
             raise NotImplementedError("LlamaForCausalLM.forward: the loss path (labels) is training-side and not built")
+        if attention_mask is not None and not bool(torch.as_tensor(attention_mask).to(torch.bool).all()):
+            import warnings       # the reference does the same silently (:236 only asks whether the mask is all zero); say it once
+            warnings.warn("LlamaForCausalLM.forward: attention_mask has zeros (padding) — like the reference's xformers path "
+                          "(modeling_llama_xformer.py:232-237) padding is NOT masked: every position attends causally", stacklevel=2)
         if output_attentions:
             raise NotImplementedError("LlamaForCausalLM.forward: attention probabilities are never materialised (flash attention)")
         P = self._pack()

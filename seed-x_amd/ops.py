@@ -519,7 +519,24 @@ def attention_f32(qkv, kcache, vcache, pos_dev, G, T, H, D, scale, dtype, tiled=
     a = _lib.AttnF32Args()
     a.q, a.kcache, a.vcache, a.out, a.pos0_dev = _p(qkv), _p(kcache), _p(vcache), _p(buf), _p(pos_dev)
     a.q_row_stride, a.cache_seq_stride = qkv.stride(0), kcache.stride(0)
-    a.G, a.T, a.H, a.D, a.Tmax, a.dtype, a.scale = G, T, H, D, kcache.shape[2], code, float(scale)
+    a.G, a.T, a.H, a.D, a.Tmax, a.dtype, a.scale, a.causal = G, T, H, D, kcache.shape[2], code, float(scale), 1
+    check(_lib.load().sx_attention_f32(C.byref(a), _stream()), "sx_attention_f32")
+    return ret
+
+
+def attention_f32_full(q, k, v, scale, dtype):
+    """Non-causal fp32 attention (fp32 FMA arithmetic and softmax): q [B, Sq, H, D], k / v [B, Skv, H, D] fp32 views with unit D stride
+    (e.g. slices of one fused projection output). Returns the planes of the context [B*Sq, H*D] (split16's row layout)."""
+    B, Sq, H, D = q.shape
+    Skv = k.shape[1]
+    assert q.dtype == k.dtype == v.dtype == torch.float32 and k.shape == (B, Skv, H, D) and v.shape == k.shape
+    assert q.stride(3) == 1 and q.stride(2) == D and q.stride(0) == Sq * q.stride(1), "q rows must be [B*Sq] rows of H*D heads"
+    assert k.stride(3) == 1 and v.stride() == k.stride()
+    ret, buf, code = _planes_out(B * Sq, H * D, dtype, q.device, False)
+    a = _lib.AttnF32Args()
+    a.q, a.kcache, a.vcache, a.out, a.pos0_dev = _p(q), _p(k), _p(v), _p(buf), None
+    a.q_row_stride, a.cache_seq_stride, a.kv_row_stride, a.kv_head_stride = q.stride(1), k.stride(0), k.stride(1), k.stride(2)
+    a.G, a.T, a.H, a.D, a.Tmax, a.dtype, a.scale, a.causal = B, Sq, H, D, Skv, code, float(scale), 0
     check(_lib.load().sx_attention_f32(C.byref(a), _stream()), "sx_attention_f32")
     return ret
 

@@ -124,7 +124,8 @@ class IpcComm(Comm):
 
     CHUNK = 4096                               # floats per workgroup (SX_ONESHOT_CHUNK in include/seedx_hip.h)
 
-    def __init__(self, bootstrap=None, cap_floats=131072, device=None, max_spin=0, graph_safe=True, neighbor_only=False):
+    def __init__(self, bootstrap=None, cap_floats=131072, device=None, max_spin=0, graph_safe=True, neighbor_only=False,
+                 self_test=True):
         import ctypes as C
         import torch.distributed as dist
         from . import _lib
@@ -173,6 +174,67 @@ class IpcComm(Comm):
             self._status = torch.zeros(1, dtype=torch.int32, device=self.device)
             torch.cuda.synchronize()
         dist.barrier(group=bootstrap)          # every rank has opened every handle before the first collective
+        # First contact with the peers' memory (other GPUs over xGMI, or other processes on this GPU): prove the protocol before any
+        # model uses it. A failure here (peer stores not visible, a flag that never arrives, wrong sums) must not become wrong tokens or
+        # a 16-s spin inside generate(): the communicator then routes EVERY collective to the bootstrap group (RCCL / gloo) and says so.
+        self.fallback_reason = None
+        if self_test:
+            self._self_test()
+
+    SELF_TEST_SPIN = 1 << 22      # bounded poll of the self-test's launches (~ a few seconds at worst, then a status word, not a hang)
+
+    def _self_test(self):
+        import warnings
+        ok, why = True, ""
+        spin, self.max_spin = self.max_spin, self.SELF_TEST_SPIN
+        try:
+            with torch.cuda.device(self.device):
+                n = min(self.cap, 3 * self.CHUNK + 17 * 4)               # several chunks + a ragged tail
+                idx = torch.arange(n, device=self.device, dtype=torch.float32)
+                if self.neighbor_only:
+                    for ep in range(4):                                   # both staging slots, twice
+                        send = torch.stack([idx[:2048] + 1000.0 * self.rank + ep, -(idx[:2048] + 1000.0 * self.rank + ep)])   # [first | last]
+                        got = self.halo_exchange(send)
+                        exp0 = -(idx[:2048] + 1000.0 * (self.rank - 1) + ep) if self.rank > 0 else None
+                        exp1 = idx[:2048] + 1000.0 * (self.rank + 1) + ep if self.rank < self.world - 1 else None
+                        torch.cuda.synchronize()
+                        if int(self._status.item()):
+                            ok, why = False, f"halo epoch {ep}: a neighbour's flag never arrived"
+                            break
+                        if (exp0 is not None and not torch.equal(got[0], exp0)) or (exp1 is not None and not torch.equal(got[1], exp1)):
+                            ok, why = False, f"halo epoch {ep}: neighbour rows arrived with wrong contents"
+                            break
+                else:
+                    for ep in range(4):
+                        t = (idx % 7 + 1.0) * (self.rank + 1) + ep       # small integers: the rank-ordered fp32 sum is exact
+                        self._launch(t)
+                        exp = (idx % 7 + 1.0) * (self.world * (self.world + 1) // 2) + ep * self.world
+                        torch.cuda.synchronize()
+                        if int(self._status.item()):
+                            ok, why = False, f"all-reduce epoch {ep}: a peer's flag never arrived within {self.SELF_TEST_SPIN} polls"
+                            break
+                        if not torch.equal(t, exp):
+                            ok, why = False, f"all-reduce epoch {ep}: wrong sum (max abs deviation {float((t - exp).abs().max()):.3g})"
+                            break
+                    if ok:
+                        mine = idx[:1024] + 4096.0 * self.rank
+                        out = torch.empty((self.world, 1024), dtype=torch.float32, device=self.device)
+                        self._launch(mine.contiguous(), gather_out=out)
+                        torch.cuda.synchronize()
+                        exp = idx[:1024][None, :] + 4096.0 * torch.arange(self.world, device=self.device, dtype=torch.float32)[:, None]
+                        if int(self._status.item()) or not torch.equal(out, exp):
+                            ok, why = False, "all-gather: wrong contents or a missing peer"
+        except RuntimeError as e:            # a launch error is a failed self-test too
+            ok, why = False, f"launch failed: {e}"
+        self.max_spin = spin
+        verdicts = [None] * self.world
+        self._dist.all_gather_object(verdicts, (bool(ok), why), group=self.group)
+        bad = [(r, w) for r, (o, w) in enumerate(verdicts) if not o]
+        if bad:
+            self.fallback_reason = "; ".join(f"rank {r}: {w}" for r, w in bad)
+            self.graph_safe = False
+            warnings.warn(f"IpcComm rank {self.rank}: the one-shot IPC collectives failed their start-up self-test ({self.fallback_reason}); "
+                          f"every collective of this communicator now runs on the bootstrap process group instead (not graph-capturable)")
 
     def halo_exchange(self, edges):
         """Neighbour-only exchange over the peer-mapped staging buffers: ONE launch, 2 x row bytes in and out, no all-gather of
@@ -180,15 +242,19 @@ class IpcComm(Comm):
         if not self.neighbor_only:
             if self._halo is None:                       # collective: every rank reaches its first halo exchange together
                 self._halo = IpcComm(self.group, cap_floats=self.cap, device=self.device, max_spin=self.max_spin,
-                                     graph_safe=self.graph_safe, neighbor_only=True)
+                                     graph_safe=self.graph_safe, neighbor_only=True, self_test=self.fallback_reason is None)
+                if self.fallback_reason is not None:
+                    self._halo.fallback_reason = self.fallback_reason
             return self._halo.halo_exchange(edges)
         e = edges.contiguous()
         assert e.shape[0] == 2 and e.is_cuda
         send = torch.stack([e[1], e[0]], dim=0).contiguous()                    # [my last row | my first row]
         nbytes = send.numel() * send.element_size()
-        if nbytes % 16 or nbytes // 4 > self.cap or (send.storage_offset() * send.element_size()) % 8:
+        if self.fallback_reason is not None or nbytes % 16 or nbytes // 4 > self.cap or (send.storage_offset() * send.element_size()) % 8:
             return self._halo_fallback(edges)
-        out = torch.empty_like(send)
+        # zeros, not empty: a timed-out exchange returns before writing the neighbour rows (sticky status, check()); the row-sharded
+        # UNet must then see zero padding rows, not uninitialised memory, until its per-forward check() raises
+        out = torch.zeros_like(send)
         self._launch(send.view(-1).view(torch.float32), gather_out=out.view(-1).view(torch.float32), mode=1)
         return out
 
@@ -216,9 +282,11 @@ class IpcComm(Comm):
         _lib.check(self._lib.sx_allreduce_oneshot(C.byref(a), torch.cuda.current_stream().cuda_stream), "sx_allreduce_oneshot")
 
     def _fits(self, t):
-        return t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and 0 < t.numel() <= self.cap
+        return self.fallback_reason is None and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and 0 < t.numel() <= self.cap
 
     def require_capacity(self, n_floats):
+        if self.fallback_reason is not None:
+            return                              # nothing is captured any more: graph_safe is False
         if self.graph_safe and n_floats > self.cap:
             raise RuntimeError(f"IpcComm: a captured collective of {n_floats} floats does not fit the staging capacity {self.cap}; "
                                f"construct it with cap_floats >= {n_floats}")
@@ -244,7 +312,7 @@ class IpcComm(Comm):
         nbytes = t.numel() * t.element_size()
         if self._fits(t):
             self._launch(t, gather_out=out)
-        elif t.is_cuda and t.dtype != torch.float32 and nbytes % 4 == 0 and 0 < nbytes // 4 <= self.cap:
+        elif self.fallback_reason is None and t.is_cuda and t.dtype != torch.float32 and nbytes % 4 == 0 and 0 < nbytes // 4 <= self.cap:
             # a gather moves bits, it does no arithmetic: any dtype travels as 32-bit words (the row-sharded UNet's 16-bit conv
             # halo rows, int32 ids, ...) through the same one-shot kernel
             if (t.storage_offset() * t.element_size()) % 4:
@@ -262,10 +330,12 @@ class IpcComm(Comm):
         computed since is wrong. The status word is sticky (first failed epoch) and the communicator stays failed — the
         slot-reuse argument of csrc/comm.hip no longer holds after a missed epoch. One 4-byte read-back; the generate loop
         calls it next to its per-token read-back."""
-        st = int(self._status.item())
+        st = int(self._status.item()) if self.fallback_reason is None else 0     # (after a failed self-test the kernel is never used again)
         if st:
             raise RuntimeError(f"IpcComm rank {self.rank}: a peer did not arrive in epoch {st} (bounded poll expired); "
                                f"results since then are invalid and this communicator must be rebuilt")
+        if self._halo is not None:            # the neighbour-only child communicator of halo_exchange() has a status word of its own
+            self._halo.check()
 
     def barrier(self):
         self._dist.barrier(group=self.group)

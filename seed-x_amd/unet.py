@@ -503,6 +503,10 @@ class UNet2DConditionModel:
         out = out.view(B, -1, out.shape[-1])
         if tp > 1:
             out = seqpar.gather_rows(out, self.comm)
+            # a halo exchange / collective that timed out returned WITHOUT its payload (IpcComm's sticky status, also of the
+            # neighbour-only child communicator): one 4-byte read-back per forward turns that into an error instead of a wrong image
+            if not torch.cuda.is_current_stream_capturing():
+                self.comm.check()
         return out
 
     # ---- diffusers-compatible call ---------------------------------------------------------------------------------------

@@ -10,11 +10,11 @@ from tests.test_models_gpu import StubTokenizer, relerr
 pytestmark = pytest.mark.gpu
 
 
-def _agent(dev, dtype, sd_llm, sd_agent, cfg, vit_dim, G):
+def _agent(dev, dtype, sd_llm, sd_agent, cfg, vit_dim, G, precise=None):
     from seedx_amd.llama import LlamaForCausalLM
     from seedx_amd.seed_x import ContinuousLVLM
     from seedx_amd.visual_encoder import Resampler
-    llm = LlamaForCausalLM(dict(cfg), max_cache_len=512, max_batch=G)
+    llm = LlamaForCausalLM(dict(cfg), max_cache_len=512, max_batch=G, precise=precise)
     llm.load_state_dict(dict(sd_llm))
     H = cfg["hidden_size"]
     agent = ContinuousLVLM(llm, Resampler(4, H, 2, kv_dim=vit_dim), Resampler(4, vit_dim, 2, kv_dim=H), add_patch_pos=True)
@@ -74,9 +74,9 @@ def test_generate_batch_above_16_sequences(dev, dtype):
     tok = StubTokenizer()
     kw = dict(num_img_gen_tokens=16, max_new_tokens=26, eos_token_id=None, force_image_at=3)
     agent = _agent(dev, dtype, sd_llm, sd_agent, cfg, vit_dim, 20)
-    assert agent.llm._pack()["decode_tiled"]
+    assert agent.llm._pack()["decode_tiled"] and not agent.llm.precise       # above 16 sequences: the plain 16-bit flow
     batch = agent.generate_batch(tok, reqs, **kw)
-    single = _agent(dev, dtype, sd_llm, sd_agent, cfg, vit_dim, 1)
+    single = _agent(dev, dtype, sd_llm, sd_agent, cfg, vit_dim, 1, precise=False)   # like with like (the precise default differs by the 16-bit noise)
     tol = 3e-3 if dtype == torch.float16 else 2.4e-2
     same = 0
     for r in (0, 7, 15, 16, 19):                       # rows of both operand blocks

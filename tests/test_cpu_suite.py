@@ -380,9 +380,32 @@ def test_bench_gpus2_launches_two_ranks_itself():
     rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["scaling"] == "weak" and rec["generations_per_step"] == 4
     assert abs(rec["value"] - 2 * 3 * 4 / (rec["ms_per_step"] * 3 / 1e3)) < 1e-6 * rec["value"]
+    assert [g["rank"] for g in rec["ranks_seen"]] == [0, 1] and len({g["device_id"] for g in rec["ranks_seen"]}) == 2
+    assert out.stderr.count("[bench rank ") == 2
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--stub"],
                          capture_output=True, text=True, timeout=120, env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
     assert bad.returncode != 0 and "rank(s) came up" in (bad.stderr + bad.stdout)
+
+
+def test_bench_gpus8_launch_path_and_ranks_seen():
+    """The driver's N = 8 invocation without 8 GPUs: eight gloo ranks of the stub workload started by bench.py
+    itself — rank start-up, request sharding, the barrier / max-over-ranks clock and a JSON line that names all eight ranks."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1",
+                          "--backend", "gloo", "--stub", "--batch", "16"], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["n_gpus"] == 8 and rec["scaling"] == "weak" and rec["generations_per_step"] == 16
+    assert abs(rec["value"] - 8 * 2 * 16 / (rec["ms_per_step"] * 2 / 1e3)) < 1e-6 * rec["value"]
+    assert sorted(g["rank"] for g in rec["ranks_seen"]) == list(range(8)) and len({g["device_id"] for g in rec["ranks_seen"]}) == 8
+    assert out.stderr.count("[bench rank ") == 8
+
+
+def test_ranks_seen_flags_shared_devices():
+    from seedx_amd import dist_utils as du
+    ctx = du.Ctx(0, 1, 0, "gloo")
+    assert du.ranks_seen(ctx)[0]["rank"] == 0
 
 
 # ---- tensor-parallel host logic (parallel.py) ------------------------------------------------------------------------

@@ -1,0 +1,80 @@
+"""The plain 16-bit flow of the Llama decoder (LlamaForCausalLM(precise=False): one 16-bit rounding per MFMA operand — what lock-step
+batches above 16 sequences run, e.g. BASELINE config 2 at 32) at MODEL level with the RMSNorm fold ON (the fold rewrites
+wgu_t / wqkv_t with gamma folded in, with a layer-0 and a last-layer exception, and was only covered at kernel level): geometries whose
+o / down launches have a multiple of 64 workgroups (H = 1024: 64 16-row groups; H = 5120: 256 20-row groups), max_batch >= 5, gamma far
+from 1, both dtypes; decode-step hidden states and ids against SX_RMS_FOLD=0 and against the fp32 oracle.
+Reference: modeling_llama_xformer.py:283-303 (decoder layer), :95 (RMSNorm)."""
+import pytest
+import torch
+
+from oracle import restated, weights
+
+pytestmark = pytest.mark.gpu
+TOL = {torch.float16: 3e-3, torch.bfloat16: 2.4e-2}
+
+
+def relerr(x, ref):
+    x, ref = x.double().cpu(), ref.double().cpu()
+    return ((x - ref).norm() / ref.norm()).item()
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("H,nh,I,L", [(1024, 8, 2816, 3), (5120, 40, 13824, 2)])
+def test_rmsnorm_fold_model_level(dev, dt, H, nh, I, L, monkeypatch):
+    from seedx_amd.llama import LlamaForCausalLM
+    cfg = dict(hidden_size=H, intermediate_size=I, num_hidden_layers=L, num_attention_heads=nh, vocab_size=500, rms_norm_eps=1e-5,
+               max_position_embeddings=128)
+    g = torch.Generator().manual_seed(11)
+    sd = weights.llama_sd(cfg)
+    for k in sd:
+        if "layernorm" in k or k == "model.norm.weight":
+            sd[k] = (1.0 + 0.5 * torch.randn(sd[k].shape, generator=g)).abs().clamp_min(0.2)     # gamma far from 1: a swapped ln1 / ln2 shows
+    sd = {k: v.to(dt).float() for k, v in sd.items()}
+    G, T0, STEPS = 8, 10, 4
+    xs = [torch.randn(T0, H, generator=g) * 0.5 for _ in range(G)]
+    cur0 = torch.arange(20, 20 + G, dtype=torch.int32)
+    img_ids = torch.arange(400, 466, dtype=torch.int32, device=dev)
+    runs = {}
+    for fold in ("1", "0"):
+        monkeypatch.setenv("SX_RMS_FOLD", fold)
+        llm = LlamaForCausalLM(dict(cfg), max_cache_len=64, max_batch=G, precise=False)
+        llm.load_state_dict(dict(sd))
+        llm.eval().to(dev, dtype=dt)
+        P = llm._pack()
+        assert bool(P["rms_fold"]) == (fold == "1") and P["decode_tiled"], (fold, P["rms_fold"])
+        if H == 5120:
+            assert P["layers"][0]["wo_t20"] is not None                  # the 20-row tiles feed the fold's 256 partial sums
+        llm.forward_embeds_batch([x.to(dev) for x in xs], list(range(G)))
+        P["cur"].copy_(cur0.to(dev))
+        P["step"].zero_()
+        out_ids = torch.full((G, STEPS), -1, dtype=torch.int32, device=dev)
+        hid = torch.zeros((G, STEPS, H), device=dev)
+        for _ in range(STEPS):
+            llm.decode_step(img_ids, out_ids, hid, use_graph=False)
+        runs[fold] = (out_ids.cpu(), hid.cpu())
+        del llm
+        torch.cuda.empty_cache()
+    ids_f, hid_f = runs["1"]
+    ids_u, hid_u = runs["0"]
+    num = den = 0.0                                  # hidden state k of a sequence compares while the tokens fed so far are the same
+    for s in range(G):
+        for k in range(STEPS):
+            if torch.equal(ids_f[s, :k], ids_u[s, :k]):
+                num += float((hid_f[s, k].double() - hid_u[s, k].double()).pow(2).sum())
+                den += float(hid_u[s, k].double().pow(2).sum())
+    e_fu = (num / den) ** 0.5
+    agree = float((ids_f == ids_u).float().mean())
+    # the fp32 oracle, teacher-forced on the folded run's tokens, for three of the sequences
+    emb = sd["model.embed_tokens.weight"]
+    worst_f = worst_u = 0.0
+    for s in (0, 3, 7):
+        fed = [int(cur0[s])] + [int(t) for t in ids_f[s, :STEPS - 1]]
+        x = torch.cat([xs[s], emb[torch.tensor(fed)]], dim=0).unsqueeze(0)
+        _, _, hn = restated.llama_forward(sd, cfg, x, table_dtype=dt)
+        worst_f = max(worst_f, relerr(hid_f[s], hn[0, T0:]))
+        if torch.equal(ids_f[s], ids_u[s]):
+            worst_u = max(worst_u, relerr(hid_u[s], hn[0, T0:]))
+    print(f"RMSNorm fold at model level, H={H} {dt}: folded vs oracle {worst_f:.2e}, unfolded vs oracle {worst_u:.2e}, folded vs unfolded "
+          f"{e_fu:.2e}, ids equal {agree:.0%}")
+    assert worst_f < TOL[dt] and worst_u < TOL[dt]
+    assert e_fu < 1.5 * TOL[dt] and agree >= 0.85

@@ -199,6 +199,45 @@ def test_attention_f32(dev, dt, G, T, H, D, pos):
         assert torch.equal(yt.dense(), dense)
 
 
+@pytest.mark.parametrize("dt", DTS)
+def test_attention_f32_full_strided_kv(dev, dt):
+    """Non-causal mode with K / V as strided views of one fused projection output (ResamplerXLV2's PerceiverAttention / AttentionPool2d)."""
+    from seedx_amd import ops
+    g = torch.Generator().manual_seed(9)
+    for (B, Sq, Skv, H, D) in [(2, 16, 52, 2, 64), (3, 1, 17, 4, 64), (2, 64, 128, 16, 64)]:
+        q = torch.randn(B, Sq, H, D, generator=g).to(dev)
+        kv = torch.randn(B, Skv, 2, H, D, generator=g).to(dev)
+        y = ops.attention_f32_full(q, kv[:, :, 0], kv[:, :, 1], 0.125, dt)
+        s = torch.einsum("bqhd,bkhd->bhqk", q.double().cpu(), kv[:, :, 0].double().cpu()) * 0.125
+        ref = torch.einsum("bhqk,bkhd->bqhd", torch.softmax(s, -1), kv[:, :, 1].double().cpu()).reshape(B * Sq, H * D)
+        e = relerr(y[:, :H * D].float() + y[:, H * D:].float(), ref)
+        assert e < (2e-6 if dt == torch.float16 else 2e-5), (B, Sq, Skv, H, D, e)
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_resampler_xlv2_precise_vs_oracle(dev, dt, monkeypatch):
+    """ResamplerXLV2 with fp32-grade activations (the default): prompt / pooled embeds within 1e-4 (fp16 planes) of the fp32 oracle on the
+    16-bit checkpoint's weights; the plain 16-bit flow (SX_XLV2_PRECISE=0) stays inside its 2e-3 / 1.6e-2."""
+    from seedx_amd.detokenizer import ResamplerXLV2
+    cfg = weights.MINI_XLV2
+    sd = {k: v.to(dt).float() for k, v in weights.xlv2_sd(cfg).items()}
+    x = torch.randn(2, 36, cfg["embedding_dim"], generator=torch.Generator().manual_seed(7))
+    p_ref, pool_ref = restated.resampler_xlv2_forward(sd, cfg, x)
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("SX_XLV2_PRECISE", mode)
+        m = ResamplerXLV2(normalize=False, **cfg)
+        assert m.precise == (mode == "1")
+        m.load_state_dict(sd, prefix="resampler.")
+        m.to(dev, dt)
+        p, pool = m(x.to(dev))
+        res[mode] = (relerr(p, p_ref), relerr(pool, pool_ref))
+    print(f"ResamplerXLV2 {dt}: precise prompt / pooled {res['1'][0]:.2e} / {res['1'][1]:.2e}; plain {res['0'][0]:.2e} / {res['0'][1]:.2e}")
+    tol = 1e-4 if dt == torch.float16 else 8e-4
+    assert max(res["1"]) < tol
+    assert max(res["0"]) < (2e-3 if dt == torch.float16 else 1.6e-2) and min(res["0"]) > 3 * max(res["1"])
+
+
 # ---- model level ------------------------------------------------------------------------------------------------------
 def _llm(dev, dt, sd, cfg, **kw):
     from seedx_amd.llama import LlamaForCausalLM
