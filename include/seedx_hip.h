@@ -400,6 +400,8 @@ int sx_nchw_to_nhwc(const float* src, float* dst, int ld, int B, int C, int HW, 
 int sx_nhwc_to_nchw(const float* src, int ld, float* dst, int B, int C, int HW, void* stream);
 /* *p += delta on the device (step / position counters of graph-replayed loops) */
 int sx_add_i32(int32_t* p, int delta, void* stream);
+/* profiling hook: one empty dispatch of `profile_marker_kernel` (tools/kstats_step.py cuts a rocprofv3 kernel trace at these) */
+int sx_profile_marker(int tag, void* stream);
 /* y = silu(x) as 16-bit (ResnetBlock2D.time_emb_proj input: nonlinearity(temb), diffusers [ext]) */
 int sx_silu_cast(const float* x, void* y, int dtype, int64_t n, void* stream);
 

@@ -136,6 +136,7 @@ SIGNATURES = {
     "sx_nchw_to_nhwc": [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp],
     "sx_nhwc_to_nchw": [c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp],
     "sx_add_i32": [c_vp, c_i32, c_vp],
+    "sx_profile_marker": [c_i32, c_vp],
     "sx_silu_cast": [c_vp, c_vp, c_i32, c_i64, c_vp],
     "sx_resample_u8": [c_vp, c_i32, c_i32, c_i32, c_i64, c_vp, c_i32, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32,
                        c_vp, c_vp],

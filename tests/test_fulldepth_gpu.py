@@ -71,9 +71,9 @@ def test_vit_g_48_layers(dev, vit48):
         ref = restated.vit_forward(sd, cfg, x)
     y = m(x)
     e = relerr(y, ref)
-    _report("ViT-G/448, 48 layers, B = 2 crops, fp16: [2, 256, 4096] features", e, 1.5e-3)
+    _report("ViT-G/448, 48 layers, B = 2 crops, fp16: [2, 256, 4096] features", e, 1e-3)
     assert y.shape == (2, 256, 4096) and torch.isfinite(y).all()
-    assert e < 1.5e-3
+    assert e < 1e-3
 
 
 def test_llama_13b_40_layers_prefill_and_128_decode_steps(dev, llm40):
@@ -138,7 +138,7 @@ def test_llama_13b_40_layers_prefill_and_128_decode_steps(dev, llm40):
 
 def test_config0_one_generation_end_to_end(dev, vit48, llm40):
     """BASELINE config 0 at full size, one request: uint8 image → GPU preprocessing → ViT-G (48) → input resampler → 165-token
-    prefill → 4 text tokens + <img> + 64 forced + </img> → output resampler → ResamplerXLV2 → 5 CFG-7.5 Euler steps of the
+    prefill → 4 text tokens + <img> + 64 forced + </img> → output resampler → ResamplerXLV2 → 50 CFG-7.5 Euler steps of the
     complete SDXL UNet @128² → SDXL VAE decode (fp32-grade) → [1, 3, 1024, 1024]. The oracle chain runs on ITS OWN intermediate
     results (errors compound stage to stage), teacher-forced only on the token ids."""
     import sys
@@ -188,8 +188,8 @@ def test_config0_one_generation_end_to_end(dev, vit48, llm40):
     ad.init_pipe(vae=vae, scheduler=EulerDiscreteScheduler(), visual_encoder=vit, image_transform=None, discrete_model=None,
                  dtype=DT, device=dev)
     noise = torch.randn(1, 4, 128, 128, generator=torch.Generator().manual_seed(42))
-    lat = ad.generate(image_embeds=out["img_gen_feat"], latents=noise.clone(), num_inference_steps=5, output_type="latent")
-    img = ad.generate(image_embeds=out["img_gen_feat"], latents=noise.clone(), num_inference_steps=5, output_type="pt")
+    lat = ad.generate(image_embeds=out["img_gen_feat"], latents=noise.clone(), num_inference_steps=N_STEPS, output_type="latent")
+    img = ad.generate(image_embeds=out["img_gen_feat"], latents=noise.clone(), num_inference_steps=N_STEPS, output_type="pt")
     # ---- oracle chain (fp32 on the GPU) --------------------------------------------------------------------------------
     with torch.no_grad():
         ref_emb = restated.vit_forward(sd_vit, vcfg, crops)
@@ -202,7 +202,7 @@ def test_config0_one_generation_end_to_end(dev, vit48, llm40):
                                          None, DT, new, [])
         finally:
             torch.set_default_device(old_device)
-        ref_lat = ra.adapter_generate(sd_vit, vcfg, sd_x, weights.FULL_XLV2, sd_u, ucfg, noise.to(dev), 5,
+        ref_lat = ra.adapter_generate(sd_vit, vcfg, sd_x, weights.FULL_XLV2, sd_u, ucfg, noise.to(dev), N_STEPS,
                                       image_embeds=ref["img_gen_feat"])
         ref_img = ra.decode_to_pt(sd_vae, A, ref_lat)
         # the same oracle stages fed with the HIP path's OWN stage inputs: north_star's "within 1e-3 of the reference on the same inputs"
@@ -214,19 +214,19 @@ def test_config0_one_generation_end_to_end(dev, vit48, llm40):
                                           None, DT, new, [])
         finally:
             torch.set_default_device(old_device)
-        same_lat = ra.adapter_generate(sd_vit, vcfg, sd_x, weights.FULL_XLV2, sd_u, ucfg, noise.to(dev), 5,
+        same_lat = ra.adapter_generate(sd_vit, vcfg, sd_x, weights.FULL_XLV2, sd_u, ucfg, noise.to(dev), N_STEPS,
                                        image_embeds=out["img_gen_feat"].float())
         same_img = ra.decode_to_pt(sd_vae, A, lat.float())
     chain = {"ViT features [2,256,4096]": relerr(emb, ref_emb),
              "LLM final-norm states of the 70 fed tokens": relerr(out["last_hidden_states"], ref["last_hidden"]),
              "output-resampled image features [1,64,4096]": relerr(out["img_gen_feat"], ref["img_gen_feat"]),
-             "latents after 5 UNet CFG steps [1,4,128,128]": relerr(lat, ref_lat),
+             "latents after the 50 UNet CFG steps [1,4,128,128]": relerr(lat, ref_lat),
              "decoded image in [0,1] [1,3,1024,1024]": relerr(img, ref_img)}
     stage = {"ViT-G (48 layers) on the same crops": chain["ViT features [2,256,4096]"],
              "input resampler + LLM (40 layers, 70 fed tokens) on the same ViT features: final-norm states":
                  relerr(out["last_hidden_states"], same["last_hidden"]),
              "... + output resampler: image features": relerr(out["img_gen_feat"], same["img_gen_feat"]),
-             "ResamplerXLV2 + 5 UNet CFG steps on the same image features: latents": relerr(lat, same_lat),
+             "ResamplerXLV2 + 50 UNet CFG-7.5 Euler steps on the same image features: latents": relerr(lat, same_lat),
              "VAE decode of the same latents: image": relerr(img, same_img)}
     for k, e in chain.items():
         _report("config-0 chain (oracle on its OWN intermediates: errors compound), " + k, e, CHAIN_BOUND)
@@ -238,3 +238,5 @@ def test_config0_one_generation_end_to_end(dev, vit48, llm40):
 
 
 CHAIN_BOUND = 2.5e-3      # five stages of <= 1e-3 each on top of each other (round 4 measured 2.05e-3 with the 16-bit LLM flow)
+N_STEPS = 50              # BASELINE's de-tokenizer setting (eval_text2img_seed_x_i.py:91); round 4 ran 5 steps here — with 5 large Euler
+                          # steps the CFG-amplified (x 7.5) UNet error weighs 1.5e-3 on the latents, at the real 50 it is < 1e-3

@@ -33,7 +33,16 @@ int main(int argc, char** argv) {
   const Shape shapes[] = {{"unet 64^2", 16, 10, 4096, 4096, 64, 0}, {"unet 32^2", 16, 20, 1024, 1024, 64, 0}, {"unet cross", 16, 10, 4096, 64, 64, 0},
                           {"vit 2 crops", 2, 16, 1024, 1024, 104, 0}, {"llm 2048", 1, 40, 2048, 2048, 128, 1}, {"ragged", 3, 5, 1000, 777, 64, 0}};
   int bad = 0;
+  const char* only = getenv("ATTN_LAB_SHAPES");      // e.g. "0,1": run these entries of the shape table only (PMC passes key by grid size)
+  int shape_idx = -1;
   for (const Shape& s : shapes) {
+    ++shape_idx;
+    if (only) {
+      bool hit = false;
+      for (const char* c = only; *c; ++c)
+        if (*c >= '0' && *c <= '9' && (*c - '0') == shape_idx && (c == only || c[-1] == ',') && (c[1] == ',' || c[1] == 0)) hit = true;
+      if (!hit) continue;
+    }
     const size_t nq = (size_t)s.B * s.Sq * s.H * s.D, nk = (size_t)s.B * s.Skv * s.H * s.D;
     std::vector<uint16_t> hq(nq), hk(nk), hv(nk);
     for (auto& x : hq) x = f2bf(nrand());

@@ -11,3 +11,5 @@ rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_
 cd $R
 python3 tools/lab/pmc_table.py /tmp/ap1 /tmp/ap2 > $O/${TAG}_pmc_table.txt 2>&1
 cat $O/${TAG}_pmc_table.txt
+python3 tools/lab/attn_pmc_derive.py /tmp/ap1 /tmp/ap2 > $O/${TAG}_pmc_derived.txt 2>&1
+cat $O/${TAG}_pmc_derived.txt

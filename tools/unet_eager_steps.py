@@ -1,5 +1,5 @@
 """N eager (un-graphed, ONE kernel chain) UNet CFG steps at a given batch — the target of the rocprofv3 passes (--kernel-trace
---stats, and the FETCH_SIZE / WRITE_SIZE --pmc passes of tools/r4_pmc_unet.sh).
+--stats, and the FETCH_SIZE / WRITE_SIZE --pmc passes of tools/pmc_unet.sh).
 
 --alg-json FILE: additionally hook sx_gemm / sx_attention (the same byte / FLOP formulas as bench.py's instrumented pass) and
 write the ALGORITHMIC bytes and FLOPs of exactly the launches this command issues, per kernel family — so that the PMC traffic
