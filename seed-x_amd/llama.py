@@ -38,6 +38,41 @@ def glu_pack_rows(lin, gate):
     return torch.cat([lin.view(I // 16, 16, K), gate.view(I // 16, 16, K)], dim=1).reshape(2 * I, K).contiguous()
 
 
+def merge_peft_lora(sd, lora_alpha=32, adapter="default"):
+    """A PeftModel (LoRA) checkpoint of the LLM → the plain LlamaForCausalLM state dict, merged at load time — the optional
+    configs/clm_models/llm_seed_x_lora.yaml route (peft.LoraConfig r 32, lora_alpha 32 on q/k/v/o/gate/up/down, modules_to_save = the
+    norms): W' = W + (lora_B · lora_A) · lora_alpha / r, exactly peft's Linear.merge() / get_delta_weight()
+    (proj/peft/src/peft/tuners/lora.py:779-806); `modules_to_save` copies replace the wrapped module's weight. The product is formed
+    in fp32 and cast back to W's dtype. Keys without the `base_model.model.` prefix pass through unchanged."""
+    out, lora = {}, {}
+    pre = "base_model.model."
+    for k, v in sd.items():
+        k = k[len(pre):] if k.startswith(pre) else k
+        if ".lora_A." in k or ".lora_B." in k:
+            mod, rest = k.split(".lora_", 1)
+            which, ad = rest.split(".")[0], rest.split(".")[1]
+            if ad == adapter or rest.split(".")[1] == "weight":       # `X.lora_A.<adapter>.weight` (or, older peft, `X.lora_A.weight`)
+                lora.setdefault(mod, {})[which] = v
+            continue
+        if ".lora_dropout." in k or ".lora_embedding_" in k:
+            continue
+        if ".modules_to_save." in k:
+            mod, rest = k.split(".modules_to_save.", 1)
+            if rest.split(".")[0] == adapter:
+                out[mod + "." + rest.split(".", 1)[1]] = v
+            continue
+        k = k.replace(".original_module.", ".").replace(".base_layer.", ".")
+        out.setdefault(k, v)
+    for mod, ab in lora.items():
+        if "A" not in ab or "B" not in ab:
+            raise KeyError(f"merge_peft_lora: {mod} has only one of lora_A / lora_B")
+        w = out[mod + ".weight"]
+        r = ab["A"].shape[0]
+        delta = (ab["B"].float() @ ab["A"].float()) * (float(lora_alpha) / r)
+        out[mod + ".weight"] = (w.float() + delta.to(w.device)).to(w.dtype)
+    return out
+
+
 class LlamaConfigLite:
     def __init__(self, hidden_size, intermediate_size, num_hidden_layers, num_attention_heads, vocab_size,
                  rms_norm_eps=1e-5, max_position_embeddings=4096, rope_base=10000.0, **_):
@@ -115,8 +150,9 @@ class LlamaForCausalLM:
 
     # ---- reference-compatible plumbing ---------------------------------------------------------------------
     @classmethod
-    def from_pretrained(cls, pretrained_model_name_or_path, torch_dtype=torch.float16, low_cpu_mem_usage=True, **kw):
-        """HF directory (config.json + *.bin / *.safetensors shards), like llm_seed_x_i.yaml:1-3."""
+    def from_pretrained(cls, pretrained_model_name_or_path, torch_dtype=torch.float16, low_cpu_mem_usage=True, peft_adapter=None, **kw):
+        """HF directory (config.json + *.bin / *.safetensors shards), like llm_seed_x_i.yaml:1-3. ``peft_adapter``: optional PEFT LoRA
+        adapter directory merged into the weights at load."""
         import glob
         import json
         import os
@@ -128,7 +164,22 @@ class LlamaForCausalLM:
             sd.update(load_file(f))
         for f in sorted(glob.glob(os.path.join(pretrained_model_name_or_path, "pytorch_model*.bin"))):
             sd.update(torch.load(f, map_location="cpu"))
-        m.load_state_dict(sd)
+        lora_alpha = 32
+        if peft_adapter is not None:
+            # a PEFT adapter directory (adapter_config.json + adapter_model.safetensors | .bin), what PeftModel.from_pretrained(model_id)
+            # reads in src/models/mllm/peft_models.py:106: merged into the base weights at load (merge_peft_lora)
+            acfg = json.load(open(os.path.join(peft_adapter, "adapter_config.json")))
+            lora_alpha = acfg.get("lora_alpha", 32)
+            fs = os.path.join(peft_adapter, "adapter_model.safetensors")
+            if os.path.exists(fs):
+                from safetensors.torch import load_file
+                ad = load_file(fs)
+            else:
+                ad = torch.load(os.path.join(peft_adapter, "adapter_model.bin"), map_location="cpu")
+            # adapter files name the LoRA matrices `….lora_A.weight` (the adapter name is dropped on save)
+            sd = {("base_model.model." + k if not k.startswith("base_model.model.") else k): v for k, v in sd.items()}
+            sd.update(ad)
+        m.load_state_dict(sd, lora_alpha=lora_alpha)
         m.dtype = torch_dtype
         return m
 
@@ -141,7 +192,9 @@ class LlamaForCausalLM:
             keys += [p + "input_layernorm.weight", p + "post_attention_layernorm.weight"]
         return keys
 
-    def load_state_dict(self, sd, strict=True):
+    def load_state_dict(self, sd, strict=True, lora_alpha=32):
+        if any(".lora_A." in k for k in sd):                 # a PeftModel checkpoint (llm_seed_x_lora.yaml): merge the adapters at load
+            sd = merge_peft_lora(sd, lora_alpha=lora_alpha)
         missing = [k for k in self.expected_keys() if k not in sd]
         if missing and strict:
             raise KeyError(f"LlamaForCausalLM: missing keys {missing[:6]} (+{max(0, len(missing) - 6)})")

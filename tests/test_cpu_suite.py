@@ -408,6 +408,60 @@ def test_ranks_seen_flags_shared_devices():
     assert du.ranks_seen(ctx)[0]["rank"] == 0
 
 
+def test_merge_peft_lora_matches_peft_merge():
+    """The optional LoRA route (configs/clm_models/llm_seed_x_lora.yaml): a PeftModel-style state dict merges at load to
+    W + (B A) alpha / r, norms from modules_to_save — checked against the formula and, where the reference tree exists, against the
+    reference's own peft Linear.merge() (proj/peft/src/peft/tuners/lora.py:779-806)."""
+    from seedx_amd.llama import LlamaForCausalLM, merge_peft_lora
+    g = torch.Generator().manual_seed(0)
+    H, I, r, alpha = 32, 64, 4, 8
+    base = {"model.embed_tokens.weight": torch.randn(50, H, generator=g), "model.norm.weight": torch.ones(H),
+            "lm_head.weight": torch.randn(50, H, generator=g)}
+    peft_sd = {}
+    p = "model.layers.0."
+    shapes = {"self_attn.q_proj": (H, H), "self_attn.k_proj": (H, H), "self_attn.v_proj": (H, H), "self_attn.o_proj": (H, H),
+              "mlp.gate_proj": (I, H), "mlp.up_proj": (I, H), "mlp.down_proj": (H, I)}
+    want = dict(base)
+    for n, (o, i) in shapes.items():
+        w, A, B = torch.randn(o, i, generator=g), torch.randn(r, i, generator=g), torch.randn(o, r, generator=g)
+        peft_sd[f"base_model.model.{p}{n}.weight"] = w
+        peft_sd[f"base_model.model.{p}{n}.lora_A.default.weight"] = A
+        peft_sd[f"base_model.model.{p}{n}.lora_B.default.weight"] = B
+        want[p + n + ".weight"] = w + (B @ A) * (alpha / r)
+    for n in ("input_layernorm", "post_attention_layernorm"):
+        peft_sd[f"base_model.model.{p}{n}.original_module.weight"] = torch.ones(H)
+        peft_sd[f"base_model.model.{p}{n}.modules_to_save.default.weight"] = want.setdefault(p + n + ".weight", torch.rand(H, generator=g) + 0.5)
+    peft_sd.update({"base_model.model." + k: v for k, v in base.items()})
+    got = merge_peft_lora(peft_sd, lora_alpha=alpha)
+    assert set(got) == set(want)
+    for k in want:
+        assert torch.allclose(got[k], want[k], atol=1e-6), k
+    m = LlamaForCausalLM(dict(hidden_size=H, intermediate_size=I, num_hidden_layers=1, num_attention_heads=2, vocab_size=50))
+    missing, _ = m.load_state_dict(peft_sd, lora_alpha=alpha)            # auto-detected and merged
+    assert missing == [] and torch.allclose(m._sd[p + "mlp.down_proj.weight"], want[p + "mlp.down_proj.weight"], atol=1e-6)
+    ref_lora = os.path.join("/root/reference", "proj", "peft", "src")
+    if os.path.isdir(ref_lora):
+        from oracle import refshim
+        refshim.install()                                                 # stand-ins for transformers.deepspeed & co (absent here)
+        sys.path.insert(0, ref_lora)
+        try:
+            from peft.tuners.lora import Linear as PeftLinear
+        except Exception:                                                 # the reference's peft needs packages this image may lack
+            PeftLinear = None
+        finally:
+            sys.path.remove(ref_lora)
+        assert PeftLinear is not None, "the reference's peft Linear did not import: the merge is then only checked against the formula"
+        if PeftLinear is not None:
+            lin = PeftLinear("default", H, I, r=r, lora_alpha=alpha, lora_dropout=0.0)
+            n = "mlp.gate_proj"
+            with torch.no_grad():
+                lin.weight.copy_(peft_sd[f"base_model.model.{p}{n}.weight"])
+                lin.lora_A["default"].weight.copy_(peft_sd[f"base_model.model.{p}{n}.lora_A.default.weight"])
+                lin.lora_B["default"].weight.copy_(peft_sd[f"base_model.model.{p}{n}.lora_B.default.weight"])
+                lin.merge()
+            assert torch.allclose(lin.weight.data, got[p + n + ".weight"], atol=1e-5)
+
+
 # ---- tensor-parallel host logic (parallel.py) ------------------------------------------------------------------------
 def test_llama_tp_shard_reconstructs_full_layer():
     """Megatron slices of one decoder layer: column-parallel outputs concatenate, row-parallel partial products sum, to
