@@ -447,7 +447,8 @@ def measure_roofline(w):
     Returns (roofline of the dominant kernel family, per-phase dict)."""
     from seedx_amd import _lib, ops
     lib = _lib.load()
-    real = {n: getattr(lib, n) for n in ("sx_gemm", "sx_gemm_gn", "sx_gemm_ln", "sx_gemv", "sx_attention", "sx_attn_decode_b", "sx_attn_decode_fused")}
+    real = {n: getattr(lib, n) for n in ("sx_gemm", "sx_gemm_gn", "sx_gemm_ln", "sx_gemv", "sx_attention", "sx_attn_decode_b", "sx_attn_decode_fused",
+                                         "sx_attention_f32")}
     rec = []                       # (family, phase, flops, bytes, start, end)
     executed = {}                  # phase -> MFMA FLOPs actually issued (plane-carrying launches counted with their tripled K)
     stack = ["other"]
@@ -469,17 +470,19 @@ def measure_roofline(w):
         a = args_ref._obj
         n_out = a.N // 2 if a.glu else a.N
         n_st = a.n_valid if a.n_valid else n_out
-        a_bytes = 2.0 * (a.B * a.Hin * a.Win * a.Cin if a.a_mode == 1 else a.M * a.K)   # operands once + output once
+        pl = 2 if a.a_planes == 2 else 1                   # precise LLM: A carries the hi and lo planes (2x the A bytes, 2x the MFMA work)
+        a_bytes = 2.0 * (a.B * a.Hin * a.Win * a.Cin if a.a_mode == 1 else a.M * a.K * pl)   # operands once + output once
         byt = a_bytes + 2.0 * a.N * a.K + a.M * n_st * (4.0 if a.out_dtype == 2 else 2.0) + (4.0 * a.M * n_st if a.residual else 0.0)
         if len(rest) == 2 and rest[0]._obj.row_stats_out:
             byt += 2.0 * a.M * a.N
-        executed[stack[-1]] = executed.get(stack[-1], 0.0) + 2.0 * a.M * a.N * a.K
+        executed[stack[-1]] = executed.get(stack[-1], 0.0) + 2.0 * a.M * a.N * a.K * pl
         return timed("gemm", 2.0 * a.M * a.N * a.K / ops.OPERAND_PLANES, byt, fn, args_ref, *rest)
 
     def h_gemv(args_ref, stream):
         a = args_ref._obj
         n_out = a.N // 2 if a.glu else a.N
-        byt = 2.0 * a.N * a.K + 2.0 * a.M * a.K + a.M * n_out * (4.0 if a.out_dtype == 2 else 2.0) + (4.0 * a.M * n_out if a.residual else 0.0)
+        pl = 2 if a.x_planes == 2 else 1
+        byt = 2.0 * a.N * a.K + 2.0 * a.M * a.K * pl + a.M * n_out * (4.0 if (a.out_dtype & 0xff) == 2 else 2.0) + (4.0 * a.M * n_out if a.residual else 0.0)
         return timed("gemv", 2.0 * a.M * a.N * a.K, byt, real["sx_gemv"], args_ref, stream)
 
     def h_attn(args_ref, stream):
@@ -499,6 +502,19 @@ def measure_roofline(w):
         a = args_ref._obj          # one-launch form: K and V of pos[g] + 1 keys per sequence
         keys = float(w.agent.llm._P["pos"][:a.G].sum().item()) + a.G
         return timed("attn_decode", 4.0 * keys * a.H * a.D, 2.0 * 2.0 * keys * a.H * a.D, real["sx_attn_decode_fused"], args_ref, stream)
+
+    def h_attn_f32(args_ref, stream):
+        # precise LLM: fp32 attention over the fp32 cache. T = 1 (decode step): K and V of pos[g] + 1 keys per sequence, 4 bytes each →
+        # the decode phase's KV bytes; T > 1 (prefill / chunk): fp32 FMA work, its own family (not an MFMA kernel)
+        a = args_ref._obj
+        if not a.causal:
+            keys, pairs = float(a.G) * a.Tmax, float(a.G) * a.T * a.Tmax
+        else:
+            pos = w.agent.llm._P["pos"][:a.G].float()
+            keys = float((pos + a.T).sum().item())
+            pairs = float((a.T * pos + a.T * (a.T + 1) / 2.0).sum().item())
+        fam_ = "attn_decode" if (a.T == 1 and a.causal) else "attention_f32"
+        return timed(fam_, 4.0 * pairs * a.H * a.D, 4.0 * 2.0 * keys * a.H * a.D, real["sx_attention_f32"], args_ref, stream)
 
     def phase_wrap(obj, name, phase):
         cls = type(obj)
@@ -540,6 +556,7 @@ def measure_roofline(w):
         if agent is not None:
             lib.sx_attn_decode_b = h_attn_decode
             lib.sx_attn_decode_fused = h_attn_decode_fused
+            lib.sx_attention_f32 = h_attn_f32
         w.step(1)
         torch.cuda.synchronize()
     finally:

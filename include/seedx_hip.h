@@ -169,6 +169,11 @@ typedef struct sx_gemv_args {
                         * fp32-grade activation as two 16-row operand blocks [2][K/32][16][32] (block 0 = hi, block 1 = lo; sx_split16 /
                         * sx_rmsnorm_planes / sx_attention_f32 with SX_TILED16): every weight fragment feeds two MFMAs and the two
                         * partial results are added ahead of the epilogue — the weights stream once, y = epi((hi + lo) W^T) */
+  int32_t out_planes;  /* 1 (M <= 16): the tiled 16-bit output (SX_TILED16) or x16_out is written as two planes [2][cols/32][16][32]
+                        * (block 0 = rn16(v), block 1 = rn16(v - block 0)): the next sx_gemv's x with x_planes = 2, without a sx_split16 launch */
+  const float* x16_gamma; /* optional fp32 [N] with x16_out: x16_out holds o * gamma (the NEXT LlamaRMSNorm's weight applied on the
+                        * activation side, so that the next projection keeps its exact checkpoint weights and only scales by rstd from
+                        * row_ssq_in — the RMSNorm fold of the precise mode; row_ssq_out is still the sum of squares of o itself) */
 } sx_gemv_args;
 /* workgroups in x (= partial rows of row_ssq_out) sx_gemv launches for an M x N x K problem with / without GLU on the MFMA path */
 int sx_gemv_ssq_parts(int N, int glu, int w_layout);

@@ -37,7 +37,7 @@ class GemvArgs(C.Structure):
                 ("dtype", c_i32), ("out_dtype", c_i32), ("act", c_i32), ("glu", c_i32),
                 ("w_layout", c_i32), ("x_layout", c_i32), ("workspace", c_vp), ("workspace_bytes", C.c_uint64),
                 ("x16_out", c_vp), ("row_ssq_out", c_vp), ("row_ssq_in", c_vp), ("ssq_in_parts", c_i32), ("ssq_dim", c_i32),
-                ("ssq_eps", c_f32), ("x_planes", c_i32)]
+                ("ssq_eps", c_f32), ("x_planes", c_i32), ("out_planes", c_i32), ("x16_gamma", c_vp)]
 
 
 class AttnF32Args(C.Structure):

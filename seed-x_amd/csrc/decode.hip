@@ -27,6 +27,8 @@ struct GemvP {
   float ssq_inv_dim, ssq_eps;
   int planes2;  // MB = 2 kernels with M <= 16: x block 1 is the LO plane of an fp32-grade activation (sx_gemv_args.x_planes = 2) — the two
                 // blocks' results are added ahead of the epilogue
+  int out_planes;          // the 16-bit tiled output (y_tiled) or x16_out is written as two planes: block 0 = hi, block 1 = lo (rows <= 16)
+  const float* x16_gamma;  // x16_out holds o * gamma[col] (the NEXT RMSNorm's gamma applied on the activation side: the weights stay exact)
 };
 
 template <typename TT, int MR>
@@ -115,6 +117,19 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvP p) {
 // (o-proj 3.4 TB/s); as 256 groups of 20 every CU streams the same bytes and no cross-workgroup reduction is needed.
 __device__ const unsigned g_zero_line[16] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
 
+// lo plane of four fp32 values whose hi plane (two packed dwords) is `hi`: rn16(x - float(hi)), same element type
+__device__ __forceinline__ u32x2_t lo_plane(f32x4_t x, u32x2_t hi, bool bf16) {
+  u32x2_t lo;
+  if (bf16) {
+    lo[0] = pack2<BF16>(x[0] - BF16::to_f32(hi[0] & 0xffff), x[1] - BF16::to_f32(hi[0] >> 16));
+    lo[1] = pack2<BF16>(x[2] - BF16::to_f32(hi[1] & 0xffff), x[3] - BF16::to_f32(hi[1] >> 16));
+  } else {
+    lo[0] = pack2<F16>(x[0] - F16::to_f32(hi[0] & 0xffff), x[1] - F16::to_f32(hi[0] >> 16));
+    lo[1] = pack2<F16>(x[2] - F16::to_f32(hi[1] & 0xffff), x[3] - F16::to_f32(hi[1] >> 16));
+  }
+  return lo;
+}
+
 // MB = 2 (17..32 activation rows, lock-step batch 32): the x operand is two 16-row blocks — tiles [2][K/32][16][32] or rows 16..31 of
 // the row-major x — and every weight fragment feeds two MFMAs, so the weights still stream ONCE for all 32 sequences. Outputs, the
 // 16-bit tiled output, x16_out and the sums of squares follow the same block structure (row m = 16 b + r).
@@ -178,6 +193,7 @@ __global__ __launch_bounds__(NWV * 64) void gemm_skinny_kernel(const GemvP p) {
     const int per = p.ssq_parts >> 4;                                   // parts % 64 == 0 (host-checked) → per % 4 == 0
 #pragma unroll
     for (int b = 0; b < MB; ++b) {
+      if (b > 0 && p.planes2) break;                                    // block 1 is the lo plane of the same rows: no list of its own
       const f32x4_t* src = (const f32x4_t*)(p.ssq_in + (size_t)(r + 16 * b) * p.ssq_parts + (size_t)(wave * 4 + g) * per);
       float s0 = 0.f;
 #pragma unroll 5
@@ -192,6 +208,7 @@ __global__ __launch_bounds__(NWV * 64) void gemm_skinny_kernel(const GemvP p) {
     __syncthreads();
 #pragma unroll
     for (int b = 0; b < MB; ++b) {
+      if (b > 0 && p.planes2) break;
       float tot = 0.f;
 #pragma unroll
       for (int w = 0; w < NWV; ++w) tot += ssq_red[w][r + 16 * b];
@@ -372,14 +389,20 @@ __global__ __launch_bounds__(NWV * 64) void gemm_skinny_kernel(const GemvP p) {
         u32x2_t w2;
         if (p.out_dtype == SX_BF16) { w2[0] = pack2<BF16>(o[0], o[1]); w2[1] = pack2<BF16>(o[2], o[3]); }
         else { w2[0] = pack2<F16>(o[0], o[1]); w2[1] = pack2<F16>(o[2], o[3]); }
-        *(u32x2_t*)((unsigned short*)p.y + tblk + (size_t)(col >> 5) * 512 + (size_t)r * 32 + (col & 31)) = w2;
+        unsigned short* yt = (unsigned short*)p.y + tblk + (size_t)(col >> 5) * 512 + (size_t)r * 32 + (col & 31);
+        *(u32x2_t*)yt = w2;
+        if (p.out_planes) *(u32x2_t*)(yt + (size_t)ncols * 16) = lo_plane(o, w2, p.out_dtype == SX_BF16);   // block 1 = o - hi
       } else if (p.out_dtype == SX_F32) {
         *(f32x4_t*)((float*)p.y + off) = o;
         if (p.x16_out) {     // folded RMSNorm, producer side: the new residual stream also as the next GEMV's 16-bit operand tiles
+          f32x4_t og = o;      // precise mode: gamma of the NEXT norm goes onto the activation (weights stay exact), two planes
+          if (p.x16_gamma) og = o * *(const f32x4_t*)(p.x16_gamma + col);
           u32x2_t w2;
-          if (std::is_same<TT, BF16>::value) { w2[0] = pack2<BF16>(o[0], o[1]); w2[1] = pack2<BF16>(o[2], o[3]); }
-          else { w2[0] = pack2<F16>(o[0], o[1]); w2[1] = pack2<F16>(o[2], o[3]); }
-          *(u32x2_t*)(p.x16_out + tblk + (size_t)(col >> 5) * 512 + (size_t)r * 32 + (col & 31)) = w2;
+          if (std::is_same<TT, BF16>::value) { w2[0] = pack2<BF16>(og[0], og[1]); w2[1] = pack2<BF16>(og[2], og[3]); }
+          else { w2[0] = pack2<F16>(og[0], og[1]); w2[1] = pack2<F16>(og[2], og[3]); }
+          unsigned short* xt = p.x16_out + tblk + (size_t)(col >> 5) * 512 + (size_t)r * 32 + (col & 31);
+          *(u32x2_t*)xt = w2;
+          if (p.out_planes) *(u32x2_t*)(xt + (size_t)ncols * 16) = lo_plane(og, w2, std::is_same<TT, BF16>::value);
           ssq_l += o[0] * o[0] + o[1] * o[1] + o[2] * o[2] + o[3] * o[3];
         }
       } else {
@@ -389,7 +412,7 @@ __global__ __launch_bounds__(NWV * 64) void gemm_skinny_kernel(const GemvP p) {
         *(u32x2_t*)((unsigned short*)p.y + off) = w2;
       }
     }
-    if (p.ssq_out) {           // (whole wave: rows >= M contribute zeros and are never read)
+    if (p.ssq_out && !(b > 0 && p.planes2)) {           // (whole wave: rows >= M contribute zeros and are never read)
       ssq_l += __shfl_xor(ssq_l, 16, 64);
       ssq_l += __shfl_xor(ssq_l, 32, 64);
       if (g == 0) p.ssq_out[(size_t)m * gridDim.x + blockIdx.x] = ssq_l;      // [16 MB][parts]
@@ -923,8 +946,11 @@ extern "C" int sx_gemv(const sx_gemv_args* a, void* stream) {
   SX_CHECK(a->x_planes >= 0 && a->x_planes <= 2, "sx_gemv: x_planes=%d", a->x_planes);
   const bool planes2 = a->x_planes == 2;
   p.planes2 = planes2 ? 1 : 0;
-  SX_CHECK(!planes2 || (a->M <= 16 && a->x_layout == 1 && !a->x16_out && !a->row_ssq_in),
-           "sx_gemv: x_planes = 2 needs M <= 16, tiled x (two blocks: hi, lo) and no RMSNorm fold");
+  SX_CHECK(!planes2 || (a->M <= 16 && a->x_layout == 1), "sx_gemv: x_planes = 2 needs M <= 16 and tiled x (two blocks: hi, lo)");
+  p.out_planes = a->out_planes ? 1 : 0;
+  p.x16_gamma = a->x16_gamma;
+  SX_CHECK(!p.out_planes || (a->M <= 16 && (p.y_tiled || a->x16_out)), "sx_gemv: out_planes needs M <= 16 and a tiled 16-bit output (SX_TILED16 or x16_out)");
+  SX_CHECK(!a->x16_gamma || (a->x16_out && (((uintptr_t)a->x16_gamma) & 15) == 0), "sx_gemv: x16_gamma belongs to x16_out (16-B aligned fp32 [N])");
   SX_CHECK(a->w_layout >= 0 && a->w_layout <= 2, "sx_gemv: w_layout must be 0 (row-major), 1 (decode tiles) or 2 (20-row decode tiles)");
   SX_CHECK(a->w_layout != 2 || (!a->glu && a->N % 20 == 0 && a->N % 32 == 0), "sx_gemv: w_layout 2 needs N %% 20 == 0, N %% 32 == 0, no GLU");
   // MI355X (tools/bench_gemv.py, 13B shapes): VALU path 6.5 / 4.7 / 3.0 TB/s at M = 1 / 4 / 8, MFMA path 4.0-4.4 TB/s at any M

@@ -134,7 +134,6 @@ __global__ void rope_kv_f32_kernel(float* qkv, float* kc, float* vc, const float
 // loaded once for the QB query rows. Online softmax per (group, row), the 16 groups meet in LDS in group order (deterministic).
 // Output: the two 16-bit planes of the context rows (the o-projection's A operand), row-major or tiled (store_planes8's layouts,
 // one element at a time).
-constexpr int QB = 4;
 struct AttnF32P {
   const float* q;          // row r = g*T + t at q + r*q_stride, head h at + h*D (already rotated)
   const float* kc;
@@ -146,9 +145,11 @@ struct AttnF32P {
   float scale;
 };
 
-template <typename TT>
+// QB query rows per workgroup: 4 for the decode step and short chunks, 8 for prefill (every key row is loaded once per QB rows: the
+// K / V re-reads from L2 halve — 1.5k-token prompts, BASELINE config 5)
+template <typename TT, int QB>
 __global__ __launch_bounds__(256) void attn_f32_kernel(const AttnF32P p) {
-  __shared__ float red[16][QB][132];
+  __shared__ float red[4][QB][132];
   const int q0 = blockIdx.x * QB, h = blockIdx.y, g = blockIdx.z, D = p.D;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int grp = wave * 4 + (lane >> 4), dl = lane & 15;
@@ -205,15 +206,32 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const AttnF32P p) {
       }
     }
   }
+  // the four 16-lane groups of a wave first (xor-16 / xor-32 butterflies: the same order in every lane), then the four waves through LDS
+  // in wave order: deterministic
 #pragma unroll
   for (int i = 0; i < QB; ++i) {
-    if (dvalid) {
+    float mw = fmaxf(m_run[i], __shfl_xor(m_run[i], 16, 64));
+    mw = fmaxf(mw, __shfl_xor(mw, 32, 64));
+    const float sc = (m_run[i] == -INFINITY) ? 0.f : __expf(m_run[i] - mw);
+    float lw = l_run[i] * sc;
+    lw += __shfl_xor(lw, 16, 64);
+    lw += __shfl_xor(lw, 32, 64);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) red[grp][i][dl * 8 + e] = o[i][e];
+    for (int e = 0; e < 8; ++e) {
+      float t = o[i][e] * sc;
+      t += __shfl_xor(t, 16, 64);
+      t += __shfl_xor(t, 32, 64);
+      o[i][e] = t;
     }
-    if (dl == 0) {
-      red[grp][i][128] = m_run[i];
-      red[grp][i][129] = l_run[i];
+    if ((lane >> 4) == 0) {
+      if (dvalid) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[wave][i][dl * 8 + e] = o[i][e];
+      }
+      if (dl == 0) {
+        red[wave][i][128] = mw;
+        red[wave][i][129] = lw;
+      }
     }
   }
   __syncthreads();
@@ -223,10 +241,10 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const AttnF32P p) {
     if (i >= nq || d >= D) continue;
     float mg = -INFINITY;
 #pragma unroll
-    for (int gg = 0; gg < 16; ++gg) mg = fmaxf(mg, red[gg][i][128]);
+    for (int gg = 0; gg < 4; ++gg) mg = fmaxf(mg, red[gg][i][128]);
     float acc = 0.f, lsum = 0.f;
 #pragma unroll
-    for (int gg = 0; gg < 16; ++gg) {
+    for (int gg = 0; gg < 4; ++gg) {
       const float mgk = red[gg][i][128];
       const float w = (mgk == -INFINITY) ? 0.f : __expf(mgk - mg);
       acc = fmaf(w, red[gg][i][d], acc);
@@ -323,9 +341,15 @@ extern "C" int sx_attention_f32(const sx_attn_f32_args* a, void* stream) {
   SX_CHECK(p.row_stride % 4 == 0 && p.head_stride % 4 == 0 && p.seq_stride % 4 == 0 && (((uintptr_t)a->kcache) & 15) == 0 &&
            (((uintptr_t)a->vcache) & 15) == 0, "sx_attention_f32: K / V strides and pointers must keep 16-B alignment");
   p.T = a->T; p.H = a->H; p.D = a->D; p.Tmax = a->Tmax; p.tiled = tiled; p.scale = a->scale; p.causal = a->causal ? 1 : 0;
-  const dim3 grid((a->T + QB - 1) / QB, a->H, a->G);
-  if (dt == SX_BF16) hipLaunchKernelGGL(attn_f32_kernel<BF16>, grid, dim3(256), 0, ST, p);
-  else hipLaunchKernelGGL(attn_f32_kernel<F16>, grid, dim3(256), 0, ST, p);
+  if (a->T > 8) {
+    const dim3 grid((a->T + 7) / 8, a->H, a->G);
+    if (dt == SX_BF16) hipLaunchKernelGGL((attn_f32_kernel<BF16, 8>), grid, dim3(256), 0, ST, p);
+    else hipLaunchKernelGGL((attn_f32_kernel<F16, 8>), grid, dim3(256), 0, ST, p);
+  } else {
+    const dim3 grid((a->T + 3) / 4, a->H, a->G);
+    if (dt == SX_BF16) hipLaunchKernelGGL((attn_f32_kernel<BF16, 4>), grid, dim3(256), 0, ST, p);
+    else hipLaunchKernelGGL((attn_f32_kernel<F16, 4>), grid, dim3(256), 0, ST, p);
+  }
   SX_HIP_LAUNCH_CHECK();
   return SX_OK;
 }

@@ -248,13 +248,15 @@ class LlamaForCausalLM:
             skinny GEMM, whose wave-wide loads then cover whole contiguous kilobytes: 2.85 → 4.2 TB/s per layer in situ,
             tools/bench_gemv_layout.py). Costs the weights' size again (25.7 GB of 288 GB at 13B); prefill keeps row-major."""
             N, K = w.shape
-            return ops.pack_decode_tiles(w) if (self.G >= 5 and N % 32 == 0 and K % 64 == 0 and K >= 256) else None
+            # (precise mode: every lock-step batch size runs the MFMA skinny GEMM — the lo plane is its second operand block — so the
+            # tiles exist from G = 1: 15.1 → 8 ms per token step at G = 4, BASELINE config 5)
+            return ops.pack_decode_tiles(w) if ((self.G >= 5 or self.precise) and N % 32 == 0 and K % 64 == 0 and K >= 256) else None
         P["lm_head_t"] = tiles(lm)
         # RMSNorm folded into the batched decode step (single rank, G >= 5; sx_gemv_args.x16_out / row_ssq_*): the decode-tile copies
         # of the projections that FOLLOW a norm carry that norm's gamma (W' = W · diag(gamma), product rounded once to 16 bits) —
         # wgu of every layer (post_attention_layernorm) and wqkv of layers >= 1 (input_layernorm; layer 0's input comes from the
         # embedding, not from a GEMV). Prefill keeps the row-major, unfolded weights and the norm kernel.
-        bal20 = self.G >= 5 and os.environ.get("SX_GEMV_BAL20", "1") != "0"
+        bal20 = (self.G >= 5 or self.precise) and os.environ.get("SX_GEMV_BAL20", "1") != "0"
         # the consumer adds the producer's per-workgroup sums of squares 64 at a time: the o / down launches (N = H) must have a
         # multiple of 64 workgroups (H = 5120: 256 with 20-row tiles, 320 without)
         # (asked from the library, not re-derived here: sx_gemv's own workgroup count for an N = H launch in that weight layout)
@@ -297,6 +299,11 @@ class LlamaForCausalLM:
         # precise decode step on the skinny GEMM (operand tiles, two planes): every projection shape must satisfy its MFMA path
         P["precise_tiled"] = all(k % 64 == 0 and k >= 256 for k in (self.H, self.H_l, self.I_l)) and \
             all(n % 32 == 0 for n in (3 * self.H_l, self.H, 2 * self.I_l, self.V_l))
+        # RMSNorm fold of the precise decode step (single rank, decode tiles, a multiple of 64 workgroups in the o / down launches —
+        # the plain fold's conditions): the residual GEMV writes the two planes of x * gamma_next and the rows' sums of squares, the
+        # projection behind the norm scales by rstd. gamma sits on the ACTIVATION here: the checkpoint's weights stay exact.
+        P["rms_fold_precise"] = self.precise and P["precise_tiled"] and P["decode_tiled"] and tp == 1 and parts % 64 == 0 \
+            and self.H % 32 == 0 and self.I_l % 32 == 0 and os.environ.get("SX_RMS_FOLD", "1") != "0"
         inv = 1.0 / (self.config.rope_base ** (torch.arange(0, self.hd, 2).float() / self.hd))
         fr = torch.outer(torch.arange(self.Tmax).float(), inv)           # [Tmax, hd/2] fp32 (:97-113)
         P["cos"], P["sin"] = fr.cos().to(dev).contiguous(), fr.sin().to(dev).contiguous()
@@ -464,21 +471,40 @@ class LlamaForCausalLM:
         comm, lead = self.comm, self.comm.rank == 0
         eps, scale = self.config.rms_norm_eps, 1.0 / math.sqrt(hd)
         tl, ws, f32 = P["precise_tiled"], P["gemv_ws"], torch.float32
-        dtl = tl and P["decode_tiled"] and G >= 5            # decode-tile weight copies exist and pay off
+        dtl = tl and P["decode_tiled"]                       # decode-tile weight copies (built for every G in precise mode)
 
         def lin(xp, lw, k, **kw):
             if tl:
                 return ops.gemv(xp, lw[k], w_tiles=lw[k + "_t"] if dtl else None, workspace=ws if dtl else None,
                                 w_tiles20=lw.get(k + "_t20") if dtl else None, out_dtype=f32, **kw)
             return ops.gemm(xp, lw[k], a_planes=2, out_dtype=f32, **kw)
+        fold = P["rms_fold_precise"]
+        x16 = ssq = None
+        nl = len(P["layers"])
         for li, lw in enumerate(P["layers"]):
-            h, _ = ops.rmsnorm_planes(x, lw["ln1"], eps, dt, tiled=tl)
-            qkv = lin(h, lw, "wqkv")                                                  # [G, 3H] fp32
+            if fold and li > 0:
+                qkv = lin(x16, lw, "wqkv", ssq_in=(ssq, self.H, eps))                 # x16 = planes of x * ln1 (written by the down GEMV)
+            else:
+                h, _ = ops.rmsnorm_planes(x, lw["ln1"], eps, dt, tiled=tl)
+                qkv = lin(h, lw, "wqkv")                                              # [G, 3H] fp32
             ops.rope_kv_append_f32(qkv, P["kc"][li], P["vc"][li], P["cos"], P["sin"], P["pos"], G, 1, nh, hd, dt)
             att = ops.attention_f32(qkv, P["kc"][li], P["vc"][li], P["pos"], G, 1, nh, hd, scale, dt, tiled=tl)
+            if fold:
+                # residual GEMV: fp32 x, the planes of x * gamma of the NEXT norm, the rows' sums of squares; GLU epilogue: planes directly
+                x, x16, ssq = lin(att, lw, "wo", residual=x, emit_norm=True, planes_out=True, norm_gamma=lw["ln2"])
+                g = ops.gemv(x16, lw["wgu"], act="silu", glu=True, w_tiles=lw["wgu_t"], y_tiled=True, planes_out=True,
+                             ssq_in=(ssq, self.H, eps))
+                if li + 1 < nl:
+                    x, x16, ssq = lin(g, lw, "wd", residual=x, emit_norm=True, planes_out=True, norm_gamma=P["layers"][li + 1]["ln1"])
+                else:                        # the final norm wants fp32 states: its own launch (rmsnorm_planes in _decode_step_body)
+                    x = lin(g, lw, "wd", residual=x)
+                continue
             x = comm.all_reduce(lin(att, lw, "wo", residual=x if lead else None))
             h, _ = ops.rmsnorm_planes(x, lw["ln2"], eps, dt, tiled=tl)
-            g = ops.split16(lin(h, lw, "wgu", act="silu", glu=True), dt, tiled=tl)
+            if tl:                           # SiLU-GLU epilogue writes the two planes of its result itself (no sx_split16 launch)
+                g = ops.gemv(h, lw["wgu"], act="silu", glu=True, w_tiles=lw["wgu_t"] if dtl else None, y_tiled=True, planes_out=True)
+            else:
+                g = ops.split16(lin(h, lw, "wgu", act="silu", glu=True), dt)
             x = comm.all_reduce(lin(g, lw, "wd", residual=x if lead else None))
         ops.add_i32(P["pos"], 1)
         ops.add_i32(P["ctx"], 1)

@@ -257,14 +257,17 @@ class Tiled16:
 
 
 def gemv(x, w, residual=None, act=None, glu=False, out_dtype=None, w_tiles=None, y_tiled=False, workspace=None,
-         emit_norm=False, ssq_in=None, w_tiles20=None):
+         emit_norm=False, ssq_in=None, w_tiles20=None, planes_out=False, norm_gamma=None):
     """w_tiles: the same weight in the decode layout (pack_decode_tiles); used instead of w when the MFMA path runs.
     x may be a Tiled16 (then w_tiles is required); y_tiled returns the 16-bit result as a Tiled16 for the next gemv.
     workspace: zero-initialised uint8 scratch enabling split-K over workgroups for shapes that need it (sx_gemv_args.workspace).
     RMSNorm fold (sx_gemv_args.x16_out / row_ssq_*; MFMA path, tiled x): ``emit_norm`` (fp32 residual outputs) → returns
     (y, x16, ssq): y also as 16-bit operand tiles and the rows' sums of squares per workgroup; ``ssq_in`` = (ssq, dim, eps) of
     the producer → the accumulators are scaled by rsqrt(sum(ssq) / dim + eps) (gamma lives in this launch's weights).
-    w_tiles20: the weight as 20-row decode tiles (pack_decode_tiles20) instead of w_tiles: one workgroup per 20 rows."""
+    w_tiles20: the weight as 20-row decode tiles (pack_decode_tiles20) instead of w_tiles: one workgroup per 20 rows.
+    planes_out (M <= 16): the tiled 16-bit result (y_tiled) or the emit_norm x16 is written as two planes (Tiled16 planes = 2) for a next
+    gemv with fp32-grade x; norm_gamma (with emit_norm): x16 = planes of y * gamma — the NEXT RMSNorm's weight on the activation side, so
+    the projection behind the norm keeps exact weights and only applies rstd (ssq_in)."""
     lib = _lib.load()
     xt = isinstance(x, Tiled16)
     if xt:
@@ -278,7 +281,7 @@ def gemv(x, w, residual=None, act=None, glu=False, out_dtype=None, w_tiles=None,
     out_dtype = out_dtype or x.dtype
     dev = x.t.device if xt else x.device
     if y_tiled:
-        yt = Tiled16(M, n_out, out_dtype, dev)
+        yt = Tiled16(M, n_out, out_dtype, dev, planes=2 if planes_out else 1)
         y = yt.t
     else:
         y = torch.empty((M, n_out), dtype=out_dtype, device=dev)
@@ -295,6 +298,9 @@ def gemv(x, w, residual=None, act=None, glu=False, out_dtype=None, w_tiles=None,
     args.dtype, args.out_dtype, args.act, args.glu = _DT[x.dtype], _DT[out_dtype], ACT[act], 1 if glu else 0
     if y_tiled:
         args.out_dtype |= _lib.SX_TILED16
+    if planes_out:
+        assert M <= 16 and (y_tiled or emit_norm)
+        args.out_planes = 1
     if w_tiles is not None and (xt or y_tiled or M >= 5) and K % 64 == 0 and K >= 256 and N % 32 == 0:
         assert w_tiles.shape == w.shape and w_tiles.dtype == w.dtype and w_tiles.is_contiguous()
         args.W, args.w_layout = w_tiles.data_ptr(), 1
@@ -304,7 +310,10 @@ def gemv(x, w, residual=None, act=None, glu=False, out_dtype=None, w_tiles=None,
     x16 = ssq = None
     if emit_norm:
         assert args.w_layout in (1, 2) and out_dtype == torch.float32 and not glu and not y_tiled
-        x16 = Tiled16(M, n_out, w.dtype, dev)
+        x16 = Tiled16(M, n_out, w.dtype, dev, planes=2 if planes_out else 1)
+        if norm_gamma is not None:
+            assert norm_gamma.dtype == torch.float32 and norm_gamma.is_contiguous() and norm_gamma.numel() == n_out
+            args.x16_gamma = norm_gamma.data_ptr()
         ssq = torch.empty((16 * ((M + 15) // 16), lib.sx_gemv_ssq_parts(N, 0, args.w_layout)), dtype=torch.float32, device=dev)   # [row][workgroup]
         args.x16_out, args.row_ssq_out = x16.t.data_ptr(), ssq.data_ptr()
     if ssq_in is not None:

@@ -137,6 +137,52 @@ def test_gemv_two_planes(dev, dt, M):
 
 
 @pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("M", [1, 11, 16])
+def test_gemv_plane_outputs_and_precise_rmsnorm_fold(dev, dt, M):
+    """sx_gemv_args.out_planes / x16_gamma: (a) the SiLU-GLU epilogue writes the two planes of its fp32 result itself; (b) a residual GEMV
+    emits the planes of y * gamma and the rows' sums of squares; (c) the projection behind the norm reads those planes, keeps its exact weights
+    and scales by rstd — together LlamaRMSNorm with gamma on the activation side (the precise decode step's fold)."""
+    from seedx_amd import ops
+    from seedx_amd.llama import glu_pack_rows
+    g = torch.Generator().manual_seed(40 + M)
+    K, H, I2 = 512, 5120, 2816
+    x = torch.randn(M, K, generator=g).to(dev)
+    xt = ops.split16(x, dt, tiled=True)
+    split = lambda t: (lambda hi: hi.float() + (t - hi.float()).to(dt).float())(t.to(dt))
+    # (a)
+    wg = (torch.randn(I2, K, generator=g) / math.sqrt(K)).to(dev, dt)
+    wk = glu_pack_rows(wg[: I2 // 2], wg[I2 // 2:])
+    wkt = ops.pack_decode_tiles(wk)
+    y32 = ops.gemv(xt, wk, act="silu", glu=True, w_tiles=wkt, out_dtype=torch.float32)
+    yp = ops.gemv(xt, wk, act="silu", glu=True, w_tiles=wkt, y_tiled=True, planes_out=True)
+    assert yp.planes == 2 and torch.equal(yp.dense(), split(y32))
+    # (b)
+    wo = (torch.randn(H, K, generator=g) / math.sqrt(K)).to(dev, dt)
+    res = torch.randn(M, H, generator=g).to(dev) * 3.0
+    gam = (1.0 + 0.5 * torch.randn(H, generator=g)).abs().clamp_min(0.2).to(dev)
+    ws = torch.zeros(16384 + 8 * 32 * H * 4, dtype=torch.uint8, device=dev)
+    for layout in ("t", "t20"):
+        kw = dict(w_tiles=ops.pack_decode_tiles(wo), w_tiles20=ops.pack_decode_tiles20(wo) if layout == "t20" else None, workspace=ws)
+        y_plain = ops.gemv(xt, wo, residual=res, out_dtype=torch.float32, **kw)
+        y, x16, ssq = ops.gemv(xt, wo, residual=res, out_dtype=torch.float32, emit_norm=True, planes_out=True, norm_gamma=gam, **kw)
+        assert torch.equal(y, y_plain) and x16.planes == 2 and ssq.shape[0] == 16 and ssq.shape[1] % 64 == 0
+        assert torch.equal(x16.dense(), split(y * gam))
+        assert relerr(ssq[:M].sum(1), y.double().pow(2).sum(1)) < 1e-6
+        # (c)
+        wq = (torch.randn(1536, H, generator=g) / math.sqrt(H)).to(dev, dt)
+        out = ops.gemv(x16, wq, w_tiles=ops.pack_decode_tiles(wq), out_dtype=torch.float32, ssq_in=(ssq, H, 1e-5))
+        yd = y.double()
+        ref = (x16.dense().double() * torch.rsqrt(yd.pow(2).mean(-1, keepdim=True) + 1e-5)) @ wq.double().T
+        e = relerr(out, ref)
+        print(f"precise RMSNorm fold {dt} M={M} {layout}: consumer vs fp64 {e:.2e}")
+        assert e < 2e-6
+        # against LlamaRMSNorm itself (planes of the normalised row through the un-folded path): the two orders of rounding agree to the planes' precision
+        h, _ = ops.rmsnorm_planes(y, gam, 1e-5, dt, tiled=True)
+        out2 = ops.gemv(h, wq, w_tiles=ops.pack_decode_tiles(wq), out_dtype=torch.float32)
+        assert relerr(out, out2) < (3e-6 if dt == torch.float16 else 4e-5)
+
+
+@pytest.mark.parametrize("dt", DTS)
 def test_rope_kv_append_f32(dev, dt):
     from seedx_amd import ops
     G, T, H, D, Tmax = 3, 5, 2, 128, 64
