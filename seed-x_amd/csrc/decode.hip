@@ -906,7 +906,7 @@ using namespace sxk_decode;
 #define ST ((hipStream_t)stream)
 static int g_skinny_var[3] = {0, 0, 0};  // tuning hook (sx_gemv_tune): [2] = split-K factor (0 auto, -1 never, 2 / 4 / 8 forced)
 extern "C" int sx_gemv_tune(int key, int value) {
-  SX_CHECK((key == 2 && (value == -1 || value == 0 || value == 1 || value == 2 || value == 4 || value == 8)) || (key == 1 && (value == 0 || value == 1)),
+  SX_CHECK((key == 2 && (value == -1 || value == 0 || value == 1 || value == 2 || value == 4 || value == 8)) || (key == 1 && (value == 0 || value == 1 || value == 2)),
            "sx_gemv_tune: key %d value %d", key, value);
   g_skinny_var[key] = value;
   return SX_OK;
@@ -984,7 +984,8 @@ extern "C" int sx_gemv(const sx_gemv_args* a, void* stream) {
         if (tail20) hipLaunchKernelGGL((gemm_skinny_kernel<TT, 2, 4, 4, true, 2>), grid, dim3(256), 0, ST, p);   \
         else if (r2) hipLaunchKernelGGL((gemm_skinny_kernel<TT, 2, 4, 4, false, 2>), grid, dim3(256), 0, ST, p); \
         else hipLaunchKernelGGL((gemm_skinny_kernel<TT, 1, 4, 4, false, 2>), grid, dim3(256), 0, ST, p);         \
-      } else if (tail20) hipLaunchKernelGGL((gemm_skinny_kernel<TT, 2, 4, 2, true, 2>), grid, dim3(256), 0, ST, p); \
+      } else if (tail20 && g_skinny_var[1] == 2) hipLaunchKernelGGL((gemm_skinny_kernel<TT, 2, 4, 4, true, 2>), grid, dim3(256), 0, ST, p); \
+      else if (tail20) hipLaunchKernelGGL((gemm_skinny_kernel<TT, 2, 4, 2, true, 2>), grid, dim3(256), 0, ST, p); \
       else if (r2) hipLaunchKernelGGL((gemm_skinny_kernel<TT, 2, 4, 2, false, 2>), grid, dim3(256), 0, ST, p);   \
       else hipLaunchKernelGGL((gemm_skinny_kernel<TT, 1, 4, 4, false, 2>), grid, dim3(256), 0, ST, p);           \
     } else if (tail20) hipLaunchKernelGGL((gemm_skinny_kernel<TT, 2, 4, 4, true>), grid, dim3(256), 0, ST, p); \

@@ -3,7 +3,7 @@
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
 cd $R
-timeout 420 bash tools/r4_pmc_unet.sh fp16 > $O/r4_pmc_unet.out 2>&1; head -c 400 $O/r4_unet_pmc_traffic.json; echo
+timeout 420 bash tools/pmc_unet.sh fp16 > $O/r4_pmc_unet.out 2>&1; head -c 400 $O/r4_unet_pmc_traffic.json; echo
 [ -s $O/r4_unet_pmc_traffic.json ] && cp $O/r4_unet_pmc_traffic.json profiles/r4_unet_pmc_traffic.json
 timeout 400 python bench.py --steps 5 --warmup 2 > $O/r4_bench_line_head.json 2> $O/r4_bench_line_head.err; echo "bench rc=$?"; head -c 600 $O/r4_bench_line_head.json; echo
 cd /tmp && export TMPDIR=/tmp

@@ -4,7 +4,7 @@
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
 cd $R
-bash tools/r4_pmc_unet.sh fp16 > $O/r4_pmc_unet.out 2>&1; head -c 600 $O/r4_unet_pmc_traffic.json; echo
+bash tools/pmc_unet.sh fp16 > $O/r4_pmc_unet.out 2>&1; head -c 600 $O/r4_unet_pmc_traffic.json; echo
 cp $O/r4_unet_pmc_traffic.json profiles/r4_unet_pmc_traffic.json       # bench.py reads profiles/ (same box, same sources)
 python bench.py --steps 5 --warmup 2 > $O/r4_bench_line.json 2> $O/r4_bench_line.err; head -c 400 $O/r4_bench_line.json; echo
 cd /tmp && export TMPDIR=/tmp

@@ -1,5 +1,5 @@
 #!/bin/bash
-# configs 1, 2, 5 at HEAD (3 and 4: tools/r4_run16.sh)
+# configs 1, 2, 5 at HEAD (3 and 4: tools/runs/r4_run16.sh)
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
 cd $R
