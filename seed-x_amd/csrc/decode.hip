@@ -117,6 +117,11 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvP p) {
 // (o-proj 3.4 TB/s); as 256 groups of 20 every CU streams the same bytes and no cross-workgroup reduction is needed.
 __device__ const unsigned g_zero_line[16] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
 
+// the hi plane of an fp16 pair saturates at the largest finite value (csrc/precise.hip split1 does the same): the remainder travels in lo
+__device__ __forceinline__ f32x4_t sat_f16(f32x4_t x) {
+  return (f32x4_t){__builtin_amdgcn_fmed3f(x[0], -65504.f, 65504.f), __builtin_amdgcn_fmed3f(x[1], -65504.f, 65504.f),
+                   __builtin_amdgcn_fmed3f(x[2], -65504.f, 65504.f), __builtin_amdgcn_fmed3f(x[3], -65504.f, 65504.f)};
+}
 // lo plane of four fp32 values whose hi plane (two packed dwords) is `hi`: rn16(x - float(hi)), same element type
 __device__ __forceinline__ u32x2_t lo_plane(f32x4_t x, u32x2_t hi, bool bf16) {
   u32x2_t lo;
@@ -388,6 +393,7 @@ __global__ __launch_bounds__(NWV * 64) void gemm_skinny_kernel(const GemvP p) {
       if (p.y_tiled) {      // 16-bit operand tiles [ncols/32][16][32] for the next skinny GEMM (x_layout = 1)
         u32x2_t w2;
         if (p.out_dtype == SX_BF16) { w2[0] = pack2<BF16>(o[0], o[1]); w2[1] = pack2<BF16>(o[2], o[3]); }
+        else if (p.out_planes) { const f32x4_t oc = sat_f16(o); w2[0] = pack2<F16>(oc[0], oc[1]); w2[1] = pack2<F16>(oc[2], oc[3]); }   // hi saturates, lo carries the rest
         else { w2[0] = pack2<F16>(o[0], o[1]); w2[1] = pack2<F16>(o[2], o[3]); }
         unsigned short* yt = (unsigned short*)p.y + tblk + (size_t)(col >> 5) * 512 + (size_t)r * 32 + (col & 31);
         *(u32x2_t*)yt = w2;
@@ -399,6 +405,7 @@ __global__ __launch_bounds__(NWV * 64) void gemm_skinny_kernel(const GemvP p) {
           if (p.x16_gamma) og = o * *(const f32x4_t*)(p.x16_gamma + col);
           u32x2_t w2;
           if (std::is_same<TT, BF16>::value) { w2[0] = pack2<BF16>(og[0], og[1]); w2[1] = pack2<BF16>(og[2], og[3]); }
+          else if (p.out_planes) { const f32x4_t oc = sat_f16(og); w2[0] = pack2<F16>(oc[0], oc[1]); w2[1] = pack2<F16>(oc[2], oc[3]); }
           else { w2[0] = pack2<F16>(og[0], og[1]); w2[1] = pack2<F16>(og[2], og[3]); }
           unsigned short* xt = p.x16_out + tblk + (size_t)(col >> 5) * 512 + (size_t)r * 32 + (col & 31);
           *(u32x2_t*)xt = w2;

@@ -13,9 +13,12 @@
 
 namespace sxk_precise {
 
+// hi saturates at the largest finite fp16 (a value beyond 65504 would round to inf and make lo = -inf): the remainder then travels in lo, so
+// the pair stays exact-ish up to 2 x 65504 — real Llama checkpoints have "massive activation" channels in the thousands, not beyond. bf16 has
+// the fp32 exponent range: the clamp never binds there.
 template <typename TT>
 __device__ __forceinline__ void split1(float x, unsigned short& hi, unsigned short& lo) {
-  hi = TT::from_f32(x);
+  hi = TT::from_f32(__builtin_amdgcn_fmed3f(x, -65504.f, 65504.f));
   lo = TT::from_f32(x - TT::to_f32(hi));
 }
 

@@ -48,6 +48,11 @@ def test_split16_bit_exact_both_layouts(dev, dt):
     assert torch.equal(y2[:, :256], h2) and torch.equal(y2[:, 256:], l2)
     # the planes carry >= 19 (fp16: 21) bits of the fp32 value
     assert relerr(y[:, :256].float() + y[:, 256:].float(), x) < (3e-6 if dt == torch.float16 else 2e-5)
+    # beyond the fp16 range the hi plane saturates at 65504 and the remainder travels in lo (no inf / NaN up to 2 x 65504)
+    big = torch.tensor([[1.0e5, -9.0e4, 65504.0, 7.0e4, 3.0, -65520.0, 1.2e5, 0.0]], device=dev).repeat(2, 4)
+    yb = ops.split16(big, dt)
+    rec = yb[:, :32].float() + yb[:, 32:].float()
+    assert torch.isfinite(rec).all() and relerr(rec, big) < (5e-4 if dt == torch.float16 else 2e-5)
 
 
 @pytest.mark.parametrize("dt", DTS)
