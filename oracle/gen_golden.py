@@ -352,6 +352,52 @@ def lvlm_case_inputs(name, gold):
     return kw
 
 
+LLAMA16_TOKS = [17, 44, 301]
+
+
+def run_reference_llama_ckpt16():
+    """The reference's LlamaForCausalLM on the weights a 16-bit checkpoint holds and with the RoPE tables it uses when its scripts run it in
+    16 bit — executed in fp32 on the CPU: the ground truth of the decoder's precise mode at north_star's 1e-3 (tests/golden/
+    llama_mini_ckpt16.npz). The reference casts cos / sin to the activation dtype on every call (modeling_llama_xformer.py:128-131); here the
+    module runs in fp32, so the rounded tables are put into its `cos_cached` / `sin_cached` buffers (values, not code: what an fp16 / bf16
+    run of the same module multiplies with)."""
+    from transformers import LlamaConfig
+    mods = refshim.reference_modules()
+    cfg = weights.MINI_LLM
+    out = {}
+    x = torch.randn(1, 21, cfg["hidden_size"], generator=torch.Generator().manual_seed(3030)) * 0.5
+    out["x"] = x
+    out["toks"] = np.array(LLAMA16_TOKS)
+    with torch.no_grad():
+        for tag, dt in (("fp16", torch.float16), ("bf16", torch.bfloat16)):
+            sd = {k: v.to(dt).float() for k, v in weights.llama_sd(cfg).items()}
+            llm = mods["LlamaForCausalLM"](LlamaConfig(**cfg)).eval()
+            full = dict(llm.state_dict())
+            full.update(sd)
+            llm.load_state_dict(full, strict=True)
+            for layer in llm.model.layers:
+                re = layer.self_attn.rotary_emb
+                re.cos_cached.copy_(re.cos_cached.to(dt).float())
+                re.sin_cached.copy_(re.sin_cached.to(dt).float())
+            T = x.shape[1]
+            o = llm(inputs_embeds=x, attention_mask=torch.ones(1, T, dtype=torch.long), use_cache=True, output_hidden_states=True,
+                    return_dict=True)
+            out[tag + ".logits"], out[tag + ".hidden"] = o.logits, o.hidden_states[-1]
+            pkv, steps = o.past_key_values, []
+            for i, t in enumerate(LLAMA16_TOKS):
+                o = llm(input_ids=torch.tensor([[t]]), attention_mask=torch.ones(1, T + 1 + i, dtype=torch.long), past_key_values=pkv,
+                        use_cache=True, return_dict=True)
+                pkv = o.past_key_values
+                steps.append(o.logits[0, -1])
+            out[tag + ".step_logits"] = torch.stack(steps)
+    return {"llama_mini_ckpt16.npz": out}
+
+
+def main_llama16():
+    for name, arrs in run_reference_llama_ckpt16().items():
+        _save(name, **arrs)
+
+
 def main_generate():
     for name, arrs in run_reference_generate().items():
         _save(name, **arrs)
@@ -370,7 +416,11 @@ if __name__ == "__main__":
     if "--generate-only" in sys.argv:
         main_generate()
         raise SystemExit(0)
+    if "--llama16-only" in sys.argv:
+        main_llama16()
+        raise SystemExit(0)
     if "--detok-only" not in sys.argv:
         main()
         main_generate()
+        main_llama16()
     main_detok()

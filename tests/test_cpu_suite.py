@@ -49,6 +49,22 @@ def test_oracle_llama_matches_golden():
     assert _rel(l2, g["logits2"]) < 2e-5 and _rel(h2, g["hidden2"]) < 2e-5
 
 
+@pytest.mark.parametrize("tag,dt", [("fp16", torch.float16), ("bf16", torch.bfloat16)])
+def test_oracle_llama_matches_ckpt16_golden(tag, dt):
+    """tests/golden/llama_mini_ckpt16.npz = the reference's LlamaForCausalLM on 16-bit-representable weights with the RoPE tables of a 16-bit
+    run, executed in fp32 (oracle/gen_golden.py run_reference_llama_ckpt16): the oracle with table_dtype reproduces it — prefill of 21
+    positions and 3 cached decode steps."""
+    gold = np.load(os.path.join(GOLD, "llama_mini_ckpt16.npz"))
+    cfg = weights.MINI_LLM
+    sd = {k: v.to(dt).float() for k, v in weights.llama_sd(cfg).items()}
+    x = torch.from_numpy(gold["x"])
+    logits, past, hn = restated.llama_forward(sd, cfg, x, table_dtype=dt)
+    assert _rel(logits, torch.from_numpy(gold[tag + ".logits"])) < 2e-5 and _rel(hn, torch.from_numpy(gold[tag + ".hidden"])) < 2e-5
+    for i, t in enumerate(gold["toks"].tolist()):
+        l2, past, _ = restated.llama_forward(sd, cfg, sd["model.embed_tokens.weight"][torch.tensor([[t]])], past, table_dtype=dt)
+        assert _rel(l2[0, -1], torch.from_numpy(gold[tag + ".step_logits"][i])) < 2e-5
+
+
 def test_oracle_logits_rule_matches_golden():
     g = _gold("logits_rule.npz")
     ids = list(range(400, 466))

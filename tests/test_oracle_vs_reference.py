@@ -55,6 +55,18 @@ def test_llama_prefill_and_decode_match_reference():
     assert _rel(l2, o2.logits) < 2e-5 and _rel(h2, o2.hidden_states[-1]) < 2e-5
 
 
+def test_llama_ckpt16_fixture_reproduces_from_the_live_reference():
+    """tests/golden/llama_mini_ckpt16.npz is what the reference's own module computes (gen_golden.run_reference_llama_ckpt16 re-run here)."""
+    import os
+    import numpy as np
+    from oracle import gen_golden as gg
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "llama_mini_ckpt16.npz"))
+    live = gg.run_reference_llama_ckpt16()["llama_mini_ckpt16.npz"]
+    for k in gold.files:
+        a = live[k].detach().numpy() if torch.is_tensor(live[k]) else np.asarray(live[k])
+        assert a.shape == gold[k].shape and np.allclose(a, gold[k], rtol=1e-5, atol=1e-6), k
+
+
 def test_logits_rule_matches_reference_processor():
     """generation.py:19-31 with a fake tokenizer whose image-token ids are 400..465."""
     cls = refshim.reference_modules()["AutoImageTokenGenerationProcessor"]
