@@ -10,6 +10,7 @@
 // and the softmax bookkeeping must not be re-associated.
 // Reference being matched: modeling_llama_xformer.py:95 (RMSNorm), :141-149 (RoPE), :204-239 (attention), run by the fp32 oracle.
 #include "sx_common.h"
+#include <type_traits>
 
 namespace sxk_precise {
 
@@ -18,7 +19,7 @@ namespace sxk_precise {
 // the fp32 exponent range: the clamp never binds there.
 template <typename TT>
 __device__ __forceinline__ void split1(float x, unsigned short& hi, unsigned short& lo) {
-  hi = TT::from_f32(__builtin_amdgcn_fmed3f(x, -65504.f, 65504.f));
+  hi = TT::from_f32(std::is_same<TT, F16>::value ? __builtin_amdgcn_fmed3f(x, -65504.f, 65504.f) : x);
   lo = TT::from_f32(x - TT::to_f32(hi));
 }
 
