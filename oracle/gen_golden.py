@@ -393,8 +393,38 @@ def run_reference_llama_ckpt16():
     return {"llama_mini_ckpt16.npz": out}
 
 
+def run_reference_modules_ckpt16():
+    """ViT (both head dims), the LLM-side Resampler and ResamplerXLV2 of the reference, executed in fp32 on the weights a 16-bit (fp16)
+    checkpoint holds (tests/golden/modules_mini_ckpt16.npz): the same modules as vit_hd*.npz / resampler_mini.npz / xlv2_mini.npz, without the
+    0.8-1.2e-3 that rounding fp32 fixture weights to fp16 costs — so that the HIP modules are compared with the REFERENCE's numbers at
+    north_star's tolerance."""
+    mods = refshim.reference_modules()
+    r16 = lambda sd: {k: v.to(torch.float16).float() for k, v in sd.items()}
+    g = torch.Generator().manual_seed(4040)
+    out = {}
+    with torch.no_grad():
+        for tag, cfg in (("vit_hd128", weights.MINI_VIT), ("vit_hd104", weights.MINI_VIT_104)):
+            m = mods["VisionTransformerWithAttnPool"](**cfg).eval()
+            m.load_state_dict(r16(weights.vit_sd(cfg)), strict=True)
+            x = torch.randn(2, 3, cfg["image_size"], cfg["image_size"], generator=g)
+            out[tag + ".x"], out[tag + ".y"] = x, m(x).float()
+        r = mods["Resampler"](grid_size=4, embed_dim=320, num_heads=2, kv_dim=256).eval()
+        r.load_state_dict(r16(weights.resampler_sd(weights._g(7), "", 4, 320, 256)), strict=True)
+        x = torch.randn(2, 16, 256, generator=g)
+        out["resampler.x"], out["resampler.y"] = x, r(x)
+        cfgx = weights.MINI_XLV2
+        m = mods["ResamplerXLV2"](normalize=False, **cfgx).eval()
+        m.load_state_dict(r16(weights.xlv2_sd(cfgx, pre="")), strict=True)
+        x = torch.randn(2, 24, cfgx["embedding_dim"], generator=g)
+        out["xlv2.x"] = x
+        out["xlv2.prompt"], out["xlv2.pooled"] = m(x)
+    return {"modules_mini_ckpt16.npz": out}
+
+
 def main_llama16():
     for name, arrs in run_reference_llama_ckpt16().items():
+        _save(name, **arrs)
+    for name, arrs in run_reference_modules_ckpt16().items():
         _save(name, **arrs)
 
 

@@ -83,6 +83,20 @@ def test_oracle_resamplers_match_golden():
     assert _rel(pe, g["prompt"]) < 2e-5 and _rel(pooled, g["pooled"]) < 2e-5
 
 
+def test_oracle_modules_match_ckpt16_golden():
+    """tests/golden/modules_mini_ckpt16.npz (the reference's ViT / Resampler / ResamplerXLV2 in fp32 on fp16-representable weights): the oracle
+    on the same rounded weights reproduces it."""
+    g = _gold("modules_mini_ckpt16.npz")
+    r16 = lambda sd: {k: v.to(torch.float16).float() for k, v in sd.items()}
+    for tag, cfg in (("vit_hd128", weights.MINI_VIT), ("vit_hd104", weights.MINI_VIT_104)):
+        assert _rel(restated.vit_forward(r16(weights.vit_sd(cfg)), cfg, g[tag + ".x"]), g[tag + ".y"]) < 2e-5
+    sd = r16(weights.resampler_sd(weights._g(7), "", 4, 320, 256))
+    assert _rel(restated.resampler_forward(sd, "", g["resampler.x"], 2, 1e-5), g["resampler.y"]) < 2e-5
+    cfg = weights.MINI_XLV2
+    pe, pooled = restated.resampler_xlv2_forward(r16(weights.xlv2_sd(cfg, pre="")), cfg, g["xlv2.x"], pre="")
+    assert _rel(pe, g["xlv2.prompt"]) < 2e-5 and _rel(pooled, g["xlv2.pooled"]) < 2e-5
+
+
 @pytest.mark.parametrize("name", ["comp2", "t2i", "anyres5", "truncated"])
 def test_oracle_lvlm_generate_matches_reference_executed_golden(name):
     """oracle/restated.lvlm_generate (+ greedy_generate, logits_rule) against tests/golden/lvlm_generate_mini.npz = the

@@ -65,6 +65,11 @@ def test_llama_ckpt16_fixture_reproduces_from_the_live_reference():
     for k in gold.files:
         a = live[k].detach().numpy() if torch.is_tensor(live[k]) else np.asarray(live[k])
         assert a.shape == gold[k].shape and np.allclose(a, gold[k], rtol=1e-5, atol=1e-6), k
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "modules_mini_ckpt16.npz"))
+    live = gg.run_reference_modules_ckpt16()["modules_mini_ckpt16.npz"]
+    for k in gold.files:
+        a = live[k].detach().numpy() if torch.is_tensor(live[k]) else np.asarray(live[k])
+        assert a.shape == gold[k].shape and np.allclose(a, gold[k], rtol=1e-5, atol=1e-6), k
 
 
 def test_logits_rule_matches_reference_processor():
