@@ -17,10 +17,6 @@ import torch.nn.functional as F
 SITES = ("n1", "q0", "k0", "q", "k", "v", "p", "ao", "n2", "glu", "lm")    # q0 / k0: the qkv GEMM's 16-bit output ahead of RoPE
 
 
-def r16(x, on, dt):
-    return x.to(dt).float() if on else x
-
-
 def r2(x, mode, dt):
     """mode 0: exact; 1: one 16-bit rounding; 2: hi + lo planes (both 16-bit, lo flushed to zero when subnormal like a denorm-flushing MFMA)."""
     if mode == 0:
