@@ -150,51 +150,61 @@ struct AttnF32P {
 };
 
 // QB query rows per workgroup: 4 for the decode step and short chunks, 8 for prefill (every key row is loaded once per QB rows: the
-// K / V re-reads from L2 halve — 1.5k-token prompts, BASELINE config 5)
-template <typename TT, int QB>
+// K / V re-reads from L2 halve — 1.5k-token prompts, BASELINE config 5). DC = 8-dim chunks per lane: 1 covers D <= 128 (16 lanes x 8),
+// 2 covers D <= 256 (lane dl owns dims [8 dl, 8 dl + 8) and [128 + 8 dl, 128 + 8 dl + 8): the LLM-side resamplers' head_dim 160).
+template <typename TT, int QB, int DC>
 __global__ __launch_bounds__(256) void attn_f32_kernel(const AttnF32P p) {
-  __shared__ float red[4][QB][132];
+  constexpr int DW = 8 * DC, DMAX = 128 * DC;
+  __shared__ float red[4][QB][DMAX + 4];
   const int q0 = blockIdx.x * QB, h = blockIdx.y, g = blockIdx.z, D = p.D;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int grp = wave * 4 + (lane >> 4), dl = lane & 15;
-  const bool dvalid = dl * 8 < D;
+  bool dvalid[DC];
+#pragma unroll
+  for (int c = 0; c < DC; ++c) dvalid[c] = c * 128 + dl * 8 < D;
   int pos0 = p.causal ? p.pos0_dev[g] : p.Tmax;   // not causal: every row sees all Tmax keys
   if (pos0 < 0) pos0 = 0;
   const int nq = min(QB, p.T - q0);
-  float qv[QB][8], o[QB][8], m_run[QB], l_run[QB];
+  float qv[QB][DW], o[QB][DW], m_run[QB], l_run[QB];
 #pragma unroll
   for (int i = 0; i < QB; ++i) {
     m_run[i] = -INFINITY;
     l_run[i] = 0.f;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { qv[i][e] = 0.f; o[i][e] = 0.f; }
-    if (i < nq && dvalid) {
-      const float* qr = p.q + (size_t)((size_t)g * p.T + q0 + i) * p.q_stride + (size_t)h * D + dl * 8;
-      const f32x4_t a = *(const f32x4_t*)qr, b = *(const f32x4_t*)(qr + 4);
+    for (int e = 0; e < DW; ++e) { qv[i][e] = 0.f; o[i][e] = 0.f; }
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { qv[i][e] = a[e] * p.scale; qv[i][4 + e] = b[e] * p.scale; }
+    for (int c = 0; c < DC; ++c) {
+      if (i < nq && dvalid[c]) {
+        const float* qr = p.q + (size_t)((size_t)g * p.T + q0 + i) * p.q_stride + (size_t)h * D + c * 128 + dl * 8;
+        const f32x4_t a = *(const f32x4_t*)qr, b = *(const f32x4_t*)(qr + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { qv[i][8 * c + e] = a[e] * p.scale; qv[i][8 * c + 4 + e] = b[e] * p.scale; }
+      }
     }
   }
   const float* kh = p.kc + (size_t)g * p.seq_stride + (size_t)h * p.head_stride;
   const float* vh = p.vc + (size_t)g * p.seq_stride + (size_t)h * p.head_stride;
   const int kend = min(p.Tmax, pos0 + q0 + nq);       // keys 0 .. kend-1 are visible to the block's last row
   for (int t = grp; t < kend; t += 16) {
-    float kf[8], vf[8];
+    float kf[DW], vf[DW];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { kf[e] = 0.f; vf[e] = 0.f; }
-    if (dvalid) {
-      const float* kr = kh + (size_t)t * p.row_stride + dl * 8;
-      const float* vr = vh + (size_t)t * p.row_stride + dl * 8;
-      const f32x4_t k0 = *(const f32x4_t*)kr, k1 = *(const f32x4_t*)(kr + 4);
-      const f32x4_t v0 = *(const f32x4_t*)vr, v1 = *(const f32x4_t*)(vr + 4);
+    for (int e = 0; e < DW; ++e) { kf[e] = 0.f; vf[e] = 0.f; }
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { kf[e] = k0[e]; kf[4 + e] = k1[e]; vf[e] = v0[e]; vf[4 + e] = v1[e]; }
+    for (int c = 0; c < DC; ++c) {
+      if (dvalid[c]) {
+        const float* kr = kh + (size_t)t * p.row_stride + c * 128 + dl * 8;
+        const float* vr = vh + (size_t)t * p.row_stride + c * 128 + dl * 8;
+        const f32x4_t k0 = *(const f32x4_t*)kr, k1 = *(const f32x4_t*)(kr + 4);
+        const f32x4_t v0 = *(const f32x4_t*)vr, v1 = *(const f32x4_t*)(vr + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { kf[8 * c + e] = k0[e]; kf[8 * c + 4 + e] = k1[e]; vf[8 * c + e] = v0[e]; vf[8 * c + 4 + e] = v1[e]; }
+      }
     }
 #pragma unroll
     for (int i = 0; i < QB; ++i) {
       float s = 0.f;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) s = fmaf(kf[e], qv[i][e], s);
+      for (int e = 0; e < DW; ++e) s = fmaf(kf[e], qv[i][e], s);
       s += __shfl_xor(s, 1, 64);
       s += __shfl_xor(s, 2, 64);
       s += __shfl_xor(s, 4, 64);
@@ -205,7 +215,7 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const AttnF32P p) {
         const float pr = __expf(s - m_new);
         l_run[i] = l_run[i] * alpha + pr;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[i][e] = fmaf(pr, vf[e], o[i][e] * alpha);
+        for (int e = 0; e < DW; ++e) o[i][e] = fmaf(pr, vf[e], o[i][e] * alpha);
         m_run[i] = m_new;
       }
     }
@@ -221,38 +231,41 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const AttnF32P p) {
     lw += __shfl_xor(lw, 16, 64);
     lw += __shfl_xor(lw, 32, 64);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
+    for (int e = 0; e < DW; ++e) {
       float t = o[i][e] * sc;
       t += __shfl_xor(t, 16, 64);
       t += __shfl_xor(t, 32, 64);
       o[i][e] = t;
     }
     if ((lane >> 4) == 0) {
-      if (dvalid) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) red[wave][i][dl * 8 + e] = o[i][e];
+      for (int c = 0; c < DC; ++c) {
+        if (dvalid[c]) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) red[wave][i][c * 128 + dl * 8 + e] = o[i][8 * c + e];
+        }
       }
       if (dl == 0) {
-        red[wave][i][128] = mw;
-        red[wave][i][129] = lw;
+        red[wave][i][DMAX] = mw;
+        red[wave][i][DMAX + 1] = lw;
       }
     }
   }
   __syncthreads();
-  // thread → (row i, dim d): 256 threads cover QB * 128 outputs in QB * 128 / 256 passes
-  for (int idx = threadIdx.x; idx < QB * 128; idx += 256) {
-    const int i = idx >> 7, d = idx & 127;
+  // thread → (row i, dim d): 256 threads cover QB * DMAX outputs in QB * DMAX / 256 passes
+  for (int idx = threadIdx.x; idx < QB * DMAX; idx += 256) {
+    const int i = idx / DMAX, d = idx - i * DMAX;
     if (i >= nq || d >= D) continue;
     float mg = -INFINITY;
 #pragma unroll
-    for (int gg = 0; gg < 4; ++gg) mg = fmaxf(mg, red[gg][i][128]);
+    for (int gg = 0; gg < 4; ++gg) mg = fmaxf(mg, red[gg][i][DMAX]);
     float acc = 0.f, lsum = 0.f;
 #pragma unroll
     for (int gg = 0; gg < 4; ++gg) {
-      const float mgk = red[gg][i][128];
+      const float mgk = red[gg][i][DMAX];
       const float w = (mgk == -INFINITY) ? 0.f : __expf(mgk - mg);
       acc = fmaf(w, red[gg][i][d], acc);
-      lsum = fmaf(w, red[gg][i][129], lsum);
+      lsum = fmaf(w, red[gg][i][DMAX + 1], lsum);
     }
     const float val = lsum > 0.f ? acc / lsum : 0.f;
     unsigned short hi, lo;
@@ -333,7 +346,7 @@ extern "C" int sx_attention_f32(const sx_attn_f32_args* a, void* stream) {
   SX_CHECK(a && a->q && a->kcache && a->vcache && a->out && (a->pos0_dev || !a->causal), "sx_attention_f32: null pointer");
   const int tiled = (a->dtype & SX_TILED16) ? 1 : 0, dt = a->dtype & 0xff;
   SX_CHECK(dt == SX_F16 || dt == SX_BF16, "sx_attention_f32: dtype (of the output planes)");
-  SX_CHECK(a->D % 8 == 0 && a->D >= 8 && a->D <= 128, "sx_attention_f32: head_dim %d", a->D);
+  SX_CHECK(a->D % 8 == 0 && a->D >= 8 && a->D <= 256, "sx_attention_f32: head_dim %d (multiple of 8, <= 256)", a->D);
   SX_CHECK(a->G >= 1 && a->T >= 1 && a->H >= 1 && a->Tmax >= 1, "sx_attention_f32: G/T/H/Tmax");
   SX_CHECK(a->q_row_stride >= (int64_t)a->H * a->D && a->q_row_stride % 4 == 0 && (((uintptr_t)a->q) & 15) == 0, "sx_attention_f32: q_row_stride");
   SX_CHECK(!tiled || ((int64_t)a->G * a->T <= 16 && (a->H * a->D) % 32 == 0), "sx_attention_f32: operand tiles hold <= 16 rows, H*D %% 32 == 0");
@@ -345,14 +358,18 @@ extern "C" int sx_attention_f32(const sx_attn_f32_args* a, void* stream) {
   SX_CHECK(p.row_stride % 4 == 0 && p.head_stride % 4 == 0 && p.seq_stride % 4 == 0 && (((uintptr_t)a->kcache) & 15) == 0 &&
            (((uintptr_t)a->vcache) & 15) == 0, "sx_attention_f32: K / V strides and pointers must keep 16-B alignment");
   p.T = a->T; p.H = a->H; p.D = a->D; p.Tmax = a->Tmax; p.tiled = tiled; p.scale = a->scale; p.causal = a->causal ? 1 : 0;
-  if (a->T > 8) {
+  if (a->D > 128) {             // two 8-dim chunks per lane (the LLM-side resamplers' head_dim 160): 4 rows per workgroup
+    const dim3 grid((a->T + 3) / 4, a->H, a->G);
+    if (dt == SX_BF16) hipLaunchKernelGGL((attn_f32_kernel<BF16, 4, 2>), grid, dim3(256), 0, ST, p);
+    else hipLaunchKernelGGL((attn_f32_kernel<F16, 4, 2>), grid, dim3(256), 0, ST, p);
+  } else if (a->T > 8) {
     const dim3 grid((a->T + 7) / 8, a->H, a->G);
-    if (dt == SX_BF16) hipLaunchKernelGGL((attn_f32_kernel<BF16, 8>), grid, dim3(256), 0, ST, p);
-    else hipLaunchKernelGGL((attn_f32_kernel<F16, 8>), grid, dim3(256), 0, ST, p);
+    if (dt == SX_BF16) hipLaunchKernelGGL((attn_f32_kernel<BF16, 8, 1>), grid, dim3(256), 0, ST, p);
+    else hipLaunchKernelGGL((attn_f32_kernel<F16, 8, 1>), grid, dim3(256), 0, ST, p);
   } else {
     const dim3 grid((a->T + 3) / 4, a->H, a->G);
-    if (dt == SX_BF16) hipLaunchKernelGGL((attn_f32_kernel<BF16, 4>), grid, dim3(256), 0, ST, p);
-    else hipLaunchKernelGGL((attn_f32_kernel<F16, 4>), grid, dim3(256), 0, ST, p);
+    if (dt == SX_BF16) hipLaunchKernelGGL((attn_f32_kernel<BF16, 4, 1>), grid, dim3(256), 0, ST, p);
+    else hipLaunchKernelGGL((attn_f32_kernel<F16, 4, 1>), grid, dim3(256), 0, ST, p);
   }
   SX_HIP_LAUNCH_CHECK();
   return SX_OK;

@@ -64,6 +64,10 @@ class Resampler:
         self._sd = None
         self._packed = {}
         self.device, self.dtype = None, torch.float16
+        # fp32-grade activations (default; SX_RESAMPLER_PRECISE=0 for the plain 16-bit flow): two operand planes into the four GEMMs, fp32 K / V
+        # and attention (csrc/precise.hip). The input resampler's output IS the LLM's image-token input and the output resampler's output IS
+        # the de-tokenizer's conditioning: at one 16-bit rounding per operand each sat at 6-7e-4 of the fp32 reference on its own.
+        self.precise = os.environ.get("SX_RESAMPLER_PRECISE", "1") != "0"
 
     def parameter_names(self, prefix=""):
         names = ["pos_embed", "query", "attn.in_proj_weight", "attn.in_proj_bias", "attn.out_proj.weight",
@@ -125,6 +129,7 @@ class Resampler:
         q = ops.layernorm(f32(sd["query"]), f32(sd["ln_q.weight"]), f32(sd["ln_q.bias"]), self.eps, torch.float32)
         q = ops.add(q, f32(sd["pos_embed"]))
         P["q"] = ops.gemm(ops.cast(q, dt), w16(Win[:E]), bias=f32(bin_[:E]))       # [nq, E] 16-bit
+        P["q32"] = ops.gemm(ops.split16(q, dt), w16(Win[:E]), a_planes=2, bias=f32(bin_[:E]), out_dtype=torch.float32)   # precise mode
         self._packed[key] = P
         return P
 
@@ -135,6 +140,18 @@ class Resampler:
         P = self._pack(n_kv)
         E, H = self.embed_dim, self.num_heads
         hd = E // H
+        if self.precise and hd % 8 == 0 and hd <= 256:
+            f32, dt, nq = torch.float32, self.dtype, self.num_queries
+            x2 = (x if x.dtype == f32 else ops.cast(x.contiguous(), f32)).reshape(B * n_kv, -1).contiguous()
+            if "kv_w" in P:
+                x2 = ops.gemm(ops.split16(x2, dt), P["kv_w"], a_planes=2, out_dtype=f32)
+            h = ops.layernorm(x2, P["ln_kv"][0], P["ln_kv"][1], self.eps, f32)
+            kv = ops.gemm(ops.split16(h, dt), P["kv_in_w"], a_planes=2, residual=P["kv_res"], res_mod=n_kv, out_dtype=f32)   # [B*n_kv, 2E] fp32
+            kv5 = kv.view(B, n_kv, 2, H, hd)
+            q4 = P["q32"].view(1, nq, H, hd).expand(B, nq, H, hd).contiguous()      # the shared queries, one copy per sample (small)
+            att = ops.attention_f32_full(q4, kv5[:, :, 0], kv5[:, :, 1], 1.0 / math.sqrt(hd), dt)            # planes [B*nq, 2E]
+            out = ops.gemm(att, P["out_w"], a_planes=2, bias=P["out_b"], out_dtype=f32)
+            return out.view(B, nq, E)
         x16 = x if x.dtype == self.dtype else ops.cast(x.contiguous(), self.dtype)
         x2 = x16.reshape(B * n_kv, -1)
         if "kv_w" in P:

@@ -229,7 +229,8 @@ def _attn_ref(q, kc, vc, pos, T, scale):
 
 
 @pytest.mark.parametrize("dt", DTS)
-@pytest.mark.parametrize("G,T,H,D,pos", [(3, 1, 4, 128, [0, 17, 130]), (2, 37, 2, 128, [0, 0]), (2, 9, 3, 64, [20, 3]), (1, 70, 2, 104, [5])])
+@pytest.mark.parametrize("G,T,H,D,pos", [(3, 1, 4, 128, [0, 17, 130]), (2, 37, 2, 128, [0, 0]), (2, 9, 3, 64, [20, 3]), (1, 70, 2, 104, [5]),
+                                         (2, 11, 2, 160, [7, 0]), (1, 5, 1, 256, [40])])
 def test_attention_f32(dev, dt, G, T, H, D, pos):
     from seedx_amd import ops
     Tmax = 256
@@ -255,7 +256,7 @@ def test_attention_f32_full_strided_kv(dev, dt):
     """Non-causal mode with K / V as strided views of one fused projection output (ResamplerXLV2's PerceiverAttention / AttentionPool2d)."""
     from seedx_amd import ops
     g = torch.Generator().manual_seed(9)
-    for (B, Sq, Skv, H, D) in [(2, 16, 52, 2, 64), (3, 1, 17, 4, 64), (2, 64, 128, 16, 64)]:
+    for (B, Sq, Skv, H, D) in [(2, 16, 52, 2, 64), (3, 1, 17, 4, 64), (2, 64, 128, 16, 64), (2, 16, 36, 2, 160), (1, 64, 256, 32, 160)]:
         q = torch.randn(B, Sq, H, D, generator=g).to(dev)
         kv = torch.randn(B, Skv, 2, H, D, generator=g).to(dev)
         y = ops.attention_f32_full(q, kv[:, :, 0], kv[:, :, 1], 0.125, dt)
@@ -287,6 +288,28 @@ def test_resampler_xlv2_precise_vs_oracle(dev, dt, monkeypatch):
     tol = 1e-4 if dt == torch.float16 else 8e-4
     assert max(res["1"]) < tol
     assert max(res["0"]) < (2e-3 if dt == torch.float16 else 1.6e-2) and min(res["0"]) > 3 * max(res["1"])
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_resampler_precise_vs_oracle(dev, dt, monkeypatch):
+    """The 2-D perceiver Resampler (ViT attn_pool, ContinuousLVLM input / output resamplers) with fp32-grade activations (the default):
+    head_dim 160 (two 8-dim chunks per lane in the fp32 attention) and 128, against the fp32 oracle on 16-bit-representable weights."""
+    from seedx_amd.visual_encoder import Resampler
+    for (grid, E, heads, kv_dim, n_kv) in [(4, 320, 2, 256, 16), (4, 256, 2, 320, 36)]:
+        sd = {k: v.to(dt).float() for k, v in weights.resampler_sd(weights._g(7), "", grid, E, kv_dim).items()}
+        x = torch.randn(2, n_kv, kv_dim, generator=torch.Generator().manual_seed(12))
+        ref = restated.resampler_forward(sd, "", x, heads, 1e-5)
+        res = {}
+        for mode in ("1", "0"):
+            monkeypatch.setenv("SX_RESAMPLER_PRECISE", mode)
+            r = Resampler(grid, E, heads, kv_dim=kv_dim)
+            assert r.precise == (mode == "1")
+            r.load_state_dict(sd)
+            r.to(dev, dt)
+            res[mode] = relerr(r(x.to(dev)), ref)
+        print(f"Resampler E={E} hd={E // heads} {dt}: precise {res['1']:.2e}, plain {res['0']:.2e}")
+        assert res["1"] < (1e-4 if dt == torch.float16 else 8e-4)
+        assert res["0"] < (2e-3 if dt == torch.float16 else 1.6e-2) and res["0"] > 3 * res["1"]
 
 
 # ---- model level ------------------------------------------------------------------------------------------------------
