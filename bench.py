@@ -45,7 +45,7 @@ FLOP_VAE_DECODE = 10.47e12   # SDXL VAE decoder at 128x128 latents (conv/linear/
 PARITY_BOUND = {
     "fp16": {
         "metric": "rel-L2 vs the fp32 oracle (oracle/restated*.py) on the same inputs; every row is an assert in the named GPU test",
-        "ViT-G/448 features, all 48 layers, B = 2 crops": {"asserted": 1e-3, "measured": 8.3e-4,
+        "ViT-G/448 features, all 48 layers, B = 2 crops": {"asserted": 1e-3, "measured": 3.2e-4, "measured_unrounded_fp32_weights": 8.1e-4,
                                                              "test": "tests/test_fulldepth_gpu.py::test_vit_g_48_layers"},
         "LLM logits (all positions) and final-norm states, all 40 layers at 13B dims: 165-token prefill, decode steps 1 / 64 / 128 "
         "(precise mode = the default up to 16 lock-step sequences)": {
@@ -54,9 +54,10 @@ PARITY_BOUND = {
             "asserted": 1e-3, "measured": 8.6e-4, "test": "tests/test_fullsize_gpu.py::test_unet_full_sdxl_forward, "
             "tests/test_fullsize2_gpu.py::test_unet_full_8ch_bc3_forward, ::test_full_size_50_step_t2i_loop_drift"},
         "config-0 generation at full size and depth, every stage against the oracle stage on the SAME inputs (ViT | resamplers + LLM | "
-        "ResamplerXLV2 + 50 UNet steps | VAE)": {"asserted": 1e-3, "measured": [8.5e-4, 6.7e-4, 8.9e-4, 4.3e-4],
+        "ResamplerXLV2 + 50 UNet steps | VAE), every module on the weights a 16-bit checkpoint holds": {
+            "asserted": 1e-3, "measured": [3.1e-4, 2.1e-4, 5.5e-4, 4.3e-4], "measured_unrounded_fp32_weights": [8.3e-4, 6.2e-4, 9.0e-4, 4.3e-4],
                                                   "test": "tests/test_fulldepth_gpu.py::test_config0_one_generation_end_to_end"},
-        "same generation, oracle chain on its OWN intermediates (the stages' errors compound)": {"asserted": 2.5e-3, "measured": 1.24e-3,
+        "same generation, oracle chain on its OWN intermediates (the stages' errors compound)": {"asserted": 2.5e-3, "measured": 5.5e-4,
                                                                                                "test": "same"},
         "SDXL VAE decode / encode at 1024 px (fp32-grade mode)": {"asserted": 1e-4, "measured": 2.0e-5,
                                                                   "test": "tests/test_fullsize2_gpu.py::test_vae_full_config_1024px"},
