@@ -242,16 +242,28 @@ def lvlm_cases(variant=0):
     return cases
 
 
-def _lvlm_weights():
+def _lvlm_weights(ckpt16=False):
+    """ckpt16: the weights a 16-bit (fp16) checkpoint holds — every tensor rounded to fp16-representable values (the `_ckpt16` fixtures)."""
     cfg = weights.MINI_LLM
-    return cfg, weights.llama_sd(cfg), weights.agent_sd(cfg, LVLM_VIT_DIM, in_grid=LVLM_GRID, out_grid=LVLM_GRID)
+    sd_llm, sd_agent = weights.llama_sd(cfg), weights.agent_sd(cfg, LVLM_VIT_DIM, in_grid=LVLM_GRID, out_grid=LVLM_GRID)
+    if ckpt16:
+        sd_llm = {k: v.to(torch.float16).float() for k, v in sd_llm.items()}
+        sd_agent = {k: v.to(torch.float16).float() for k, v in sd_agent.items()}
+    return cfg, sd_llm, sd_agent
 
 
-def _run_ref_generate(sd_llm, sd_agent, case):
-    """One call of the reference's ContinuousLVLM.generate (fp32, CPU). Returns its result dict + what llm.generate produced."""
+def _run_ref_generate(sd_llm, sd_agent, case, ckpt16=False):
+    """One call of the reference's ContinuousLVLM.generate (fp32, CPU). Returns its result dict + what llm.generate produced.
+    ckpt16: the RoPE tables of the reference's fp16 runs are put into its rotary buffers (see run_reference_llama_ckpt16)."""
     from oracle import hf_generate_shim as hs
     cfg = weights.MINI_LLM
     m = hs.build_reference_lvlm(cfg, sd_llm, sd_agent, LVLM_VIT_DIM, LVLM_GRID, LVLM_GRID, LVLM_HEADS)
+    if ckpt16:
+        with torch.no_grad():
+            for layer in m.llm.model.layers:
+                re = layer.self_attn.rotary_emb
+                re.cos_cached.copy_(re.cos_cached.to(torch.float16).float())
+                re.sin_cached.copy_(re.sin_cached.to(torch.float16).float())
     rec = {}
     inner = m.llm.generate
 
@@ -266,33 +278,33 @@ def _run_ref_generate(sd_llm, sd_agent, case):
     return out, rec
 
 
-def _aim_row(sd_llm, sd_agent, case):
+def _aim_row(sd_llm, sd_agent, case, ckpt16=False):
     """Re-aims ONE lm_head row so that the seeded random-weight model emits EOS / <img> as new token #step and not before:
     the minimum-norm row w with w·h_t = -4 for the final states h_t of the earlier steps and w·h_step = (that step's best
     logit) + 3, h_t taken from the reference's own run. Other rows are untouched, so the transcript before #step is too."""
     row, step = case["aim"]
-    _, rec = _run_ref_generate(sd_llm, sd_agent, dict(case, max_new_tokens=step + 1))
+    _, rec = _run_ref_generate(sd_llm, sd_agent, dict(case, max_new_tokens=step + 1), ckpt16)
     hs_ = torch.stack([rec["out"].hidden_states[t][-1][0, -1] for t in range(step + 1)])       # [step+1, H]
     tgt = torch.full((step + 1,), -4.0)
     tgt[step] = float(rec["out"].scores[step][0].max()) + 3.0
     w = torch.linalg.pinv(hs_.double()) @ tgt.double()
-    sd_llm["lm_head.weight"][row] = w.float()
+    sd_llm["lm_head.weight"][row] = w.float().to(torch.float16).float() if ckpt16 else w.float()    # (a checkpoint row is 16-bit too)
     return row, sd_llm["lm_head.weight"][row].clone()
 
 
-def run_reference_generate(max_variants=40):
+def run_reference_generate(max_variants=40, ckpt16=False):
     """{file: arrays}. Per case the input variant is advanced until every free arg-max of the reference's transcript wins by
     ≥ LVLM_MIN_GAP (so a 16-bit implementation is expected to reproduce the ids exactly); the chosen inputs travel in the fixture."""
     from oracle import hf_generate_shim as hs
-    cfg, sd_llm0, sd_agent = _lvlm_weights()
+    cfg, sd_llm0, sd_agent = _lvlm_weights(ckpt16)
     tok = hs.StubTokenizer()
     arrs = {}
     for name in lvlm_cases():
         for variant in range(max_variants):
             case = lvlm_cases(variant)[name]
             sd_llm = {k: v.clone() for k, v in sd_llm0.items()}
-            rows = dict([_aim_row(sd_llm, sd_agent, case)]) if case["aim"] is not None else {}
-            out, rec = _run_ref_generate(sd_llm, sd_agent, case)
+            rows = dict([_aim_row(sd_llm, sd_agent, case, ckpt16)]) if case["aim"] is not None else {}
+            out, rec = _run_ref_generate(sd_llm, sd_agent, case, ckpt16)
             o = rec["out"]
             top2 = torch.stack([torch.topk(s[0], 2).values for s in o.scores])
             gap, std = top2[:, 0] - top2[:, 1], torch.stack([s[0].std() for s in o.scores])
@@ -324,15 +336,15 @@ def run_reference_generate(max_variants=40):
         print(f"  {name}: variant {variant}, {len(seq) - n_in} new tokens {seq[n_in:].tolist()}, min free gap {float(gap[free].min()):.3f}, "
               f"text {out['text']!r}, images {out['num_gen_imgs']}")
         arrs.update({f"{name}.{k}": v for k, v in a.items()})
-    return {"lvlm_generate_mini.npz": arrs}
+    return {("lvlm_generate_mini_ckpt16.npz" if ckpt16 else "lvlm_generate_mini.npz"): arrs}
 
 
 LVLM_CASE_NAMES = ("comp2", "t2i", "anyres5", "truncated")
 
 
-def lvlm_case_weights(name, gold):
+def lvlm_case_weights(name, gold, ckpt16=False):
     """(cfg, sd_llm, sd_agent) of a committed case: the seeded weights + the fixture's re-aimed lm_head rows."""
-    cfg, sd_llm, sd_agent = _lvlm_weights()
+    cfg, sd_llm, sd_agent = _lvlm_weights(ckpt16)
     for k in gold.files:
         if k.startswith(name + ".lm_head_row_"):
             sd_llm["lm_head.weight"][int(k.rsplit("_", 1)[1])] = torch.as_tensor(np.asarray(gold[k]))
@@ -425,6 +437,8 @@ def main_llama16():
     for name, arrs in run_reference_llama_ckpt16().items():
         _save(name, **arrs)
     for name, arrs in run_reference_modules_ckpt16().items():
+        _save(name, **arrs)
+    for name, arrs in run_reference_generate(ckpt16=True).items():
         _save(name, **arrs)
 
 

@@ -97,14 +97,16 @@ def test_oracle_modules_match_ckpt16_golden():
     assert _rel(pe, g["xlv2.prompt"]) < 2e-5 and _rel(pooled, g["xlv2.pooled"]) < 2e-5
 
 
+@pytest.mark.parametrize("ckpt16", [False, True], ids=["fp32-weights", "ckpt16"])
 @pytest.mark.parametrize("name", ["comp2", "t2i", "anyres5", "truncated"])
-def test_oracle_lvlm_generate_matches_reference_executed_golden(name):
+def test_oracle_lvlm_generate_matches_reference_executed_golden(name, ckpt16):
     """oracle/restated.lvlm_generate (+ greedy_generate, logits_rule) against tests/golden/lvlm_generate_mini.npz = the
     reference's OWN ContinuousLVLM.generate / prepare_inputs_for_generation / AutoImageTokenGenerationProcessor executed over
-    the HF-4.30.2 greedy stand-in (oracle/hf_generate_shim.py): ids, per-step final hidden states, text, image features."""
+    the HF-4.30.2 greedy stand-in (oracle/hf_generate_shim.py): ids, per-step final hidden states, text, image features.
+    ckpt16: the second fixture (weights a 16-bit checkpoint holds, RoPE tables of the reference's fp16 runs), oracle with table_dtype."""
     from oracle import gen_golden as gg, hf_generate_shim as hs
-    gold = np.load(os.path.join(GOLD, "lvlm_generate_mini.npz"))
-    cfg, sd_llm, sd_agent = gg.lvlm_case_weights(name, gold)
+    gold = np.load(os.path.join(GOLD, "lvlm_generate_mini_ckpt16.npz" if ckpt16 else "lvlm_generate_mini.npz"))
+    cfg, sd_llm, sd_agent = gg.lvlm_case_weights(name, gold, ckpt16)
     kw = gg.lvlm_case_inputs(name, gold)
     tok = hs.StubTokenizer()
     nimg = kw["num_img_gen_tokens"]
@@ -113,7 +115,8 @@ def test_oracle_lvlm_generate_matches_reference_executed_golden(name):
     assert ids == gold[f"{name}.input_ids"].reshape(-1).tolist()
     out = restated.lvlm_generate(sd_llm, sd_agent, cfg, {"in_heads": 2, "out_heads": 2}, ids, kw.get("image_embeds"),
                                  kw.get("embeds_cmp_mask"), kw.get("ids_cmp_mask"), kw.get("patch_positions"), img_ids,
-                                 img_ids[0], img_ids[-1], kw["max_new_tokens"], nimg, eos_id=tok.eos_token_id, tokenizer=tok)
+                                 img_ids[0], img_ids[-1], kw["max_new_tokens"], nimg, eos_id=tok.eos_token_id, tokenizer=tok,
+                                 table_dtype=torch.float16 if ckpt16 else None)
     assert out["ids"] == gold[f"{name}.generate_ids"].tolist()
     assert out["text"] == str(gold[f"{name}.text"])
     assert out["has_img_output"] == bool(gold[f"{name}.has_img_output"]) and out["num_gen_imgs"] == int(gold[f"{name}.num_gen_imgs"])

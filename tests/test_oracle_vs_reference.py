@@ -172,6 +172,20 @@ def test_lvlm_generate_golden_is_reproducible():
         assert np.array_equal(gold[k], v), f"{k} differs from the committed fixture"
 
 
+def test_lvlm_generate_ckpt16_golden_is_reproducible():
+    """The same for tests/golden/lvlm_generate_mini_ckpt16.npz: the reference's generate() on the weights a 16-bit checkpoint holds, with the
+    RoPE tables of its fp16 runs (the fixture the HIP path is held to at north_star's 1e-3)."""
+    import os
+    import numpy as np
+    from oracle import gen_golden as gg
+    live = gg.run_reference_generate(ckpt16=True)["lvlm_generate_mini_ckpt16.npz"]
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lvlm_generate_mini_ckpt16.npz"))
+    assert set(live) == set(gold.files)
+    for k, v in live.items():
+        v = v.detach().numpy() if torch.is_tensor(v) else np.asarray(v)
+        assert np.array_equal(gold[k], v), f"{k} differs from the committed fixture"
+
+
 def test_generate_shim_drives_the_reference_hooks():
     """The stand-in must call the MODEL's own prepare_inputs_for_generation every step (step 0: inputs_embeds AND input_ids,
     later: the last id only, position = cumsum(mask) - 1) and hand the growing attention_mask back to it."""
