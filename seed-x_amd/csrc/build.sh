@@ -12,7 +12,7 @@ BASE="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result"
 FAST="-ffast-math -fno-finite-math-only"
 if [ "$FORCE" = 1 ]; then rm -f "$HERE"/.obj/*.o; fi
 pids=()
-for f in gemm gemm_pp norm attn elementwise decode preproc comm precise; do
+for f in gemm gemm_pp gemm_strip norm attn elementwise decode preproc comm precise; do
   src="$HERE/$f.hip"; obj="$HERE/.obj/$f.o"
   if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ "$HERE/sx_common.h" -nt "$obj" ] || [ "$HERE/gemm_common.h" -nt "$obj" ] || [ "$HERE/../../include/seedx_hip.h" -nt "$obj" ]; then
     extra="$FAST"

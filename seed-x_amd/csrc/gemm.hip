@@ -375,7 +375,7 @@ static const TileCfg kTiles[kNumTiles] = {
     {256, 320, false, 256, 13.32f, 0.01928f, 15.12f, 0.02173f}};
 
 inline int pick_tile(int M, int N, int K, bool glu, bool conv, int force, unsigned allow = 0x7f) {
-  if (force >= 0 && force < kNumTiles && (!glu || kTiles[force].glu_ok)) return force;
+  if (force >= 0 && force < kNumTiles && (!glu || kTiles[force].glu_ok)) return force;   // (force 9 = strip kernel: decided by the caller)
   int best = 2;
   float best_t = 1e30f;
   for (int c = 0; c < kNumTiles; ++c) {
@@ -394,6 +394,7 @@ inline int pick_tile(int M, int N, int K, bool glu, bool conv, int force, unsign
 using namespace sxk_gemm;
 
 static int g_force_tile = -1;
+static int g_use_strip = 1;       // 0 = the LayerNorm producers stay on the ping-pong tiles (A/B hook, sx_gemm_force_tile(500))
 namespace sxk_gemm { int g_use_pp = 1; }  // 0 = lock-step kernels only (A/B hook, sx_gemm_force_tile(200))
 extern "C" int sx_gemm_pick_tile(int M, int N, int K, int glu, int conv) {  // host-only: which tile config sx_gemm would use
   return sxk_gemm::pick_tile(M, N, K, glu != 0, conv != 0, -1, 0x1ff);
@@ -409,6 +410,7 @@ extern "C" int sx_gemm_force_tile(int cfg) {  // tuning / test hook: -1 = automa
   if (cfg >= 300 && cfg <= 364) { sxk_gemm::g_gm = cfg - 300; return SX_OK; }
   if (cfg >= 400 && cfg <= 409) { sxk_gemm::g_pp_variant = cfg - 400; return SX_OK; }
   if (cfg == 200 || cfg == 201) { sxk_gemm::g_use_pp = cfg - 200; return SX_OK; }
+  if (cfg == 500 || cfg == 501) { g_use_strip = cfg - 500; return SX_OK; }
   g_force_tile = cfg;
   return SX_OK;
 }
@@ -522,6 +524,11 @@ static int gemm_impl(const sx_gemm_args* a, double* gn_stats, int gn_groups, int
     allow = 1u << plain;
   }
   const int cfg = pick_tile(a->M, a->N, Kk, a->glu != 0, a->a_mode == SX_A_CONV3X3, g_force_tile, allow);
+  // LayerNorm producers (fp32 residual in, fp32 + 16-bit out, row sums): the persistent strip kernel when the launch has at least
+  // 3/4 of a strip per CU (fewer strips leave CUs idle that the one-tile-per-workgroup kernels would use) — forced tile 9 = always
+  if (p.ln_out && (g_force_tile == 9 || (g_use_strip && g_force_tile < 0 && a->M / 128 >= 192)) && strip_supported(p, a->a_mode))
+    return launch_strip(p, a->dtype, st);
+  SX_CHECK(g_force_tile != 9, "sx_gemm: forced strip kernel does not support this launch");
   if (cfg == 7 || cfg == 8) {
     // fused GroupNorm statistics: fp32 output of all N columns, whole 256-row tiles inside one sample, even channels per group
     if (gn_stats && a->out_dtype == SX_F32 && !a->glu && a->act == SX_ACT_NONE && p.n_valid == a->N && a->N % gn_groups == 0 &&

@@ -101,6 +101,11 @@ inline int plan_grid(GemmP& p, int BM, int BN, int xcd_2d, int gm_force) {
 int launch_pp(const GemmP& p, int dtype, int bn, int a_mode, hipStream_t st);
 bool pp_supported(const GemmP& p, int dtype, int bn, int a_mode);
 
+// persistent strip kernel of the fp32-residual LayerNorm producers (gemm_strip.hip): whole 128-row strips per workgroup, two
+// accumulator sets, residual loads / output stores under the main loop. strip_supported: the launch fits its contract.
+int launch_strip(const GemmP& p, int dtype, hipStream_t st);
+bool strip_supported(const GemmP& p, int a_mode);
+
 extern unsigned long long* g_dbg;
 extern int g_gm;
 extern int g_xcd_2d;

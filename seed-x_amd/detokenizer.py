@@ -237,6 +237,7 @@ class _DenoiseLoop:
         self._graph_key, self._graph, self._state = None, None, None
         self._ctx_static = None
         self.chains = 2                      # concurrent kernel chains per denoise step (1 = one serial chain)
+        self.stagger = int(os.environ.get("SX_CHAIN_STAGGER", "0"))   # chain c starts when chain c-1 has passed this many progress marks
         self._side = None
 
     def run(self, mode, latents_nchw, prompt_embeds, pooled, time_ids, scheduler, num_steps, guidance_scale,
@@ -260,7 +261,7 @@ class _DenoiseLoop:
         ts_dev = scheduler.timesteps.to(dev)
         sig_dev = scheduler.sigmas.to(dev)
         key = (mode, G, H, W, num_steps, float(guidance_scale), float(image_guidance_scale), tuple(prompt_embeds.shape),
-               tuple(pooled.shape), tuple(time_ids.shape), unet.dtype, str(dev), self.chains)
+               tuple(pooled.shape), tuple(time_ids.shape), unet.dtype, str(dev), self.chains, self.stagger)
         if self._state is None or self._graph_key != key:
             self._state = dict(lat=torch.empty((G, HW, Cl), dtype=torch.float32, device=dev),
                                scaled=torch.zeros((NB, HW, cin), dtype=torch.float32, device=dev),
@@ -298,7 +299,7 @@ class _DenoiseLoop:
 
         nloc = hi - lo
         chains = self.chains if (nloc % self.chains == 0 and nloc >= 2 * self.chains and unet.comm.world == 1) else 1
-        if chains > 1 and self._side is None:
+        if chains > 1 and (self._side is None or len(self._side) < chains - 1):
             self._side = [torch.cuda.Stream() for _ in range(chains - 1)]
 
         def step_body():
@@ -315,14 +316,25 @@ class _DenoiseLoop:
                 fork = torch.cuda.Event()
                 fork.record(main)
                 parts = []
+                # stagger: identical chains started together run the SAME kernel at the same time (two HBM-bound launches compete,
+                # two MFMA-bound ones share the power budget); started `stagger` progress marks apart, a chain's HBM-bound launches
+                # meet the other chain's MFMA-bound ones on the CU pool
+                started = [torch.cuda.Event() for _ in range(chains - 1)] if self.stagger > 0 else None
                 for c in range(chains):
                     sl = slice(lo + c * per, lo + (c + 1) * per)
                     cctx = [[kv[c * per:(c + 1) * per] for kv in per_t] for per_t in ctx]
                     st = main if c == 0 else self._side[c - 1]
                     if c:
                         st.wait_event(fork)
+                        if started is not None:
+                            st.wait_event(started[c - 1])
+                    hook = None
+                    if started is not None and c < chains - 1:
+                        def hook(i, ev=started[c], s_=st):
+                            if i == self.stagger:
+                                ev.record(s_)
                     with torch.cuda.stream(st):
-                        e = unet.forward_nhwc(S["scaled"][sl], temb[c * per:(c + 1) * per], cctx, per, H, W)
+                        e = unet.forward_nhwc(S["scaled"][sl], temb[c * per:(c + 1) * per], cctx, per, H, W, on_mark=hook)
                         ops.copy2d(e.view(-1, e.shape[-1]), eps[c * per:(c + 1) * per].view(-1, e.shape[-1]), 0)
                         parts.append(e)
                 for st in self._side[:chains - 1]:

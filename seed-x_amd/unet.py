@@ -60,6 +60,7 @@ class UNet2DConditionModel:
         self._sd, self._P = None, None
         self._ctx_key, self._ctx = None, None
         self._gn_arena, self._gn_next, self._n_gn_slots = None, 0, 64     # fused GroupNorm statistics slots per forward (47 used by SDXL)
+        self._on_mark, self._mark_i, self._trace = None, 0, None
         self._ln_ok = {}                                                   # (rows, width) → LayerNorm fold usable (ops.ln_fold_ok)
 
     @classmethod
@@ -330,7 +331,9 @@ class UNet2DConditionModel:
         else:
             sc = x.view(-1, Ci)
         st_out = self._gn_slot(B, HW)
-        return self._conv(h, B, Hc, Wc, r["w2"], bias=r["b2"], residual=sc, gn=st_out).view(B, -1, Co), st_out
+        out = self._conv(h, B, Hc, Wc, r["w2"], bias=r["b2"], residual=sc, gn=st_out).view(B, -1, Co)
+        self._mark(out)
+        return out, st_out
 
     def _transformer(self, t, x, B, ctx_kv, Hc, Wc, st_in=None):
         """Transformer2DModel with use_linear_projection [ext]. x: fp32 [B, HW, C] (this rank's rows of the Hc x Wc image);
@@ -358,6 +361,7 @@ class UNet2DConditionModel:
                 att = ops.attention(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], scale)
                 ln = rows(3 * k + 1)
                 hs = ops.gemm(att.view(-1, C), b["wo1"], bias=b["bo1"], residual=hs, out_dtype=torch.float32, ln_emit=ln)
+                self._mark(hs)
                 w, cs, bb = b["f2"]
                 q = ops.gemm(ln.x16, w, bias=bb, ln_apply=(ln, cs, 1e-5)).view(B, HW, heads, hd)
                 kv = ctx_kv[k]
@@ -371,6 +375,7 @@ class UNet2DConditionModel:
                 else:
                     ln = rows(3 * k + 3)
                     hs = ops.gemm(g, b["wff2"], bias=b["bff2"], residual=hs, out_dtype=torch.float32, ln_emit=ln)
+                self._mark(hs)
             st_out = self._gn_slot(B, HW)
             out = ops.gemm(hs, t["pout_w"], bias=t["pout_b"], residual=x.view(-1, C), out_dtype=torch.float32, gn=st_out)
             return out.view(B, HW, C), st_out
@@ -391,6 +396,7 @@ class UNet2DConditionModel:
                 kv = g.permute(1, 0, 2, 3, 4, 5).reshape(B, g.shape[0] * HW, 2, heads, hd).contiguous()
                 att = ops.attention(q, kv[:, :, 0], kv[:, :, 1], scale)
             hs = ops.gemm(att.view(-1, C), b["wo1"], bias=b["bo1"], residual=hs, out_dtype=torch.float32)
+            self._mark(hs)
             n = ops.layernorm(hs, b["n2"][0], b["n2"][1], 1e-5, dt)
             q = ops.gemm(n, b["wq2"]).view(B, HW, heads, hd)
             kv = ctx_kv[k]
@@ -400,6 +406,7 @@ class UNet2DConditionModel:
             g = ops.gemm(n, b["wff1"], bias=b["bff1"], act="gelu", glu=True)
             last = k == nb - 1
             hs = ops.gemm(g, b["wff2"], bias=b["bff2"], residual=hs, out_dtype=dt if last else torch.float32)
+            self._mark(hs)
         st_out = self._gn_slot(B, HW)
         out = ops.gemm(hs, t["pout_w"], bias=t["pout_b"], residual=x.view(-1, C), out_dtype=torch.float32, gn=st_out)
         return out.view(B, HW, C), st_out
@@ -448,10 +455,21 @@ class UNet2DConditionModel:
         emb = ops.gemm(a, P["ae2"][0], bias=P["ae2"][1], residual=e, out_dtype=torch.float32)
         return ops.gemm(ops.silu_cast(emb, dt), P["temb_w"], bias=P["temb_b"], out_dtype=torch.float32)
 
-    def forward_nhwc(self, x_in, temb_all, ctx, B, H, W):
+    def _mark(self, t=None):
+        """Progress mark of the running forward (after every resnet, in the middle and at the end of every transformer layer):
+        ``forward_nhwc(on_mark=f)`` calls f(i) at mark i — the denoise loop's staggered kernel chains record their start events there.
+        ``self._trace`` (a list, tools/determinism_trace.py): the residual stream at every mark is appended to it."""
+        if self._trace is not None and t is not None:
+            self._trace.append(t.detach().float().clone())
+        if self._on_mark is not None:
+            self._mark_i += 1
+            self._on_mark(self._mark_i)
+
+    def forward_nhwc(self, x_in, temb_all, ctx, B, H, W, on_mark=None):
         """x_in: fp32 [B, H*W, Cin] NHWC scaled latents → fp32 [B, H*W, 4] noise prediction. With a multi-rank ``comm`` every
         rank passes the full x_in, works on its H/tp pixel rows in between and returns the full (all-gathered) prediction."""
         P, dt, c = self._P, self.dtype, self.cfg
+        self._on_mark, self._mark_i = on_mark, 0
         cin = c["in_channels"]
         tp, rank = self.comm.world, self.comm.rank
         if tp > 1:
@@ -498,6 +516,7 @@ class UNet2DConditionModel:
                 st = None
         h = self._gn(x, P["norm_out"], 1e-5, True, Hc, Wc, stats=st)
         self._gn_arena = None
+        self._on_mark = None
         nv = 4 if c["out_channels"] == 4 else 0
         out = self._conv(h, B, Hc, Wc, P["conv_out_w"], bias=P["conv_out_b"], n_valid=nv)
         out = out.view(B, -1, out.shape[-1])

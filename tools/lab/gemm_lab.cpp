@@ -382,6 +382,143 @@ static void model_sweep() {
   }
 }
 
+// LayerNorm-producer launches (sx_gemm_ln: fp32 residual in, fp32 + 16-bit out, per-row sums): the persistent strip kernel
+// (forced tile 9) against the ping-pong producer epilogue (strip excluded: 500). C and x16 must agree bit for bit, the row sums
+// to fp32 summation noise (and with the fp64 sums of the stored C), repeated strip launches must reproduce EVERYTHING bit for bit.
+static int run_ln_case(const char* name, int M, int N, int K, int rounds, int iters_scale) {
+  std::vector<uint16_t> hA, hW;
+  fill_bf16(hA, (size_t)M * K, 1.0f);
+  fill_bf16(hW, (size_t)N * K, 1.0f / sqrtf((float)K));
+  void *A, *W, *C[2], *X[2];
+  double* S[2];
+  float *bias, *res;
+  HCHECK(hipMalloc(&A, hA.size() * 2));
+  HCHECK(hipMalloc(&W, hW.size() * 2));
+  HCHECK(hipMemcpy(A, hA.data(), hA.size() * 2, hipMemcpyHostToDevice));
+  HCHECK(hipMemcpy(W, hW.data(), hW.size() * 2, hipMemcpyHostToDevice));
+  const size_t n = (size_t)M * N;
+  for (int v = 0; v < 2; ++v) {
+    HCHECK(hipMalloc(&C[v], n * 4));
+    HCHECK(hipMalloc(&X[v], n * 2));
+    HCHECK(hipMalloc((void**)&S[v], (size_t)M * 16));
+  }
+  std::vector<float> hbias(N), hres(n);
+  for (auto& x : hbias) x = urand();
+  for (auto& x : hres) x = urand() * 4.0f;
+  HCHECK(hipMalloc(&bias, N * 4));
+  HCHECK(hipMalloc(&res, n * 4));
+  HCHECK(hipMemcpy(bias, hbias.data(), N * 4, hipMemcpyHostToDevice));
+  HCHECK(hipMemcpy(res, hres.data(), n * 4, hipMemcpyHostToDevice));
+  printf("== %s (LayerNorm producer): M%d N%d K%d\n", name, M, N, K);
+  auto launch = [&](int v) {   // v = 0: ping-pong producer, 1: strip kernel
+    sx_gemm_args a;
+    memset(&a, 0, sizeof(a));
+    a.A = A; a.W = W; a.C = C[v]; a.bias = bias; a.residual = res;
+    a.M = M; a.N = N; a.K = K; a.ldc = N; a.ldr = N;
+    a.dtype = SX_BF16; a.out_dtype = SX_F32; a.a_mode = SX_A_LINEAR;
+    sx_gemm_ln_args ln;
+    memset(&ln, 0, sizeof(ln));
+    ln.x16_out = X[v]; ln.row_stats_out = S[v]; ln.ld_x16 = N;
+    SXCHECK(sx_gemm_force_tile(v ? 9 : 8));   // reference: the 256x320 ping-pong producer
+    SXCHECK(sx_gemm_force_tile(v ? 501 : 500));
+    HCHECK(hipMemsetAsync(S[v], 0, (size_t)M * 16, nullptr));
+    SXCHECK(sx_gemm_ln(&a, &ln, nullptr));
+  };
+  int bad = 0;
+  for (int v = 0; v < 2; ++v) {
+    HCHECK(hipMemset(C[v], 0xff, n * 4));
+    HCHECK(hipMemset(X[v], 0xff, n * 2));
+    launch(v);
+  }
+  HCHECK(hipDeviceSynchronize());
+  std::vector<float> c0(n), c1(n);
+  std::vector<uint16_t> x0(n), x1(n);
+  std::vector<double> s0((size_t)M * 2), s1((size_t)M * 2);
+  HCHECK(hipMemcpy(c0.data(), C[0], n * 4, hipMemcpyDeviceToHost));
+  HCHECK(hipMemcpy(c1.data(), C[1], n * 4, hipMemcpyDeviceToHost));
+  HCHECK(hipMemcpy(x0.data(), X[0], n * 2, hipMemcpyDeviceToHost));
+  HCHECK(hipMemcpy(x1.data(), X[1], n * 2, hipMemcpyDeviceToHost));
+  HCHECK(hipMemcpy(s0.data(), S[0], (size_t)M * 16, hipMemcpyDeviceToHost));
+  HCHECK(hipMemcpy(s1.data(), S[1], (size_t)M * 16, hipMemcpyDeviceToHost));
+  // fp64 spot check of the ping-pong reference
+  double worst = 0;
+  for (int t = 0; t < 32; ++t) {
+    const int m = rng() % M, nn = rng() % N;
+    double s = hbias[nn] + hres[(size_t)m * N + nn];
+    for (int k = 0; k < K; ++k) s += (double)bf2f(hA[(size_t)m * K + k]) * (double)bf2f(hW[(size_t)nn * K + k]);
+    worst = std::max(worst, fabs(c0[(size_t)m * N + nn] - s) / (fabs(s) + 1.0));
+  }
+  printf("   ping-pong producer vs fp64 spot check: max rel err %.2e %s\n", worst, worst < 1e-4 ? "ok" : "BAD");
+  if (!(worst < 1e-4)) bad++;
+  size_t dc = 0, dx = 0;
+  int shown = 0;
+  for (size_t i = 0; i < n; ++i) {
+    if (memcmp(&c0[i], &c1[i], 4) != 0) {
+      dc++;
+      if (shown++ < 8) printf("      C differs at [%zu][%zu]: strip %g ping-pong %g\n", i / N, i % N, c1[i], c0[i]);
+    }
+    if (x0[i] != x1[i]) dx++;
+  }
+  double ws = 0, wsum64 = 0;
+  for (int m = 0; m < M; ++m) {
+    double e1 = 0, e2 = 0;
+    for (int c = 0; c < N; ++c) { const double v = c1[(size_t)m * N + c]; e1 += v; e2 += v * v; }
+    for (int q = 0; q < 2; ++q) {
+      const double ref = q ? e2 : e1;
+      wsum64 = std::max(wsum64, fabs(s1[2 * m + q] - ref) / (fabs(ref) + (q ? e2 : sqrt(e2 * N)) * 1e-1 + 1e-30));
+      ws = std::max(ws, fabs(s1[2 * m + q] - s0[2 * m + q]) / (fabs(s0[2 * m + q]) + (q ? e2 : sqrt(e2 * N)) * 1e-1 + 1e-30));
+    }
+  }
+  const bool ok = dc == 0 && dx == 0 && ws < 2e-5 && wsum64 < 2e-5;
+  printf("   strip vs ping-pong: C %zu / %zu differ, x16 %zu differ, row sums max rel diff %.2e (vs fp64 sums of the stored C %.2e) → %s\n", dc, n, dx,
+         ws, wsum64, ok ? "ok" : "MISMATCH");
+  if (!ok) bad++;
+  // reproducibility of the strip kernel: C, x16 AND the row sums bit for bit
+  size_t races = 0;
+  std::vector<float> c2(n);
+  std::vector<uint16_t> x2(n);
+  std::vector<double> s2((size_t)M * 2);
+  for (int rep = 0; rep < 12; ++rep) {
+    launch(1);
+    if (rep % 4 == 3) {
+      HCHECK(hipDeviceSynchronize());
+      HCHECK(hipMemcpy(c2.data(), C[1], n * 4, hipMemcpyDeviceToHost));
+      HCHECK(hipMemcpy(x2.data(), X[1], n * 2, hipMemcpyDeviceToHost));
+      HCHECK(hipMemcpy(s2.data(), S[1], (size_t)M * 16, hipMemcpyDeviceToHost));
+      if (memcmp(c2.data(), c1.data(), n * 4) || memcmp(x2.data(), x1.data(), n * 2) || memcmp(s2.data(), s1.data(), (size_t)M * 16)) races++;
+    }
+  }
+  printf("   strip kernel repeat screen: %zu mismatching repeats\n", races);
+  if (races) bad++;
+  // timing
+  hipEvent_t e0, e1;
+  HCHECK(hipEventCreate(&e0));
+  HCHECK(hipEventCreate(&e1));
+  const double flops = 2.0 * M * N * K, bytes = (double)n * (4 + 4 + 2) + (double)M * K * 2 + (double)N * K * 2;
+  const int iters = std::max(3, (int)(iters_scale * 2.0e12 / flops));
+  std::vector<double> us[2];
+  for (int r = 0; r < rounds + 1; ++r)
+    for (int v = 0; v < 2; ++v) {
+      HCHECK(hipEventRecord(e0, nullptr));
+      for (int it = 0; it < iters; ++it) launch(v);
+      HCHECK(hipEventRecord(e1, nullptr));
+      HCHECK(hipEventSynchronize(e1));
+      float ms;
+      HCHECK(hipEventElapsedTime(&ms, e0, e1));
+      if (r > 0) us[v].push_back(ms * 1e3 / iters);
+    }
+  for (int v = 0; v < 2; ++v) {
+    const double m = median(us[v]);
+    printf("   %-10s median %9.1f us  %7.1f TF  %6.2f TB/s (incl. the statistics memset)\n", v ? "strip" : "ping-pong", m, flops / m * 1e-6, bytes / m * 1e-6);
+  }
+  fflush(stdout);
+  SXCHECK(sx_gemm_force_tile(-1));
+  SXCHECK(sx_gemm_force_tile(501));
+  (void)hipFree(A); (void)hipFree(W); (void)hipFree(bias); (void)hipFree(res);
+  for (int v = 0; v < 2; ++v) { (void)hipFree(C[v]); (void)hipFree(X[v]); (void)hipFree(S[v]); }
+  return bad;
+}
+
 int main(int argc, char** argv) {
   const std::string suite = argc > 1 ? argv[1] : "core";
   const int rounds = argc > 2 ? atoi(argv[2]) : 5;
@@ -390,6 +527,20 @@ int main(int argc, char** argv) {
   HCHECK(hipGetDeviceProperties(&prop, 0));
   printf("device: %s, %d CUs, clock %d MHz; sx_version %d\n", prop.name, prop.multiProcessorCount, prop.clockRate / 1000, sx_version());
   if (suite == "model") { model_sweep(); return 0; }
+  if (suite == "strip" || suite == "stripq") {   // LayerNorm producers: the persistent strip kernel against the ping-pong producer epilogue
+    int bad = 0;
+    bad += run_ln_case("strip_small", 1024, 1280, 1280, rounds, scale);
+    bad += run_ln_case("strip_3strips_k640", 384, 256, 640, rounds, scale);
+    bad += run_ln_case("strip_uneven", 128 * 300, 512, 704, rounds, scale);
+    bad += run_ln_case("outproj_res_ln", 32768, 1280, 1280, rounds, scale);
+    if (suite == "strip") {
+      bad += run_ln_case("ff2_res_ln", 32768, 1280, 5120, rounds, scale);
+      bad += run_ln_case("c1280_batch8", 16384, 1280, 1280, rounds, scale);
+      bad += run_ln_case("n2560", 32768, 2560, 1280, rounds, scale);
+    }
+    printf("%s: %d failing checks\n", bad ? "LAB FAILED" : "LAB OK", bad);
+    return bad ? 1 : 0;
+  }
   std::vector<Case> cases;
   // name, M, N, K, glu, act, res, out32, bias, conv, B, H, W, Cin, stride, ups, ref, cfgs
   if (suite == "core" || suite == "all") {
