@@ -394,7 +394,10 @@ inline int pick_tile(int M, int N, int K, bool glu, bool conv, int force, unsign
 using namespace sxk_gemm;
 
 static int g_force_tile = -1;
-static int g_use_strip = 1;       // 0 = the LayerNorm producers stay on the ping-pong tiles (A/B hook, sx_gemm_force_tile(500))
+// The strip kernel is NOT part of the automatic choice: it is correct (bit-identical C / x16, reproducible row sums) and slower than the
+// 256x320 ping-pong producer on every production shape (profiles/r6_ab_experiments.md §1: its 128x256 sub-tiles need twice the operand
+// bytes per flop and the CU's LDS-DMA path bounds it). sx_gemm_force_tile(9) / (501) select it for the lab and the tests.
+static int g_use_strip = 0;
 namespace sxk_gemm { int g_use_pp = 1; }  // 0 = lock-step kernels only (A/B hook, sx_gemm_force_tile(200))
 extern "C" int sx_gemm_pick_tile(int M, int N, int K, int glu, int conv) {  // host-only: which tile config sx_gemm would use
   return sxk_gemm::pick_tile(M, N, K, glu != 0, conv != 0, -1, 0x1ff);
@@ -515,6 +518,11 @@ static int gemm_impl(const sx_gemm_args* a, double* gn_stats, int gn_groups, int
   if (g_use_pp || g_force_tile == 8) allow |= pp_supported(p, a->dtype, 320, a->a_mode) ? 0x100u : 0u;
   SX_CHECK(!(g_force_tile == 7 || g_force_tile == 8) || ((allow >> g_force_tile) & 1u),
            "sx_gemm: forced ping-pong tile has no kernel for this epilogue");
+  // LayerNorm producers (fp32 residual in, fp32 + 16-bit out, row sums): the persistent strip kernel when the launch has at least
+  // 3/4 of a strip per CU (fewer strips leave CUs idle that the one-tile-per-workgroup kernels would use) — forced tile 9 = always
+  if (p.ln_out && (g_force_tile == 9 || (g_use_strip && g_force_tile < 0 && a->M / 128 >= 192)) && strip_supported(p, a->a_mode))
+    return launch_strip(p, a->dtype, st);
+  SX_CHECK(g_force_tile != 9, "sx_gemm: forced strip kernel does not support this launch");
   if (ln) {
     // the fold exists on the tiles the cost model gives this shape without it, or not at all (no silent change of tile)
     const int plain = pick_tile(a->M, a->N, Kk, a->glu != 0, false, g_force_tile, 0x1ff);
@@ -524,11 +532,6 @@ static int gemm_impl(const sx_gemm_args* a, double* gn_stats, int gn_groups, int
     allow = 1u << plain;
   }
   const int cfg = pick_tile(a->M, a->N, Kk, a->glu != 0, a->a_mode == SX_A_CONV3X3, g_force_tile, allow);
-  // LayerNorm producers (fp32 residual in, fp32 + 16-bit out, row sums): the persistent strip kernel when the launch has at least
-  // 3/4 of a strip per CU (fewer strips leave CUs idle that the one-tile-per-workgroup kernels would use) — forced tile 9 = always
-  if (p.ln_out && (g_force_tile == 9 || (g_use_strip && g_force_tile < 0 && a->M / 128 >= 192)) && strip_supported(p, a->a_mode))
-    return launch_strip(p, a->dtype, st);
-  SX_CHECK(g_force_tile != 9, "sx_gemm: forced strip kernel does not support this launch");
   if (cfg == 7 || cfg == 8) {
     // fused GroupNorm statistics: fp32 output of all N columns, whole 256-row tiles inside one sample, even channels per group
     if (gn_stats && a->out_dtype == SX_F32 && !a->glu && a->act == SX_ACT_NONE && p.n_valid == a->N && a->N % gn_groups == 0 &&

@@ -43,13 +43,22 @@ using ic_t = std::integral_constant<int, V>;
 // VM operations (besides its three DMAs) that barrier interval P of a sub-tile issues: fragment pieces 0..15 = fp32 store
 // [+ the pair's 16-bit store on odd fragments] + residual load; 17 = the rows' statistics store
 constexpr int strip_po(int P) { return P < 0 ? 0 : P < 16 ? ((P & 1) ? 3 : 2) : P == 17 ? 1 : 0; }
-constexpr int kStripPeel = 10;   // k-tiles of a sub-tile whose intervals carry pieces (or follow one closely enough to change a wait count)
+constexpr int kStripPeel = 21;   // phases of a sub-tile that carry pieces (0..17) or follow one closely enough to change a wait count
 
-template <typename TT>
+// PROBE: tuning build (sx_gemm_debug_stamps): every wave sums the s_memtime spans of the six parts of its ROLLED phases and stores
+// them at the end — dbg[(block * 8 + wave) * 8 + {0: issue (fragment reads + DMA), 1: counted vmcnt, 2: lgkmcnt(0), 3: first barrier,
+// 4: MFMA segment, 5: second barrier, 6: phases counted, 7: whole kernel}]
+template <typename TT, int ABL = -1>     // ABL >= 0: probe build with compile-time ablation mask (1 = no W fragment reads, 2 = no DMA, 4 = no A fragment reads, 8 = no MFMA: timing only)
 __global__ __launch_bounds__(512) void gemm_strip_kernel(const GemmP p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   typedef typename TT::vec8 vec8;
-  constexpr int BM = 128, BN = 256, A_BYTES = BM * 128, STAGE = A_BYTES + BN * 128, RING = 3 * STAGE;
+  constexpr bool PROBE = ABL >= 0;
+  // operand ring: NSTG stages of ONE 32-deep k-step each = (128 A rows + 256 W rows) x 64 B = 24 KB. A CU that runs 128x256 sub-tiles
+  // consumes 48 KB of operands per 64-deep k-tile in ~0.55 us of MFMA time — twice the bytes per flop of a 256x320 tile — so what bounds
+  // it is (bytes in flight) / (memory latency): with three 64-deep stages a DMA had 0.5-1.5 k-tiles between issue and wait and the
+  // loop ran at 1.1-1.5 us per k-tile (latency-bound even on an idle chip); with six 32-deep stages every stage is re-issued one
+  // barrier interval after its last read and has four phases (two k-tiles) to land
+  constexpr int BM = 128, BN = 256, NSTG = 6, A_BYTES = BM * 64, STAGE = A_BYTES + BN * 64, RING = NSTG * STAGE;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* rsum = (float*)(smem + RING);             // [4 column waves][128 rows][2]
   float* bias_l = (float*)(smem + RING + 4096);    // [N]
@@ -58,7 +67,7 @@ __global__ __launch_bounds__(512) void gemm_strip_kernel(const GemmP p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = wave >> 2, wc = wave & 3;
   const int lq = (lane >> 4) * 4;
-  const int nkt = p.K / 64;
+  const int nph = p.K / 32;                        // 32-deep phases per sub-tile
   const int n_strips = p.M / BM;
   const int gstride = (int)gridDim.x * BM;
   const int my_strips = (n_strips - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
@@ -84,55 +93,62 @@ __global__ __launch_bounds__(512) void gemm_strip_kernel(const GemmP p) {
 
   // ---- per-lane offsets (fixed over the whole launch): ONE VGPR per access kind; everything wave-uniform (slot, fragment, sub-tile,
   // k-tile) travels in the instructions' scalar offset, so nothing per-fragment is hoisted into registers -------------------------
-  const int rl = lane >> 3;
-  const int dma_lane = rl * p.K * 2 + (((lane & 7) ^ rl) << 4);          // row rl of an 8-row slot, swizzled 16-B chunk
+  // LDS image of a stage: 1-KB blocks of 16 rows x 64 B (= one MFMA operand fragment = one DMA instruction). Chunk c (16 B) of row r
+  // sits at r * 64 + ((c ^ sw(r >> 2)) << 4), sw = {0, 2, 3, 1}: the four 16-lane groups a ds_read_b128 is served in then hit 16
+  // different 16-B bank groups each (rows r, r + 4, r + 8, r + 12 share a 256-B bank row)
+  auto sw4 = [](int r) -> int { return (0x78 >> (2 * ((r >> 2) & 3))) & 3; };       // r >> 2 = 0, 1, 2, 3 -> 0, 2, 3, 1 (2-bit table)
+  const int dma_lane = (lane >> 2) * p.K * 2 + (((lane & 3) ^ sw4(lane >> 2)) << 4);   // row lane >> 2 of a 16-row slot, the chunk that
+                                                                                       // belongs at physical position lane & 3
   // C / residual (ldc == ldr, fp32): fragment (i, j) = rows 64g + 16j + (lane & 15), columns 64wc + 16i + lq .. +3
-  const int c_lane = ((lane & 15) * p.ldc + lq) * 4;
+  const int c_lane = ((lane & 15) * p.ldc + lq) * 4;       // (head only; the pieces re-compute it: c_lane_now)
   // x16: after the permlane swap of a fragment pair a lane owns 8 consecutive columns of the pair's 32.
   // (the rarely used lane constants are RE-COMPUTED where they are used, from a lane id hipcc cannot hoist: kept live across the
   // launch they are the registers that spill — and a scratch reload inside a piece sits on the same vmcnt as the counted waits)
   auto lane_now = [&]() -> int {
     int l;
-    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    // s_nop 1: hipcc pads no hazard of an asm statement — its output register may be the DATA register of the 16-byte buffer_store
+    // issued just before (a VALU write needs two wait states behind such a store; without them the stores that sat in a backed-up
+    // VMEM queue wrote lane numbers instead of x16 values: 1 row in 10^5 under load, none on an idle chip)
+    asm volatile("s_nop 1\n\tv_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
     return l;
+  };
+  auto c_lane_now = [&]() -> int {
+    const int l = lane_now();
+    return ((l & 15) * p.ldc + (l >> 4) * 4) * 4;
   };
   auto x_lane_now = [&]() -> int {
     const int l = lane_now();
     return ((l & 15) * p.ln_ldx + ((l >> 4) & 1) * 16 + (l >> 5) * 8) * 2;
   };
-  const int slot_pitch = 8 * p.K * 2;                                      // bytes between consecutive 8-row DMA slots
+  const int slot_pitch = 16 * p.K * 2;                                     // bytes between consecutive 16-row DMA slots
   const int c_wave = (g * 64 * p.ldc + wc * 64) * 4, c_j = 16 * p.ldc * 4;   // uniform parts of a fragment's C offset
   const int x_wave = (g * 64 * p.ln_ldx + wc * 64) * 2, x_j = 16 * p.ln_ldx * 2;
-  const unsigned frag_row = (unsigned)(lane & 15) * 128u;
-  unsigned frag_sw[2];
-  frag_sw[0] = (unsigned)(((lane >> 4)) ^ (lane & 7)) << 4;
-  frag_sw[1] = (unsigned)((4 + (lane >> 4)) ^ (lane & 7)) << 4;
-  const unsigned a_frag = (unsigned)(g * 64) * 128u + frag_row;
-  const unsigned w_frag = (unsigned)A_BYTES + (unsigned)(wc * 64) * 128u + frag_row;
+  // fragment reads: ONE per-lane register (row lane & 15, chunk lane >> 4 of a 1-KB block); A fragment j of row group g is block
+  // 4g + j of the stage, W fragment i of column wave wc block 8 + 4wc + i (wave-uniform distances)
+  const unsigned frag0 = (unsigned)(lane & 15) * 64u + ((unsigned)((lane >> 4) ^ sw4(lane & 15)) << 4);
+  const unsigned a_blk = (unsigned)(g * 4) * 1024u, w_blk = (unsigned)A_BYTES + (unsigned)(wc * 4) * 1024u;
 
-  // ---- DMA stream: global k-tile counter over all sub-tiles of this workgroup (saturates on the last k-tile: harmless re-fetch) ----
+  // ---- DMA stream: global phase counter over all sub-tiles of this workgroup (saturates on the last phase: harmless re-fetch) ----
   Sub isub = {(int)blockIdx.x * BM, 0};
-  int ikt = 0, ileft = n_sub * nkt;
+  int iph = 0, ileft = n_sub * nph;
   int wr_stage = 0, rd_stage = 0;
-  auto issue_half = [&](int h) {    // h = 0: A slots + W slot 0; h = 1: W slots 1..3   (3 DMA instructions each)
+  // DMA slot d of the batch the stream points at: 0 = the wave's A slot (rows 16 wave ..), 1, 2 = its two W slots
+  auto issue_slot = [&](int d) {
+    if constexpr ((PROBE ? ABL : 0) & 2) return;
     unsigned char* sb = smem + wr_stage * STAGE;
-    const int ua = isub.row0 * p.K * 2 + ikt * 128 + (2 * wave) * slot_pitch;
-    const int uw = isub.n0 * p.K * 2 + ikt * 128 + (4 * wave) * slot_pitch;
-    if (h == 0) {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, SX_LDS_PTR(sb + (2 * wave) * 1024), 16, dma_lane, ua, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, SX_LDS_PTR(sb + (2 * wave + 1) * 1024), 16, dma_lane, ua + slot_pitch, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, SX_LDS_PTR(sb + A_BYTES + (4 * wave) * 1024), 16, dma_lane, uw, 0, 0);
+    if (d == 0) {
+      const int ua = isub.row0 * p.K * 2 + iph * 64 + wave * slot_pitch;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, SX_LDS_PTR(sb + wave * 1024), 16, dma_lane, ua, 0, 0);
     } else {
-#pragma unroll
-      for (int i = 1; i < 4; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, SX_LDS_PTR(sb + A_BYTES + (4 * wave + i) * 1024), 16, dma_lane, uw + i * slot_pitch, 0, 0);
+      const int uw = isub.n0 * p.K * 2 + iph * 64 + (2 * wave + d - 1) * slot_pitch;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, SX_LDS_PTR(sb + A_BYTES + (2 * wave + d - 1) * 1024), 16, dma_lane, uw, 0, 0);
     }
   };
   auto issue_advance = [&]() {
-    wr_stage = wr_stage == 2 ? 0 : wr_stage + 1;
+    wr_stage = wr_stage == NSTG - 1 ? 0 : wr_stage + 1;
     if (ileft > 1) {
       --ileft;
-      if (++ikt == nkt) { ikt = 0; isub = sub_next(isub); }
+      if (++iph == nph) { iph = 0; isub = sub_next(isub); }
     }
   };
 
@@ -174,7 +190,8 @@ __global__ __launch_bounds__(512) void gemm_strip_kernel(const GemmP p) {
       constexpr int i = P & 3, j = P >> 2;
       const f32x4_t b = *(const f32x4_t*)((const unsigned char*)bias_l + (pv_b + i * 64) + (lane_now() >> 4) * 16);
       const f32x4_t v = accE[i][j] + b;
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rCp, c_lane, pv_c + j * c_j + i * 64, 0);
+      const int cl = c_lane_now();
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rCp, cl, pv_c + j * c_j + i * 64, 0);
       lsum[j] += (v[0] + v[1]) + (v[2] + v[3]);
       lsq[j] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
       asm volatile("" : "+v"(lsum[j]), "+v"(lsq[j]));     // pin: hipcc otherwise sinks all 16 fragments' sums to piece 16 (64 live registers)
@@ -187,7 +204,7 @@ __global__ __launch_bounds__(512) void gemm_strip_kernel(const GemmP p) {
         const u32x4_t w4 = {w0[0], w1[0], w0[1], w1[1]};
         __builtin_amdgcn_raw_buffer_store_b128(w4, rXp, x_lane_now(), pv_x + j * x_j + (i - 1) * 32, 0);
       }
-      accE[i][j] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rRn, c_lane, nx_r + j * c_j + i * 64, 0));
+      accE[i][j] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rRn, cl, nx_r + j * c_j + i * 64, 0));
     } else if constexpr (P == 16) {
       // the strip's row sums (complete once its last sub-tile has gone through the pieces): four column quads of a wave → one
 #pragma unroll
@@ -219,70 +236,84 @@ __global__ __launch_bounds__(512) void gemm_strip_kernel(const GemmP p) {
     }
   };
 
+  unsigned long long prb[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const unsigned long long prb_start = PROBE ? __builtin_amdgcn_s_memtime() : 0ull;
   vec8 af[4], wf[4];
   auto lgkm0 = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
+  // MFMA segment: 16 MFMAs, accumulators tied in place (with the builtin hipcc ping-pongs each accumulator between two register
+  // quads across the two phases of the rolled loop: 128 registers for one set; no hazard inside: operands come from ds_reads behind
+  // lgkmcnt(0), every accumulator is used once per segment, its VALU readers sit barrier intervals away). Two of the phase's three
+  // DMA issues ride in the issue gaps of the MFMA stream (a 16x16x32 MFMA occupies the pipe for 16 cycles, its issue takes 4): the
+  // load segment keeps 8 fragment reads + 1 DMA + its piece
   auto mma = [&](f32x4_t (&accM)[4][4]) {
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        // accumulator tied in place (with the builtin hipcc ping-pongs each accumulator between two register quads across the two
-        // phases of the rolled loop: 128 registers for one set). No hazard inside: operands come from ds_reads behind lgkmcnt(0),
-        // every accumulator is used once per segment, its VALU readers sit barrier intervals away.
+        if constexpr ((PROBE ? ABL : 0) & 8) continue;
         if constexpr (std::is_same<TT, F16>::value)
           asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(accM[i][j]) : "v"(wf[i]), "v"(af[j]));
         else
           asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(accM[i][j]) : "v"(wf[i]), "v"(af[j]));
       }
+      if (i == 0 || i == 2) {
+        __builtin_amdgcn_sched_barrier(0);
+        issue_slot(1 + (i >> 1));
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
     __builtin_amdgcn_s_setprio(0);
   };
-  auto read_frags = [&](int ks) {
-    const unsigned char* sb = smem + rd_stage * STAGE;
+  constexpr int abl = PROBE ? ABL : 0;
+  auto read_frags = [&]() {
+    const unsigned char* sa = smem + (frag0 + (unsigned)(rd_stage * STAGE)) + a_blk;
+    const unsigned char* sw = smem + (frag0 + (unsigned)(rd_stage * STAGE)) + w_blk;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) af[j] = *(const vec8*)(sb + a_frag + j * 2048 + frag_sw[ks]);
+    for (int j = 0; j < 4; ++j)
+      if constexpr (!(abl & 4)) af[j] = *(const vec8*)(sa + j * 1024);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) wf[i] = *(const vec8*)(sb + w_frag + i * 2048 + frag_sw[ks]);
+    for (int i = 0; i < 4; ++i)
+      if constexpr (!(abl & 1)) wf[i] = *(const vec8*)(sw + i * 1024);
   };
-  // one k-tile: intervals P0 = 2u, P1 = 2u + 1 of the sub-tile (or -1, -1 in the rolled part)
-  auto ktile = [&](auto P0C, auto P1C, f32x4_t (&accM)[4][4], f32x4_t (&accE)[4][4]) {
-    constexpr int P0 = decltype(P0C)::value, P1 = decltype(P1C)::value;
-    constexpr int WAITN = 6 + strip_po(P0 - 1) + strip_po(P0) + strip_po(P1);
-    // ---- k 0..31 ; first half of the DMA batch two k-tiles ahead ----
-    issue_half(0);
-    piece(P0C, accE);
-    __builtin_amdgcn_sched_barrier(0);   // the piece's temporaries die before the 32 fragment registers are written (peak pressure)
-    read_frags(0);
-    lgkm0();
-    ST_SYNC();
-    mma(accM);
-    ST_SYNC();
-    // ---- k 32..63 ; second half ; the batch ONE k-tile ahead has landed (this wave's share) ----
-    issue_half(1);
+  // one 32-deep phase (interval P of the sub-tile, or -1 in the rolled part). The stream issues the batch FIVE phases ahead (into the
+  // stage both groups finished reading one interval ago); the counted wait retires the batch ONE phase ahead (this wave's share):
+  // issued four phases back, visible to every wave once all of them have passed this wait and the barrier behind it.
+  auto phase = [&](auto PC, f32x4_t (&accM)[4][4], f32x4_t (&accE)[4][4]) {
+    constexpr int P = decltype(PC)::value;
+    // VM operations issued behind the LAST DMA (slot 2, in an MFMA segment) of the batch issued four phases back
+    constexpr int WAITN = 10 + strip_po(P - 3) + strip_po(P - 2) + strip_po(P - 1) + strip_po(P);
+    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0;
+    if constexpr (PROBE && P < 0) t0 = __builtin_amdgcn_s_memtime();
     issue_advance();
-    piece(P1C, accE);
-    __builtin_amdgcn_sched_barrier(0);
-    read_frags(1);
+    read_frags();
+    issue_slot(0);
+    piece(PC, accE);
+    if constexpr (PROBE && P < 0) t1 = __builtin_amdgcn_s_memtime();
     wait_vmcnt<WAITN>();
+    if constexpr (PROBE && P < 0) t2 = __builtin_amdgcn_s_memtime();
     lgkm0();
+    if constexpr (PROBE && P < 0) t3 = __builtin_amdgcn_s_memtime();
     ST_SYNC();
+    if constexpr (PROBE && P < 0) t4 = __builtin_amdgcn_s_memtime();
     mma(accM);
+    if constexpr (PROBE && P < 0) t5 = __builtin_amdgcn_s_memtime();
     ST_SYNC();
-    rd_stage = rd_stage == 2 ? 0 : rd_stage + 1;
+    if constexpr (PROBE && P < 0) {
+      const unsigned long long t6 = __builtin_amdgcn_s_memtime();
+      prb[0] += t1 - t0; prb[1] += t2 - t1; prb[2] += t3 - t2; prb[3] += t4 - t3; prb[4] += t5 - t4; prb[5] += t6 - t5; prb[6] += 1;
+    }
+    rd_stage = rd_stage == NSTG - 1 ? 0 : rd_stage + 1;
   };
   auto subtile = [&](int t, f32x4_t (&accM)[4][4], f32x4_t (&accE)[4][4]) {
     set_neighbours(t);
-    ktile(ic_t<0>{}, ic_t<1>{}, accM, accE);
-    ktile(ic_t<2>{}, ic_t<3>{}, accM, accE);
-    ktile(ic_t<4>{}, ic_t<5>{}, accM, accE);
-    ktile(ic_t<6>{}, ic_t<7>{}, accM, accE);
-    ktile(ic_t<8>{}, ic_t<9>{}, accM, accE);
-    ktile(ic_t<10>{}, ic_t<11>{}, accM, accE);
-    ktile(ic_t<12>{}, ic_t<13>{}, accM, accE);
-    ktile(ic_t<14>{}, ic_t<15>{}, accM, accE);
-    ktile(ic_t<16>{}, ic_t<17>{}, accM, accE);
-    ktile(ic_t<18>{}, ic_t<19>{}, accM, accE);
-    for (int u = kStripPeel; u < nkt; ++u) ktile(ic_t<-1>{}, ic_t<-1>{}, accM, accE);
+    phase(ic_t<0>{}, accM, accE); phase(ic_t<1>{}, accM, accE); phase(ic_t<2>{}, accM, accE); phase(ic_t<3>{}, accM, accE);
+    phase(ic_t<4>{}, accM, accE); phase(ic_t<5>{}, accM, accE); phase(ic_t<6>{}, accM, accE); phase(ic_t<7>{}, accM, accE);
+    phase(ic_t<8>{}, accM, accE); phase(ic_t<9>{}, accM, accE); phase(ic_t<10>{}, accM, accE); phase(ic_t<11>{}, accM, accE);
+    phase(ic_t<12>{}, accM, accE); phase(ic_t<13>{}, accM, accE); phase(ic_t<14>{}, accM, accE); phase(ic_t<15>{}, accM, accE);
+    phase(ic_t<16>{}, accM, accE); phase(ic_t<17>{}, accM, accE); phase(ic_t<18>{}, accM, accE); phase(ic_t<19>{}, accM, accE);
+    phase(ic_t<20>{}, accM, accE);
+    for (int u = kStripPeel; u < nph; ++u) phase(ic_t<-1>{}, accM, accE);
     pv = cur; pv_ok = true;
     cur = nx;
   };
@@ -301,8 +332,10 @@ __global__ __launch_bounds__(512) void gemm_strip_kernel(const GemmP p) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) acc1[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   }
-  issue_half(0); issue_half(1); issue_advance();
-  issue_half(0); issue_half(1); issue_advance();
+  for (int b = 0; b < NSTG - 1; ++b) {    // the first five phases' operands
+    if (b) issue_advance();
+    for (int d = 0; d < 3; ++d) issue_slot(d);
+  }
   wait_vmcnt<0>();
   __syncthreads();                       // bias table + first two k-tiles
   if (g == 1) ST_SYNC();                 // group 1 runs one barrier interval behind group 0
@@ -330,6 +363,11 @@ __global__ __launch_bounds__(512) void gemm_strip_kernel(const GemmP p) {
     piece(ic_t<16>{}, accL);
     __syncthreads();
     piece(ic_t<17>{}, accL);
+    if constexpr (PROBE) {
+      prb[7] = __builtin_amdgcn_s_memtime() - prb_start;
+      if (p.dbg && lane == 0)
+        for (int q = 0; q < 8; ++q) p.dbg[((size_t)blockIdx.x * 8 + wave) * 8 + q] = prb[q];
+    }
   };
   int t = 0;
   while (true) {
@@ -344,7 +382,7 @@ __global__ __launch_bounds__(512) void gemm_strip_kernel(const GemmP p) {
 bool strip_supported(const GemmP& p, int a_mode) {
   if (a_mode != SX_A_LINEAR || p.out_dtype != SX_F32 || !p.res_init || p.glu || p.act != SX_ACT_NONE) return false;
   if (!p.ln_out || !p.ln_x16 || p.ln_in || p.gn_stats || p.bias2d || p.res_mod) return false;
-  if (p.K != p.Kw || p.K % 64 || p.K / 64 < kStripPeel) return false;
+  if (p.K != p.Kw || p.K % 64 || p.K / 32 < kStripPeel) return false;
   if (p.N % 256 || p.N > 2560 || p.M % 128 || p.n_valid != p.N) return false;
   if (p.ldc != p.ldr || p.ldc % 4 || p.ln_ldx % 8 || (((size_t)p.ln_x16) & 15) || (((size_t)p.C) & 15) || (((size_t)p.residual) & 15)) return false;
   if ((uint64_t)p.M * p.ldc * 4 >= 0x7fffffffull || (uint64_t)p.M * p.ln_ldx * 2 >= 0x7fffffffull) return false;
@@ -352,18 +390,43 @@ bool strip_supported(const GemmP& p, int a_mode) {
 }
 
 template <typename TT>
-static int launch_strip_t(const GemmP& p, int cus, hipStream_t st) {
+static int launch_strip_t(const GemmP& p0, int cus, hipStream_t st) {
+  GemmP p = p0;
+  p.dbg = g_dbg;
+  // (probe builds: sx_gemm_debug_stamps + sx_gemm_force_tile(300 + ablation mask))
   const int strips = p.M / 128;
   const int grid = strips < cus ? strips : cus;
-  const size_t lds = 3 * (size_t)(128 + 256) * 128 + 4096 + (size_t)p.N * 4;
-  auto k = gemm_strip_kernel<TT>;
+  const size_t lds = 6 * (size_t)(128 + 256) * 64 + 4096 + (size_t)p.N * 4;
+  void (*k)(const GemmP) = gemm_strip_kernel<TT, -1>;
+  if (g_dbg) {
+    k = gemm_strip_kernel<TT, 0>;
+#if defined(SX_STRIP_ABLATIONS)   // tools/lab/gemm_lab stripprobe: compile-time ablation masks (profiles/r6_strip_ablations.log)
+    switch (g_gm) {
+      case 1: k = gemm_strip_kernel<TT, 1>; break;
+      case 2: k = gemm_strip_kernel<TT, 2>; break;
+      case 4: k = gemm_strip_kernel<TT, 4>; break;
+      case 5: k = gemm_strip_kernel<TT, 5>; break;
+      case 8: k = gemm_strip_kernel<TT, 8>; break;
+      default: break;
+    }
+#endif
+  }
   static hipError_t attr[16];
   static bool done[16];
   int dev = 0;
   (void)hipGetDevice(&dev);
   dev &= 15;
   if (!done[dev]) {
-    attr[dev] = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (128 + 256) * 128 + 4096 + 2560 * 4);
+    const int ldsmax = 6 * (128 + 256) * 64 + 4096 + 2560 * 4;
+    attr[dev] = hipFuncSetAttribute((const void*)gemm_strip_kernel<TT, -1>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsmax);
+#if defined(SX_STRIP_ABLATIONS)
+    const void* probes[6] = {(const void*)gemm_strip_kernel<TT, 0>, (const void*)gemm_strip_kernel<TT, 1>, (const void*)gemm_strip_kernel<TT, 2>,
+                             (const void*)gemm_strip_kernel<TT, 4>, (const void*)gemm_strip_kernel<TT, 5>, (const void*)gemm_strip_kernel<TT, 8>};
+#else
+    const void* probes[1] = {(const void*)gemm_strip_kernel<TT, 0>};
+#endif
+    for (const void* q : probes)
+      if (attr[dev] == hipSuccess) attr[dev] = hipFuncSetAttribute(q, hipFuncAttributeMaxDynamicSharedMemorySize, ldsmax);
     done[dev] = true;
   }
   SX_CHECK(attr[dev] == hipSuccess, "sx_gemm: cannot reserve LDS for the strip kernel: %s", hipGetErrorString(attr[dev]));
