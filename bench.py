@@ -40,8 +40,9 @@ FLOP_LLM_TOKEN = 25.71e9
 FLOP_UNET_SAMPLE = 6.747e12
 FLOP_VAE_DECODE = 10.47e12   # SDXL VAE decoder at 128x128 latents (conv/linear/attention MACs x 2)
 
-# rel-L2 bounds vs the fp32 oracle ASSERTED by the full-size GPU parity tests, per module. "measured" = round-5 run
-# (profiles/r5_fulldepth.log, r5_pytest_gpu.log); the oracle sees the same inputs and the weights a 16-bit checkpoint holds.
+# rel-L2 bounds vs the fp32 oracle ASSERTED by the full-size GPU parity tests, per module. "measured" = the figure of the
+# last full run of the named test (profiles/r6_fulldepth.log, r6_pytest_gpu.log; the bound that counts is "asserted": the tests fail
+# above it whatever this table says); the oracle sees the same inputs and the weights a 16-bit checkpoint holds.
 PARITY_BOUND = {
     "fp16": {
         "metric": "rel-L2 vs the fp32 oracle (oracle/restated*.py) on the same inputs; every row is an assert in the named GPU test",
@@ -61,11 +62,14 @@ PARITY_BOUND = {
                                                                                                "test": "same"},
         "SDXL VAE decode / encode at 1024 px (fp32-grade mode)": {"asserted": 1e-4, "measured": 2.0e-5,
                                                                   "test": "tests/test_fullsize2_gpu.py::test_vae_full_config_1024px"},
-        "lock-step batches above 16 sequences (BASELINE config 2 at 32) run the LLM's plain 16-bit flow": {
-            "asserted": 3e-3, "measured": 2.3e-3, "note": "40 layers; 7.5e-4 at 2 layers (tests/test_fullsize_gpu.py)"}},
+        "lock-step batches above 16 sequences run the LLM's plain 16-bit flow (logged by llama.py; BASELINE config 2's `value` is the "
+        "16-sequence precise run, the 32-sequence plain run its companion `value_plain16_batch32`)": {
+            "asserted": 3e-3, "measured": 2.3e-3, "test": "tests/test_fulldepth_gpu.py::test_llama_13b_40_layers_plain16_flow",
+            "note": "40 layers; 7.5e-4 at 2 layers (tests/test_fullsize_gpu.py)"}},
     "bf16": {"rel_l2_vs_fp32_oracle": 1.2e-2, "after_50_unet_steps": 2.5e-2,
-             "note": "bf16 eps = 7.8e-3: north_star's 1e-3 is not reachable with one bf16 plane per MFMA operand (the LLM's precise mode, two "
-                     "bf16 planes, holds 1.5e-3 at miniature dims; ViT / UNet operands stay single-plane)"}}
+             "note": "bf16 eps = 7.8e-3: north_star's 1e-3 is not reachable with one bf16 plane per MFMA operand — the ViT / UNet operands are "
+                     "single-plane. (The LLM's precise mode with two bf16 planes holds 8e-6 ... 1.2e-5 against the reference-executed "
+                     "golden on 16-bit-checkpoint weights, tests/test_golden_gpu.py; 1.5e-3 was its figure on un-rounded fp32 fixture weights)"}}
 
 CONFIGS = {
     0: "headline: 1x448px image in -> text + one 1024px image out (BASELINE configs 2+3 composed)",
@@ -825,6 +829,7 @@ def parse_args(argv=None):
     ap.add_argument("--batch", type=int, default=None,
                     help="independent generations processed together per GPU per step (default 16; config 5: 4; 1 = latency mode)")
     ap.add_argument("--kv-reuse", type=int, default=1, help="config 5: keep the KV cache across turns (0 = re-prefill like the reference)")
+    ap.add_argument("--no-companion", action="store_true", help="config 2: skip the 32-sequence plain-flow companion pass")
     ap.add_argument("--chains", type=int, default=2, help="concurrent UNet kernel chains per denoise step (1 = one serial chain; "
                     "use 1 under rocprofv3 so per-kernel durations do not contain the other chain)")
     ap.add_argument("--no-vae", action="store_true", help="stop at the denoised latents (no VAE decode)")
@@ -852,7 +857,9 @@ def main(argv=None):
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         raise SystemExit(subprocess.run(cmd, env=env).returncode)
     global BATCH, USE_VAE, VAE_PRECISION
-    BATCH = a.batch if a.batch is not None else {5: 4, 2: 32}.get(a.config, 16)      # config 2 (text only): 32 lock-step sequences
+    # config 2 (text only): 16 lock-step sequences = the LLM's precise mode, whose 40-layer logits are asserted at north_star's 1e-3; the
+    # 32-sequence plain 16-bit flow (faster per sequence, 2.3e-3) runs as a companion pass into `value_plain16_batch32`
+    BATCH = a.batch if a.batch is not None else {5: 4}.get(a.config, 16)
     a.batch = BATCH
     USE_VAE = not a.no_vae
     VAE_PRECISION = a.vae_precision
@@ -908,6 +915,11 @@ def main(argv=None):
         # per-rank line on stderr (the driver's log shows every rank's own clock next to the max that the JSON line uses)
         print(f"[bench rank {rank}/{world}] device {seen[rank].get('device')} {seen[rank].get('device_id')}: {a.steps} steps x {a.batch} "
               f"generations in {dt_local:.3f} s (max over ranks {dt:.3f} s)", file=sys.stderr, flush=True)
+        # what actually ran (the model's own flag, not the command line): ADVICE r5
+        _llm = getattr(getattr(w, "agent", None), "llm", None)
+        llm_mode = None if _llm is None else (
+            "precise (fp32-grade activations: two 16-bit operand planes, fp32 q / k / v / KV cache / attention; 40-layer logits asserted at 1e-3)"
+            if _llm.precise else "plain 16-bit (one rounding per MFMA operand, 16-bit KV cache; 40-layer logits asserted at 3e-3)")
         roof = phases = None
         if rank == 0 and gpu and not a.no_roofline:
             try:
@@ -940,6 +952,34 @@ def main(argv=None):
                 w = w2
             except Exception as ex:
                 second = {"dtype": other, "error": repr(ex)}
+        # BASELINE config 2 companion: the same workload at 32 lock-step sequences = the plain 16-bit LLM flow (outside north_star's
+        # 1e-3: 2.3e-3 at 40 layers, asserted at 3e-3 by tests/test_fulldepth_gpu.py::test_llama_13b_40_layers_plain16_flow)
+        plain32 = None
+        if a.config == 2 and gpu and world == 1 and a.batch <= 16 and not a.no_companion:
+            try:
+                import gc
+                desc2, flops2 = w.describe(), w.flops()
+                w = pipe = None
+                gc.collect()
+                torch.cuda.empty_cache()
+                BATCH = 32
+                w3 = WORKLOADS[2](a, dev, dtype)
+                assert not w3.agent.llm.precise
+                w3.step(100)
+                sync()
+                t1 = time.perf_counter()
+                for sd_ in (0, 1, 2):
+                    w3.step(sd_)
+                sync()
+                dt3 = time.perf_counter() - t1
+                plain32 = {"value": 3 * 32 / dt3, "unit": "gens/s", "batch_per_gpu": 32, "ms_per_step": dt3 / 3 * 1e3, "steps": 3, "warmup": 1,
+                           "llm_mode": "plain 16-bit", "parity_bound": {"asserted": 3e-3, "measured": 2.3e-3,
+                           "test": "tests/test_fulldepth_gpu.py::test_llama_13b_40_layers_plain16_flow"}}
+                w3 = None
+                BATCH = a.batch
+            except Exception as ex:
+                plain32 = {"error": repr(ex)}
+                BATCH = a.batch
     if rank == 0:
         total = du.total_units(ctx, a.steps) * a.batch
         rec = {"metric": "end-to-end generations/sec (img-in -> txt + 1024px-img-out)" if a.config == 0 else
@@ -950,16 +990,20 @@ def main(argv=None):
                "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": a.dtype if gpu else "none",
                "data": "synthetic (seeded random uint8 image / prompt ids, random-init weights of the real dims)",
-               "config": {"workload": (desc0 if second is not None else w.describe()) if gpu else "stub (launch-path test)",
+               "config": {"workload": (desc0 if second is not None else (w.describe() if w is not None else None)) if gpu else "stub (launch-path test)",
                           "baseline_config": a.config,
-                          "llm_mode": ("precise (fp32-grade activations: two 16-bit operand planes, fp32 q / k / v / KV cache / attention)"
-                                       if a.batch <= 16 and os.environ.get("SX_LLM_PRECISE", "1") != "0" else "plain 16-bit") if gpu else None,
+                          "llm_mode": llm_mode if gpu else None,
                           "parity_bound": PARITY_BOUND.get(a.dtype) if gpu else None,
                           "parallelism": "replica x%d (independent generations, no data-path collective)" % world,
                           "batch_per_gpu": a.batch, "request_pipelining": bool(a.overlap),
                           "vae": ("none" if not USE_VAE else {"fp32": "fp32-grade (two bf16 planes per operand, fp32 accumulation)",
                                                               "fast": "single 16-bit operands"}.get(VAE_PRECISION, "auto"))},
-               "flops_per_generation": flops0 if second is not None else w.flops(), "generations_per_step": a.batch}
+               "flops_per_generation": flops0 if second is not None else (w.flops() if w is not None else None), "generations_per_step": a.batch}
+        if gpu and a.config == 2 and plain32 is not None:
+            rec["value_plain16_batch32"] = plain32.get("value")
+            rec["plain16_batch32"] = plain32
+            if w is None:
+                rec["config"]["workload"], rec["flops_per_generation"] = desc2, flops2
         if second is not None:
             if "error" in second:
                 rec["value_" + second["dtype"]] = None

@@ -334,6 +334,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p) {
     const int lim = p.n_valid < p.N ? p.n_valid : p.N;
     pair_ok[i] = (2 * i + 1 < FN) && (n0 + wc * TN + i * 32 + 32 <= lim);  // wave-uniform: the whole 32-col pair is stored
   }
+  // GLU outputs of this wave: columns [(n0 + wc TN) / 2, + 32) of the [M][N / 2] output — wide stores when all 32 exist and are aligned
+  const bool glu_wide = GLU && !OUT32 && (p.ldc & 7) == 0 && (((size_t)p.C) & 15) == 0 &&
+                        ((n0 + wc * TN) >> 1) + 32 <= (p.n_valid < (p.N >> 1) ? p.n_valid : (p.N >> 1));
   auto act1 = [&](f32x4_t x) -> f32x4_t {
     if (ACT == SX_ACT_GELU) {
       const f32x2_t g0 = gelu_erf2((f32x2_t){x[0], x[1]}), g1 = gelu_erf2((f32x2_t){x[2], x[3]});
@@ -445,6 +448,23 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p) {
         }
       }
     } else {
+      if constexpr (GLU && FN == 4) {
+        // GLU: the wave's two results (fragment pairs (0, 1) and (2, 3)) are two ADJACENT 16-column output blocks, 4 columns per
+        // lane each → the same v_permlane16_swap trade as the plain 16-bit epilogue gives every lane 8 consecutive columns: one
+        // 16-byte store per row instead of two 8-byte stores (the store tail of a tile is issue-bound, not byte-bound)
+        if (glu_wide) {
+          const u32x2_t o0 = pack4(v[0]), o1 = pack4(v[2]);
+          const auto s0 = __builtin_amdgcn_permlane16_swap(o0[0], o1[0], false, false);
+          const auto s1 = __builtin_amdgcn_permlane16_swap(o0[1], o1[1], false, false);
+          if (mok) {
+            const u32x4_t w4 = {s0[0], s1[0], s0[1], s1[1]};
+            const int q = lane >> 4;
+            const int col = ((n0 + wc * TN) >> 1) + (q & 1) * 16 + (q >> 1) * 8;
+            *(u32x4_t*)((unsigned short*)p.C + (size_t)m * p.ldc + col) = w4;
+          }
+          continue;
+        }
+      }
 #pragma unroll
       for (int i = 0; i < FN; ++i) {
         if (GLU && (i & 1)) continue;
@@ -509,30 +529,36 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p) {
       gsh[i] = row16_sum(gsh[i]);
       gqh[i] = row16_sum(gqh[i]);
     }
-    float* gacc = (float*)smem;
+    // FIXED-ORDER reduction inside the tile (round 6; LDS float atomics met in arrival order before: the tile's partial sums — and with
+    // them mean / rstd, and through the 16-bit roundings behind them the whole forward — differed from run to run): every contributing
+    // lane writes its column pair's sums to its own slot [row group][pair], one thread per (group, moment) then adds the group's slots
+    // in index order. The tiles still meet in global memory by fp64 atomics: a sum of fp32-valued terms is exact in fp64 (as long as
+    // the terms span < 2^29), hence order-independent.
+    float* gslot = (float*)smem;                                     // [2 row groups][BN / 2 pairs][2]
     const int gbase = n0 / p.gn_cpg;
     const int nlast = (n0 + BN < p.N ? n0 + BN : p.N) - 1;
     const int ngr = nlast / p.gn_cpg - gbase + 1;                    // groups this tile contributes to (<= BN / 2 + 1)
     __syncthreads();
-    for (int t = tid; t < 2 * ngr; t += 512) gacc[t] = 0.f;
-    __syncthreads();
     if ((lane & 15) == 0) {
 #pragma unroll
       for (int i = 0; i < FN; ++i) {
-        const int c0 = n0 + wc * TN + i * 16 + lq;
-        if (c0 < p.N) {
-          const int gl = c0 / p.gn_cpg - gbase, gh = (c0 + 2) / p.gn_cpg - gbase;
-          atomicAdd(&gacc[2 * gl], gsl[i]);
-          atomicAdd(&gacc[2 * gl + 1], gql[i]);
-          atomicAdd(&gacc[2 * gh], gsh[i]);
-          atomicAdd(&gacc[2 * gh + 1], gqh[i]);
-        }
+        const int cp = (wc * TN + i * 16 + lq) >> 1;
+        *(f32x4_t*)(gslot + ((size_t)g * (BN / 2) + cp) * 2) = (f32x4_t){gsl[i], gql[i], gsh[i], gqh[i]};   // pairs cp, cp + 1
       }
     }
     __syncthreads();
     const int smp = m0 / p.gn_rows;
-    for (int t = tid; t < 2 * ngr; t += 512)
-      atomicAdd(&p.gn_stats[((size_t)smp * p.gn_groups + gbase) * 2 + t], (double)gacc[t]);
+    for (int t = tid; t < 2 * ngr; t += 512) {
+      const int G = gbase + (t >> 1), which = t & 1;
+      int c_lo = G * p.gn_cpg - n0, c_hi = (G + 1) * p.gn_cpg - n0;              // the group's columns inside this tile
+      c_lo = c_lo < 0 ? 0 : c_lo;
+      const int c_end = (p.N - n0 < BN ? p.N - n0 : BN);
+      c_hi = c_hi > c_end ? c_end : c_hi;
+      float acc = 0.f;
+      for (int cp = c_lo >> 1; cp < (c_hi >> 1); ++cp) acc += gslot[(size_t)cp * 2 + which];
+      for (int cp = c_lo >> 1; cp < (c_hi >> 1); ++cp) acc += gslot[((size_t)(BN / 2) + cp) * 2 + which];
+      atomicAdd(&p.gn_stats[((size_t)smp * p.gn_groups + G) * 2 + which], (double)acc);
+    }
   }
   if (p.dbg) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the tile's stores have been issued and accepted

@@ -151,14 +151,12 @@ __global__ __launch_bounds__(320) void gn_stats_kernel(const float* x, const flo
   // each thread owns fixed channel QUADS (16-B loads: 8-B accesses stream at 0.54-0.70x the 16-B rate on gfx950) and walks
   // the block's rows four at a time. A quad may straddle two groups (C = 320: 10 channels per group), a PAIR cannot
   // (channels per group are even), so the two halves of the quad are accumulated separately.
-  __shared__ float acc[2 * 64];  // [groups][2], groups <= 64
+  __shared__ __attribute__((aligned(16))) float part[GN_MAX_SLOTS4 * 320 * 4];  // [channel quad][4]: every thread's own slot
   const int T = blockDim.x;
   const int b = blockIdx.y;
   const int r0 = blockIdx.x * rows_per_block;
   const int r1 = min(HW, r0 + rows_per_block);
   const int nq = C >> 2, cpg = C / groups;
-  for (int i = threadIdx.x; i < 2 * groups; i += T) acc[i] = 0.f;
-  __syncthreads();
   float sl[GN_MAX_SLOTS4], ql[GN_MAX_SLOTS4], sh[GN_MAX_SLOTS4], qh[GN_MAX_SLOTS4];
   const f32x4_t* src[GN_MAX_SLOTS4];
   int ld[GN_MAX_SLOTS4];
@@ -195,24 +193,24 @@ __global__ __launch_bounds__(320) void gn_stats_kernel(const float* x, const flo
     for (int k = 0; k < GN_MAX_SLOTS4; ++k)
       if (threadIdx.x + k * T < nq) add(k, src[k][(size_t)r * ld[k]]);
   }
+  // FIXED-ORDER reduction inside the block (round 6; LDS float atomics in arrival order before: the block's partial sums differed in
+  // their last bits from run to run, and with them — through the 16-bit roundings behind every normalisation — the whole forward):
+  // every thread parks its quads' four sums in its own LDS slot, one thread per (group, moment) adds the group's channel PAIRS in
+  // index order (a pair never straddles a group). The blocks meet in global memory by fp64 atomics: a sum of fp32-valued terms is
+  // exact in fp64 (terms spanning < 2^29), hence order-independent.
 #pragma unroll
   for (int k = 0; k < GN_MAX_SLOTS4; ++k) {
     const int qd = threadIdx.x + k * T;
-    if (qd < nq) {
-      const int gl = (4 * qd) / cpg, gh = (4 * qd + 2) / cpg;
-      if (gl == gh) {
-        atomicAdd(&acc[2 * gl], sl[k] + sh[k]);
-        atomicAdd(&acc[2 * gl + 1], ql[k] + qh[k]);
-      } else {
-        atomicAdd(&acc[2 * gl], sl[k]);
-        atomicAdd(&acc[2 * gl + 1], ql[k]);
-        atomicAdd(&acc[2 * gh], sh[k]);
-        atomicAdd(&acc[2 * gh + 1], qh[k]);
-      }
-    }
+    if (qd < nq) *(f32x4_t*)(part + 4 * qd) = (f32x4_t){sl[k], ql[k], sh[k], qh[k]};      // pair 2 qd: (sum, sq), pair 2 qd + 1: (sum, sq)
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < 2 * groups; i += T) atomicAdd(&stats[(size_t)b * groups * 2 + i], (double)acc[i]);
+  for (int i = threadIdx.x; i < 2 * groups; i += T) {
+    const int gi = i >> 1, which = i & 1;
+    const int p0 = gi * (cpg >> 1), p1 = p0 + (cpg >> 1);
+    float a = 0.f;
+    for (int pr = p0; pr < p1; ++pr) a += part[2 * pr + which];
+    atomicAdd(&stats[(size_t)b * groups * 2 + i], (double)a);
+  }
 }
 
 // apply: y = (x - mean) * rstd * gamma + beta (+ SiLU), optional 16-bit raw copy. Per-channel scale / shift are built ONCE per

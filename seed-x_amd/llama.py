@@ -15,13 +15,20 @@ logits, past_key_values, hidden_states with the LAST entry = post-final-norm sta
   * ``precise`` (default on; ``SX_LLM_PRECISE=0`` or ``precise=False`` for the plain 16-bit flow): fp32-grade activations — every GEMM
     A operand travels as two 16-bit planes x = hi + lo (the 16-bit checkpoint weights are exact and stream once), q / k / v, RoPE, the
     KV cache and attention stay fp32 (csrc/precise.hip). 40 layers at 13B dims: logits within 1e-3 of the reference evaluated in fp32 (2.3e-3 without;
-    the per-site budget is tools/llm_error_budget.py); costs < 1 % of a generation (the LLM is 1 % of its FLOPs and
-    the decode step is bound by the weight bytes, which do not change)
+    the per-site budget is tools/llm_error_budget.py). Measured cost (profiles/r5_llm_precise_ab.log): + 1.8 % of a
+    headline step — the LLM phases themselves + 49 % (462 → 688 ms: prefill 2.3x, token step 6.0 → 7.7 ms at 16 sequences).
+    MEMORY: the KV cache is fp32 in this mode — L·G·heads·Tmax·hd·4 B each for K and V = 6.7 GB per sequence at 13B dims with
+    Tmax = 4096 (pass ``max_cache_len``: the cache is sized from it, 0.84 GB per sequence at 512) — and the decode-tile copy of the
+    weights (+ 25.7 GB at 13B) exists for every batch size, not only G >= 5; ``memory_footprint()`` returns the figures before
+    anything is allocated, ``_pack`` logs them. The ``past_key_values`` views ``forward`` returns are fp32 in this mode (the reference
+    returns the model dtype; they are views of the module's own cache and only meant to be handed back to ``forward``).
+    Lock-step batches above 16 sequences run the plain 16-bit flow (2.3e-3 at 40 layers) — logged once at construction
   * ``comm`` with world > 1: Megatron tensor parallelism (parallel.py) — this rank owns nh/tp heads (their q/k/v rows, KV
     cache and o_proj columns), I/tp FFN rows (gate/up rows, down_proj columns) and Vpad/tp lm_head rows; the fp32
     residual stream is all-reduced after o_proj and down_proj (rank 0's GEMM epilogue adds the residual), the logits are
     all-gathered in front of the replicated greedy rule, so every rank holds identical tokens and loop state
 """
+import logging
 import math
 import os
 
@@ -132,7 +139,14 @@ class LlamaForCausalLM:
         # fp32-grade activations (module docstring). The skinny GEMM's second operand block carries the lo plane, so the lock-step
         # batch of the precise mode ends at 16 sequences; larger batches (config 2's 32) run the plain 16-bit flow.
         if precise is None:
-            precise = os.environ.get("SX_LLM_PRECISE", "1") != "0" and self.G <= 16
+            want = os.environ.get("SX_LLM_PRECISE", "1") != "0"
+            precise = want and self.G <= 16
+            if want and not precise:      # never a silent change of numerics
+                logging.getLogger("seedx_amd").warning(
+                    "LlamaForCausalLM(max_batch=%d): more than 16 lock-step sequences run the PLAIN 16-bit flow (one rounding per MFMA "
+                    "operand, 16-bit KV cache: logits 2.3e-3 from the fp32 reference at 40 layers, asserted at 3e-3) instead of the precise "
+                    "mode (1e-3 contract; at most 16 sequences: the skinny GEMM's second operand block carries the lo plane). Use "
+                    "max_batch <= 16 for the contract's tolerance.", self.G)
         self.precise = bool(precise)
         assert not self.precise or self.G <= 16, "precise mode: at most 16 lock-step sequences (the second operand block is the lo plane)"
         # Decode attention (tools/bench_decode_attention_ab.py, 16 sequences x 40 heads, ms per token of the graph-replayed step):
@@ -147,6 +161,15 @@ class LlamaForCausalLM:
         self._sd, self._P = None, None
         self._graph = None
         self.kv_epoch = 0               # bumped whenever the KV cache is reset or written outside generate_batch
+
+    def memory_footprint(self):
+        """Bytes this module will hold on its GPU once packed (per rank): 16-bit weights, their decode-tile copy (precise mode: always;
+        plain flow: from 5 lock-step sequences), and the KV cache (fp32 in precise mode) — sized from ``max_cache_len``."""
+        per_layer = (3 * self.H_l * self.H + self.H * self.H_l + 2 * self.I_l * self.H + self.H * self.I_l) * 2
+        w = self.L * per_layer + (self.V + self.V_l) * self.H * 2
+        tiles = self.L * per_layer + self.V_l * self.H * 2 if (self.G >= 5 or self.precise) else 0
+        kv = 2 * self.L * self.G * self.nh_l * self.Tmax * self.hd * (4 if self.precise else 2)
+        return {"weights": w, "decode_tiles": tiles, "kv_cache": kv, "total": w + tiles + kv}
 
     # ---- reference-compatible plumbing ---------------------------------------------------------------------
     @classmethod
@@ -231,6 +254,18 @@ class LlamaForCausalLM:
         if self.device is None or self.device.type != "cuda":
             raise RuntimeError("LlamaForCausalLM runs on the GPU only")
         sd, dev, dt = self._sd, self.device, self.dtype
+        fp = self.memory_footprint()
+        free = torch.cuda.mem_get_info(dev)[0] + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)   # + the allocator's cached blocks
+        logging.getLogger("seedx_amd").info(
+            "LlamaForCausalLM._pack (%s, %d sequences, Tmax %d): weights %.1f GB + decode tiles %.1f GB + KV cache %.1f GB (%s)",
+            "precise" if self.precise else "plain 16-bit", self.G, self.Tmax, fp["weights"] / 1e9, fp["decode_tiles"] / 1e9,
+            fp["kv_cache"] / 1e9, "fp32" if self.precise else "16-bit")
+        if fp["total"] > free:
+            raise RuntimeError(
+                f"LlamaForCausalLM: {fp['total'] / 1e9:.1f} GB needed ({fp['weights'] / 1e9:.1f} weights + {fp['decode_tiles'] / 1e9:.1f} decode "
+                f"tiles + {fp['kv_cache'] / 1e9:.1f} KV cache at max_cache_len {self.Tmax}, {self.G} sequences"
+                f"{', fp32 (precise mode)' if self.precise else ''}) but {free / 1e9:.1f} GB are free: lower max_cache_len / max_batch"
+                + (", or pass precise=False (16-bit cache, no decode tiles below 5 sequences)" if self.precise else ""))
         if self.tp > 1:     # the captured decode step all-reduces [G, H] and all-gathers [G, Vpad/tp] fp32 (see _decode_step_body)
             self.comm.require_capacity(self.G * max(self.H, self.V_l))
         f32 = lambda t: t.detach().to(dev, torch.float32).contiguous()

@@ -774,3 +774,39 @@ def test_gemm_layernorm_fold(dev, dtype):
     rows = ops.LnRows(2048, 1280, dtype, dev)
     with pytest.raises(RuntimeError, match="ping-pong"):
         ops.gemm(a, w, out_dtype=torch.float32, ln_emit=rows)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", [(1024, 1280, 1280), (128 * 300, 512, 704), (4096, 2560, 1344)])
+def test_gemm_strip_kernel_matches_pingpong_producer(dev, dtype, M, N, K):
+    """csrc/gemm_strip.hip (persistent 128-row strips, two accumulator sets, residual loads / stores under the main loop; opt-in:
+    sx_gemm_force_tile(9) — it measured slower than the ping-pong producer, profiles/r6_ab_experiments.md §1): same LayerNorm-producer
+    contract as gemm_pp.hip's. C and x16 bit for bit, row sums to fp32 summation noise and — written by plain stores in a fixed order,
+    no atomics — the same bits in every launch. Shapes: 8 workgroups x 5 sub-tiles; 300 strips over 256 workgroups (some walk two),
+    K / 32 = 22 phases (one rolled phase behind the 21 peeled ones); N = 2560 (the LDS bias table's limit)."""
+    from seedx_amd import _lib, ops
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(41)
+    a = (torch.randn(M, K, generator=g) * 0.5).to(dtype).to(dev)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dtype).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    res = (torch.randn(M, N, generator=g) * 2.0 + torch.randn(M, 1, generator=g)).to(dev)
+    try:
+        assert lib.sx_gemm_force_tile(8) == 0
+        r0 = ops.LnRows(M, N, dtype, dev)
+        c0 = ops.gemm(a, w, bias=bias, residual=res, out_dtype=torch.float32, ln_emit=r0)
+        assert lib.sx_gemm_force_tile(9) == 0
+        outs = []
+        for _ in range(3):
+            r1 = ops.LnRows(M, N, dtype, dev)
+            c1 = ops.gemm(a, w, bias=bias, residual=res, out_dtype=torch.float32, ln_emit=r1)
+            outs.append((c1.clone(), r1.x16.clone(), r1.stats.clone()))
+    finally:
+        lib.sx_gemm_force_tile(-1)
+    c1, x1, s1 = outs[0]
+    assert torch.equal(c1, c0) and torch.equal(x1, r0.x16)
+    h64 = c1.double()
+    ref = torch.stack([h64.sum(1), (h64 * h64).sum(1)], dim=1)
+    assert torch.allclose(s1, ref, rtol=3e-6, atol=1e-3), (s1 - ref).abs().max()
+    for c, x, s in outs[1:]:
+        assert torch.equal(c, c1) and torch.equal(x, x1) and torch.equal(s, s1)
