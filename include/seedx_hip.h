@@ -119,7 +119,8 @@ int sx_gemm_ln(const sx_gemm_args* args, const sx_gemm_ln_args* ln, void* stream
  * partition off/on; 200/201 = ping-pong tiles excluded from / offered to the cost model; 300+g = g tile-rows per in-XCD
  * traversal group (300 = default); 400+v = ping-pong schedule variant v (A/B builds of the bf16 256x256 linear kernel);
  * 9 = the persistent strip kernel of csrc/gemm_strip.hip for sx_gemm_ln producers (fails if the launch does not fit it);
- * 500/501 = strip kernel excluded from / offered to the automatic choice */
+ * 500/501 = strip kernel excluded from / offered to the automatic choice; 600 + mask = epilogue A/B switches (bit 0: the GLU
+ * epilogue keeps its 8-byte stores) */
 int sx_gemm_force_tile(int cfg);
 /* tuning hook: `buf` = device buffer of 4 x uint64 per workgroup; following sx_gemm launches store s_memtime stamps
  * {start, first k-tile landed, main loop done, end} per workgroup (tools/gemm_phase_probe.py). NULL switches it off. */

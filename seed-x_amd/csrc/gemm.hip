@@ -414,6 +414,7 @@ extern "C" int sx_gemm_force_tile(int cfg) {  // tuning / test hook: -1 = automa
   if (cfg >= 400 && cfg <= 409) { sxk_gemm::g_pp_variant = cfg - 400; return SX_OK; }
   if (cfg == 200 || cfg == 201) { sxk_gemm::g_use_pp = cfg - 200; return SX_OK; }
   if (cfg == 500 || cfg == 501) { g_use_strip = cfg - 500; return SX_OK; }
+  if (cfg >= 600 && cfg <= 663) { sxk_gemm::g_tune = cfg - 600; return SX_OK; }
   g_force_tile = cfg;
   return SX_OK;
 }

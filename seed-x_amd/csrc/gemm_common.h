@@ -18,6 +18,7 @@ struct GemmP {
   int gm;                         // tile-rows per group of the in-XCD traversal
   int res_init;                   // residual is the accumulators' initial value (act == none, no GLU): no epilogue loads
   int n_tiles;                    // persistent kernels: logical grid size (blocks loop bid += gridDim.x)
+  int tune;                       // A/B switches (sx_gemm_force_tile 600 + mask): bit 0 = GLU epilogue keeps its 8-byte stores
   unsigned a_bytes, w_bytes;
   unsigned long long* dbg;        // tuning hook: per-block s_memtime stamps [block][4] = start, first tile landed, main loop done, end
   // fused GroupNorm statistics of the stored fp32 output (sx_gemm_gn; ping-pong tiles only): stats[sample][group][2] += (sum, sum of
@@ -110,5 +111,6 @@ extern unsigned long long* g_dbg;
 extern int g_gm;
 extern int g_xcd_2d;
 extern int g_pp_variant;   // tuning hook (sx_gemm_force_tile 4xx)
+extern int g_tune;         // tuning hook (sx_gemm_force_tile 600 + mask) → GemmP::tune
 
 }  // namespace sxk_gemm

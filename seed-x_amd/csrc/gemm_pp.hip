@@ -335,7 +335,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p) {
     pair_ok[i] = (2 * i + 1 < FN) && (n0 + wc * TN + i * 32 + 32 <= lim);  // wave-uniform: the whole 32-col pair is stored
   }
   // GLU outputs of this wave: columns [(n0 + wc TN) / 2, + 32) of the [M][N / 2] output — wide stores when all 32 exist and are aligned
-  const bool glu_wide = GLU && !OUT32 && (p.ldc & 7) == 0 && (((size_t)p.C) & 15) == 0 &&
+  const bool glu_wide = GLU && !OUT32 && !(p.tune & 1) && (p.ldc & 7) == 0 && (((size_t)p.C) & 15) == 0 &&
                         ((n0 + wc * TN) >> 1) + 32 <= (p.n_valid < (p.N >> 1) ? p.n_valid : (p.N >> 1));
   auto act1 = [&](f32x4_t x) -> f32x4_t {
     if (ACT == SX_ACT_GELU) {
@@ -572,11 +572,13 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p) {
 }
 
 int g_pp_variant = 0;
+int g_tune = 0;
 
 template <typename TT, int BN, int AMODE, bool OUT32, int ACT, bool GLU, int VAR, int LN = 0>
 static int launch_one(const GemmP& p0, hipStream_t st) {
   GemmP p = p0;
   p.dbg = g_dbg;
+  p.tune = g_tune;
   const int grid = plan_grid(p, 256, BN, g_xcd_2d, g_gm);
   constexpr size_t lds = 2 * (size_t)(256 + BN) * 128 + (LN == 1 ? 2048 : 0);      // + the consumer's (rstd, -rstd mu) table
   auto k = gemm_pp_kernel<TT, BN, AMODE, OUT32, ACT, GLU, VAR, LN>;

@@ -75,6 +75,8 @@ static void fill_bf16(std::vector<uint16_t>& h, size_t n, float scale) {
 }
 
 static void set_cfg(int cfg) {
+  SXCHECK(sx_gemm_force_tile(600 + (cfg >= 2000 ? (cfg / 1000 - 1) : 0)));   // 2000 + c: config 1000 + c with tune mask 1 (A/B of epilogue variants)
+  if (cfg >= 2000) cfg = 1000 + cfg % 1000;
   if (cfg >= 1000) {
     SXCHECK(sx_gemm_force_tile(400 + (cfg - 1000) % 10));
     SXCHECK(sx_gemm_force_tile(cfg >= 1100 ? 8 : 7));
@@ -594,6 +596,14 @@ int main(int argc, char** argv) {
   HCHECK(hipGetDeviceProperties(&prop, 0));
   printf("device: %s, %d CUs, clock %d MHz; sx_version %d\n", prop.name, prop.multiProcessorCount, prop.clockRate / 1000, sx_version());
   if (suite == "model") { model_sweep(); return 0; }
+  if (suite == "glu") {    // GLU epilogue: 16-byte stores (1000) against the 8-byte stores (2000), same box, interleaved
+    int bad = 0;
+    bad += run_case({"geglu", 32768, 10240, 1280, 1, 1, 0, 0, 1, 0, 0, 0, 0, 0, 1, 0, 4, {1000, 2000}}, rounds, scale);
+    bad += run_case({"c640_geglu", 131072, 5120, 640, 1, 1, 0, 0, 1, 0, 0, 0, 0, 0, 1, 0, 4, {1000, 2000}}, rounds, scale);
+    bad += run_case({"llm_gateup", 2640, 27648, 5120, 1, 2, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 4, {1000, 2000}}, rounds, scale);
+    printf("%s: %d failing checks\n", bad ? "LAB FAILED" : "LAB OK", bad);
+    return bad ? 1 : 0;
+  }
   if (suite == "stripprobe") {
     for (int abl : {0, 1, 4, 5, 2, 8})
       for (int m : {1024, 32768}) probe_strip(m, 1280, 5120, abl);
