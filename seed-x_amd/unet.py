@@ -412,6 +412,8 @@ class UNet2DConditionModel:
         return out.view(B, HW, C), st_out
 
     def _ln_fold_ok(self, M, C):
+        # cached per (rows, width): the cost model's answer is a pure function of the shape. (sx_gemm_force_tile is a lab / test hook;
+        # a caller that forces tiles clears ``_ln_ok`` — tools/bench_unet_ab.py does)
         key = (M, C)
         if key not in self._ln_ok:
             self._ln_ok[key] = ops.ln_fold_ok(M, C, consumers=[(3 * C, False), (C, False), (8 * C, True)], producers=[C, 4 * C])
