@@ -30,6 +30,8 @@ extern "C" {
 #define SX_BF16 1
 #define SX_F32 2
 #define SX_BF16X3 3 /* sx_groupnorm* outputs only: bf16 planes [hi | hi | lo] per row, 3*C columns (see sx_split_bf16) */
+#define SX_F16X2 4  /* sx_groupnorm* outputs only: fp16 planes [hi | lo] per row, 2*C columns (sx_split16's row layout): the A operand
+                     * of the fp32-grade VAE convs whose weights are exact in fp16 (W duplicated per tap: A.W = Ah.W + Al.W) */
 /* OR-ed into a 16-bit OUTPUT dtype of the decode-step producers (sx_layernorm with rows <= 32, sx_attn_decode_b, sx_gemv):
  * the [rows <= 32][cols] result is written as MFMA operand tiles [rows/16][cols/32][16][32] — what sx_gemv reads with x_layout = 1
  * (tile t = columns 32t .. 32t+31 of all 16 rows, 1 KB contiguous; rows >= `rows` of a tile are not written). */
@@ -207,7 +209,8 @@ int sx_softmax_rows(const float* x, int64_t ldx, void* y, int64_t ldy, int rows,
 /* GroupNorm(+SiLU) over NHWC activations x[B][HW][C] (fp32 in). replaces diffusers
  * ResnetBlock2D.norm1/norm2 + nonlinearity, Transformer2DModel.norm, conv_norm_out [ext].
  * stats: scratch fp64 [B][groups][2] (zeroed by the call). y: 16-bit normalised output; SX_F32 is accepted when raw16 is
- * NULL; SX_BF16X3 writes y (and raw16) as [B][HW][3*C] bf16 planes, the A operand of the fp32-grade VAE mode.
+ * NULL; SX_BF16X3 writes y (and raw16) as [B][HW][3*C] bf16 planes, SX_F16X2 as [B][HW][2*C] fp16 planes: the A operands of the
+ * fp32-grade VAE mode.
  * raw16: optional 16-bit un-normalised copy of x (feeds the 1x1 shortcut conv), may be NULL. */
 int sx_groupnorm(const float* x, void* y, void* raw16, int out_dtype, const float* gamma, const float* beta,
                  double* stats, int B, int HW, int C, int groups, float eps, int silu, void* stream);
@@ -367,6 +370,11 @@ int sx_rmsnorm_planes(const float* x, const float* gamma, float* y32, void* out1
 int sx_rope_kv_append_f32(float* qkv, float* kcache, float* vcache, const float* cos_tab, const float* sin_tab,
                           const int32_t* pos0_dev, int G, int T, int H, int D, int Tmax, int64_t cache_seq_stride,
                           int table_dtype, void* stream);
+/* the same with the "mixed" cache: k fp32, v appended in table_dtype (16-bit [G][H][Tmax][D], the same element strides): three
+ * quarters of the cache bytes; v's rounding only perturbs the softmax-weighted average */
+int sx_rope_kv_append_f32_v16(float* qkv, float* kcache, void* vcache16, const float* cos_tab, const float* sin_tab,
+                              const int32_t* pos0_dev, int G, int T, int H, int D, int Tmax, int64_t cache_seq_stride,
+                              int table_dtype, void* stream);
 /* Causal attention of a T-token chunk per sequence over the fp32 cache, fp32 FMA arithmetic and softmax
  * (modeling_llama_xformer.py:204-239: prefill causal, q_len == 1 sees the whole cache): row t sees keys 0 .. pos0[g] + t.
  * Device-resident positions → graph-capturable for the decode step (T = 1). Output = the planes of the context rows [G*T][H*D].
@@ -375,7 +383,7 @@ int sx_rope_kv_append_f32(float* qkv, float* kcache, float* vcache, const float*
 typedef struct sx_attn_f32_args {
   const float* q;           /* rotated q: row g*T + t at q + row*q_row_stride, head h at + h*D (e.g. the qkv buffer, stride 3*H*D) */
   const float* kcache;      /* fp32 [G][H][Tmax][D], sequences cache_seq_stride floats apart                                       */
-  const float* vcache;
+  const void* vcache;       /* fp32, or — v16 = 1 — the "mixed" cache's 16-bit V (the planes' dtype) with the same ELEMENT strides     */
   void* out;                /* planes of [G*T][H*D], layout by dtype (see above)                                                    */
   const int32_t* pos0_dev;  /* [G] cache position of each sequence's first chunk token (causal)                                    */
   int64_t q_row_stride, cache_seq_stride;
@@ -384,6 +392,7 @@ typedef struct sx_attn_f32_args {
   int32_t G, T, H, D, Tmax, dtype;
   float scale;
   int32_t causal;           /* 1: row t sees keys 0 .. pos0[g] + t; 0: all Tmax keys                                               */
+  int32_t v16;              /* 0: fp32 V (default); 1: V is 16-bit, in the planes' dtype (head_dim <= 128): the mixed cache          */
 } sx_attn_f32_args;
 int sx_attention_f32(const sx_attn_f32_args* args, void* stream);
 /* strided 2-D copy of fp32 rows: dst[r][dst_off + c] = src[r][c]  (channel concat of skip connections) */

@@ -10,6 +10,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libseedx_hip.so")
 
 SX_F16, SX_BF16, SX_F32 = 0, 1, 2
 SX_BF16X3 = 3          # sx_groupnorm* output only: bf16 planes [hi | hi | lo] per row
+SX_F16X2 = 4           # sx_groupnorm* output only: fp16 planes [hi | lo] per row
 SX_TILED16 = 0x100     # OR-ed into a 16-bit out dtype: decode operand tiles [cols/32][16][32] (include/seedx_hip.h)
 SX_ACT_NONE, SX_ACT_GELU, SX_ACT_SILU = 0, 1, 2
 SX_A_LINEAR, SX_A_CONV3X3 = 0, 1
@@ -44,7 +45,7 @@ class AttnF32Args(C.Structure):
     _fields_ = [("q", c_vp), ("kcache", c_vp), ("vcache", c_vp), ("out", c_vp), ("pos0_dev", c_vp),
                 ("q_row_stride", c_i64), ("cache_seq_stride", c_i64), ("kv_row_stride", c_i64), ("kv_head_stride", c_i64),
                 ("G", c_i32), ("T", c_i32), ("H", c_i32), ("D", c_i32), ("Tmax", c_i32), ("dtype", c_i32),
-                ("scale", c_f32), ("causal", c_i32)]
+                ("scale", c_f32), ("causal", c_i32), ("v16", c_i32)]
 
 
 class OneshotArgs(C.Structure):
@@ -126,6 +127,7 @@ SIGNATURES = {
     "sx_split16": [c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_vp],
     "sx_rmsnorm_planes": [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_i32, c_vp],
     "sx_rope_kv_append_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64, c_i32, c_vp],
+    "sx_rope_kv_append_f32_v16": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64, c_i32, c_vp],
     "sx_attention_f32": [C.POINTER(AttnF32Args), c_vp],
     "sx_copy2d_f32": [c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_vp],
     "sx_add_f32": [c_vp, c_vp, c_vp, c_i64, c_vp],

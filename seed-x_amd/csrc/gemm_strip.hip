@@ -4,27 +4,32 @@
 //
 // (attention out-projections and ff.net.2 of diffusers' BasicTransformerBlock [ext] as the t2i loop calls them,
 // pipeline_stable_diffusion_xl_t2i_edit.py:915-922; same contract as gemm_pp.hip's LN = 2 producer epilogue, include/seedx_hip.h
-// sx_gemm_ln). These launches move 12 B per output element for 2·K flops: at K = 1280 their roofline is HBM, and the one-tile-per-
-// workgroup kernels run three serial phases per tile on a CU that holds ONE workgroup — residual pre-load (HBM), main loop (MFMA,
-// HBM idle), stores (HBM). Here the three overlap:
+// sx_gemm_ln). STATUS (round 6): correct — C / x16 bit-identical to the ping-pong producer, row sums reproducible bit for bit — and
+// SLOWER than it on every production shape (217-264 vs 154 us on the 32768 x 1280 x 1280 out-projection): opt-in through
+// sx_gemm_force_tile(9), never the automatic choice. The measurements and the reason (the CU's LDS-DMA issue path bounds a tile
+// that needs twice the operand bytes per flop) are in profiles/r6_ab_experiments.md §1; the kernel stays in the tree as the
+// measured answer to "overlap the producer's three phases inside one workgroup" and for its lab / probe build.
+//
+// These launches move 12 B per output element for 2·K flops: at K = 1280 their roofline is HBM, and the one-tile-per-workgroup
+// kernels run three serial phases per tile on a CU that holds ONE workgroup — residual pre-load (HBM), main loop (MFMA, HBM idle),
+// stores (HBM). Here the three overlap:
 //
 //   * one workgroup per CU walks whole 128-row STRIPS of the output (grid = min(strips, CUs)), 256 columns (a "sub-tile") at a time;
 //   * TWO accumulator sets of 64 registers: while sub-tile t accumulates into set t & 1, the other set is — fragment by fragment, one
-//     16x16 fragment per barrier interval of the first 8 k-tiles — turned into sub-tile t-1's output (bias add, fp32 store, 16-bit
+//     16x16 fragment per barrier interval of the first 16 phases — turned into sub-tile t-1's output (bias add, fp32 store, 16-bit
 //     copy, row sums) and immediately re-loaded with sub-tile t+1's residual. Loads, stores and the operand LDS-DMA share vmcnt in
 //     issue order, every access is a buffer instruction whose descriptor is the NULL descriptor when the neighbour sub-tile does not
 //     exist, so each barrier interval issues a compile-time number of VM operations and the counted waits stay exact;
-//   * the operand ring (3 stages x (128 A rows + 256 W rows) x 128 B) never drains: the DMA stream of global k-tile q + 2 is issued
-//     during k-tile q across sub-tile and strip boundaries;
+//   * the operand ring (6 stages of one 32-deep k-step: (128 A rows + 256 W rows) x 64 B) never drains: the DMA batch five phases
+//     ahead is issued into the stage both wave groups finished reading one interval ago, across sub-tile and strip boundaries;
 //   * a strip covers all N columns, so the rows' (Σ, Σ²) are complete inside one workgroup: lane partials → two xor shuffles → the
-//     four column waves meet in LDS in a fixed order → ONE plain 16-byte store per row. No atomics: the statistics (and everything
-//     the LayerNorm-fold consumers compute from them) are bit-reproducible from run to run.
+//     four column waves meet in LDS in a fixed order → ONE plain 16-byte store per row. No atomics.
 //
-// Schedule inside a k-tile: the 8-wave ping-pong of gemm_pp.hip (two groups of four waves one barrier interval apart; a group's
-// load segment {fragment ds_reads, 3 DMA issues, its epilogue piece, counted vmcnt, lgkmcnt(0)} runs under the other group's 16
-// MFMAs), two 32-deep phases per 64-deep k-tile; wave (g, wc) owns rows 64g.. x columns 64wc.. of the sub-tile (4 x 4 fragments).
-// The accumulation order per output element is the one of every other sx_gemm kernel (residual as the initial value, k ascending,
-// bias last): C and x16 are bit-identical to gemm_pp.hip's.
+// Schedule inside a phase: the 8-wave ping-pong of gemm_pp.hip (two groups of four waves one barrier interval apart; a group's load
+// segment {8 fragment ds_reads, 1 DMA issue, its epilogue piece, counted vmcnt, lgkmcnt(0)} runs under the other group's 16 MFMAs,
+// which carry the phase's other two DMA issues in their issue gaps); wave (g, wc) owns rows 64g.. x columns 64wc.. of the sub-tile
+// (4 x 4 fragments). The accumulation order per output element is the one of every other sx_gemm kernel (residual as the initial
+// value, k ascending, bias last): C and x16 are bit-identical to gemm_pp.hip's.
 #include "gemm_common.h"
 #include <type_traits>
 

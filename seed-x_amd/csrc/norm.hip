@@ -269,6 +269,24 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* x, const flo
     o[n4] = oh;
     o[2 * n4] = ol;
   };
+  // SX_F16X2 (round 6): fp16 planes x = hi + lo, rows laid out [hi | lo] (2*C columns) — the A operand of the VAE's fp32-grade convs
+  // when their weights are exact in fp16 (a VAE loaded `.to(dtype=torch.float16)`, which is what the reference up-casts): one weight
+  // plane, so A·W = Ah·W + Al·W is TWO products instead of the three of the bf16 form. hi saturates at the largest finite fp16 (the
+  // remainder travels in lo); only used behind a GroupNorm, whose outputs are bounded.
+  auto store_planes2 = [&](void* dst, int row, int qi, const f32x4_t v) {
+    unsigned short h[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      h[e] = F16::from_f32(__builtin_amdgcn_fmed3f(v[e], -65504.f, 65504.f));
+      l[e] = F16::from_f32(v[e] - F16::to_f32(h[e]));
+    }
+    u32x2_t oh, ol;
+    oh[0] = h[0] | ((unsigned)h[1] << 16); oh[1] = h[2] | ((unsigned)h[3] << 16);
+    ol[0] = l[0] | ((unsigned)l[1] << 16); ol[1] = l[2] | ((unsigned)l[3] << 16);
+    u32x2_t* o = (u32x2_t*)dst + (row_base + row) * 2 * n4 + qi;
+    o[0] = oh;
+    o[n4] = ol;
+  };
   auto one = [&](int i, int row, int qi, const f32x4_t v) {
     f32x4_t o = v * *(const f32x4_t*)(s_sc + 4 * qi) + *(const f32x4_t*)(s_sh + 4 * qi);
     if (silu) {
@@ -278,6 +296,11 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* x, const flo
     if (out_dt == SX_BF16X3) {
       store_planes(y, row, qi, o);
       if (raw16) store_planes(raw16, row, qi, v);
+      return;
+    }
+    if (out_dt == SX_F16X2) {
+      store_planes2(y, row, qi, o);
+      if (raw16) store_planes2(raw16, row, qi, v);
       return;
     }
     store4(y, out_dt, base4 + i, o);
@@ -404,8 +427,9 @@ static int groupnorm_impl(const float* x, const float* x2, int C1, void* y, void
   SX_CHECK(x && stats, "sx_groupnorm: null pointer");
   SX_CHECK(phase == 1 || (y && gamma && beta), "sx_groupnorm: null pointer");
   SX_CHECK(!x2 || (C1 > 0 && C1 < C && C1 % 4 == 0 && (C - C1) % 4 == 0), "sx_groupnorm2: C1=%d of C=%d", C1, C);
-  SX_CHECK(phase == 1 || out_dtype == SX_F16 || out_dtype == SX_BF16 || out_dtype == SX_BF16X3 || (out_dtype == SX_F32 && !raw16),
-           "sx_groupnorm: output must be 16-bit, SX_BF16X3, or fp32 without a raw copy");
+  SX_CHECK(phase == 1 || out_dtype == SX_F16 || out_dtype == SX_BF16 || out_dtype == SX_BF16X3 || out_dtype == SX_F16X2 ||
+               (out_dtype == SX_F32 && !raw16),
+           "sx_groupnorm: output must be 16-bit, SX_BF16X3, SX_F16X2, or fp32 without a raw copy");
   SX_CHECK(groups > 0 && groups <= 64 && C % groups == 0, "sx_groupnorm: C=%d groups=%d", C, groups);
   SX_CHECK(C % 4 == 0 && (C / groups) % 2 == 0, "sx_groupnorm: C %% 4 and (C/groups) %% 2 must be 0 (C=%d)", C);
   SX_CHECK(C / 2 <= 256 * GN_MAX_SLOTS2 && C <= GN_MAX_C, "sx_groupnorm: C=%d too large", C);

@@ -99,8 +99,11 @@ __global__ __launch_bounds__(256) void rmsnorm_planes_kernel(const float* x, con
 // RoPE (modeling_llama_xformer.py:141-149) of the q and k heads of fp32 qkv rows [G*T][3*H*D] (q rotated in place) + append of the
 // rotated k and of v to the fp32 caches [G][H][Tmax][D] at position pos0[g] + t. The tables are rounded to the model dtype first
 // (:128-131 casts them to x.dtype), the products stay fp32.
-template <typename TT>
-__global__ void rope_kv_f32_kernel(float* qkv, float* kc, float* vc, const float* cos_t, const float* sin_t, const int* pos0_dev, int T,
+// V16 (round 6, the "mixed" cache): v is appended in the model's 16-bit dtype (vc = 16-bit [G][H][Tmax][D], same ELEMENT strides) —
+// k stays fp32: the score noise of a rounded k goes through the softmax (tools/llm_error_budget.py: q / k 1.2e-3 of the 2.2e-3 at 40
+// layers, v 0.6e-3), while a rounded v only perturbs the weighted average. Three quarters of the fp32 cache's bytes.
+template <typename TT, bool V16>
+__global__ void rope_kv_f32_kernel(float* qkv, float* kc, void* vc_, const float* cos_t, const float* sin_t, const int* pos0_dev, int T,
                                    int H, int D, int Tmax, int G, long long seq_stride) {
   const int half = D / 2;
   const int64_t total = (int64_t)G * T * H * half;
@@ -124,11 +127,18 @@ __global__ void rope_kv_f32_kernel(float* qkv, float* kc, float* vc, const float
     if (!pos_ok) continue;                  // a device-resident position past the cache never writes outside it
     const float k1 = kh[j], k2 = kh[j + half];
     float* kd = kc + (size_t)g * seq_stride + ((size_t)h * Tmax + pos) * D;
-    float* vd = vc + (size_t)g * seq_stride + ((size_t)h * Tmax + pos) * D;
     kd[j] = k1 * c - k2 * s;
     kd[j + half] = k2 * c + k1 * s;
-    vd[j] = vh[j];
-    vd[j + half] = vh[j + half];
+    const size_t vo = (size_t)g * seq_stride + ((size_t)h * Tmax + pos) * D;
+    if constexpr (V16) {
+      unsigned short* vd = (unsigned short*)vc_ + vo;
+      vd[j] = TT::from_f32(vh[j]);
+      vd[j + half] = TT::from_f32(vh[j + half]);
+    } else {
+      float* vd = (float*)vc_ + vo;
+      vd[j] = vh[j];
+      vd[j + half] = vh[j + half];
+    }
   }
 }
 
@@ -141,7 +151,7 @@ __global__ void rope_kv_f32_kernel(float* qkv, float* kc, float* vc, const float
 struct AttnF32P {
   const float* q;          // row r = g*T + t at q + r*q_stride, head h at + h*D (already rotated)
   const float* kc;
-  const float* vc;
+  const void* vc;          // fp32, or (V16 kernels) the model's 16-bit dtype with the same element strides
   unsigned short* out;
   const int* pos0_dev;     // [G] cache position of the chunk's first token (causal only)
   long long q_stride, seq_stride, row_stride, head_stride;   // K / V element strides: sequence, key row, head
@@ -152,7 +162,7 @@ struct AttnF32P {
 // QB query rows per workgroup: 4 for the decode step and short chunks, 8 for prefill (every key row is loaded once per QB rows: the
 // K / V re-reads from L2 halve — 1.5k-token prompts, BASELINE config 5). DC = 8-dim chunks per lane: 1 covers D <= 128 (16 lanes x 8),
 // 2 covers D <= 256 (lane dl owns dims [8 dl, 8 dl + 8) and [128 + 8 dl, 128 + 8 dl + 8): the LLM-side resamplers' head_dim 160).
-template <typename TT, int QB, int DC>
+template <typename TT, int QB, int DC, bool V16 = false>
 __global__ __launch_bounds__(256) void attn_f32_kernel(const AttnF32P p) {
   constexpr int DW = 8 * DC, DMAX = 128 * DC;
   __shared__ float red[4][QB][DMAX + 4];
@@ -183,7 +193,7 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const AttnF32P p) {
     }
   }
   const float* kh = p.kc + (size_t)g * p.seq_stride + (size_t)h * p.head_stride;
-  const float* vh = p.vc + (size_t)g * p.seq_stride + (size_t)h * p.head_stride;
+  const size_t vbase = (size_t)g * p.seq_stride + (size_t)h * p.head_stride;
   const int kend = min(p.Tmax, pos0 + q0 + nq);       // keys 0 .. kend-1 are visible to the block's last row
   for (int t = grp; t < kend; t += 16) {
     float kf[DW], vf[DW];
@@ -193,11 +203,23 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const AttnF32P p) {
     for (int c = 0; c < DC; ++c) {
       if (dvalid[c]) {
         const float* kr = kh + (size_t)t * p.row_stride + c * 128 + dl * 8;
-        const float* vr = vh + (size_t)t * p.row_stride + c * 128 + dl * 8;
+        const size_t vo = vbase + (size_t)t * p.row_stride + c * 128 + dl * 8;
         const f32x4_t k0 = *(const f32x4_t*)kr, k1 = *(const f32x4_t*)(kr + 4);
-        const f32x4_t v0 = *(const f32x4_t*)vr, v1 = *(const f32x4_t*)(vr + 4);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { kf[8 * c + e] = k0[e]; kf[8 * c + 4 + e] = k1[e]; vf[8 * c + e] = v0[e]; vf[8 * c + 4 + e] = v1[e]; }
+        for (int e = 0; e < 4; ++e) { kf[8 * c + e] = k0[e]; kf[8 * c + 4 + e] = k1[e]; }
+        if constexpr (V16) {
+          const u32x4_t w = *(const u32x4_t*)((const unsigned short*)p.vc + vo);        // 8 values in one 16-byte load
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            vf[8 * c + 2 * e] = TT::to_f32((unsigned short)(w[e] & 0xffffu));
+            vf[8 * c + 2 * e + 1] = TT::to_f32((unsigned short)(w[e] >> 16));
+          }
+        } else {
+          const float* vr = (const float*)p.vc + vo;
+          const f32x4_t v0 = *(const f32x4_t*)vr, v1 = *(const f32x4_t*)(vr + 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { vf[8 * c + e] = v0[e]; vf[8 * c + 4 + e] = v1[e]; }
+        }
       }
     }
 #pragma unroll
@@ -325,21 +347,33 @@ extern "C" int sx_rmsnorm_planes(const float* x, const float* gamma, float* y32,
   return SX_OK;
 }
 
-extern "C" int sx_rope_kv_append_f32(float* qkv, float* kcache, float* vcache, const float* cos_tab, const float* sin_tab,
-                                     const int32_t* pos0_dev, int G, int T, int H, int D, int Tmax, int64_t cache_seq_stride,
-                                     int table_dtype, void* stream) {
+static int rope_kv_f32_impl(float* qkv, float* kcache, void* vcache, int v16, const float* cos_tab, const float* sin_tab,
+                            const int32_t* pos0_dev, int G, int T, int H, int D, int Tmax, int64_t cache_seq_stride, int table_dtype,
+                            void* stream) {
   SX_CHECK(qkv && kcache && vcache && cos_tab && sin_tab && pos0_dev, "sx_rope_kv_append_f32: null pointer");
   SX_CHECK(D % 2 == 0 && G >= 1 && T >= 1 && H >= 1, "sx_rope_kv_append_f32: D/G/T/H");
   SX_CHECK(table_dtype == SX_F16 || table_dtype == SX_BF16, "sx_rope_kv_append_f32: table_dtype");
   const int64_t n = (int64_t)G * T * H * (D / 2);
-  if (table_dtype == SX_BF16)
-    hipLaunchKernelGGL(rope_kv_f32_kernel<BF16>, gs_grid(n), dim3(256), 0, ST, qkv, kcache, vcache, cos_tab, sin_tab, pos0_dev, T, H, D, Tmax,
-                       G, (long long)cache_seq_stride);
-  else
-    hipLaunchKernelGGL(rope_kv_f32_kernel<F16>, gs_grid(n), dim3(256), 0, ST, qkv, kcache, vcache, cos_tab, sin_tab, pos0_dev, T, H, D, Tmax,
-                       G, (long long)cache_seq_stride);
+#define SX_ROPE_GO(TT, V16)                                                                                                            \
+  hipLaunchKernelGGL((rope_kv_f32_kernel<TT, V16>), gs_grid(n), dim3(256), 0, ST, qkv, kcache, vcache, cos_tab, sin_tab, pos0_dev, T, H, D, \
+                     Tmax, G, (long long)cache_seq_stride)
+  if (table_dtype == SX_BF16) { if (v16) SX_ROPE_GO(BF16, true); else SX_ROPE_GO(BF16, false); }
+  else { if (v16) SX_ROPE_GO(F16, true); else SX_ROPE_GO(F16, false); }
+#undef SX_ROPE_GO
   SX_HIP_LAUNCH_CHECK();
   return SX_OK;
+}
+
+extern "C" int sx_rope_kv_append_f32(float* qkv, float* kcache, float* vcache, const float* cos_tab, const float* sin_tab,
+                                     const int32_t* pos0_dev, int G, int T, int H, int D, int Tmax, int64_t cache_seq_stride,
+                                     int table_dtype, void* stream) {
+  return rope_kv_f32_impl(qkv, kcache, vcache, 0, cos_tab, sin_tab, pos0_dev, G, T, H, D, Tmax, cache_seq_stride, table_dtype, stream);
+}
+
+extern "C" int sx_rope_kv_append_f32_v16(float* qkv, float* kcache, void* vcache16, const float* cos_tab, const float* sin_tab,
+                                         const int32_t* pos0_dev, int G, int T, int H, int D, int Tmax, int64_t cache_seq_stride,
+                                         int table_dtype, void* stream) {
+  return rope_kv_f32_impl(qkv, kcache, vcache16, 1, cos_tab, sin_tab, pos0_dev, G, T, H, D, Tmax, cache_seq_stride, table_dtype, stream);
 }
 
 extern "C" int sx_attention_f32(const sx_attn_f32_args* a, void* stream) {
@@ -351,13 +385,30 @@ extern "C" int sx_attention_f32(const sx_attn_f32_args* a, void* stream) {
   SX_CHECK(a->q_row_stride >= (int64_t)a->H * a->D && a->q_row_stride % 4 == 0 && (((uintptr_t)a->q) & 15) == 0, "sx_attention_f32: q_row_stride");
   SX_CHECK(!tiled || ((int64_t)a->G * a->T <= 16 && (a->H * a->D) % 32 == 0), "sx_attention_f32: operand tiles hold <= 16 rows, H*D %% 32 == 0");
   AttnF32P p;
-  p.q = a->q; p.kc = a->kcache; p.vc = a->vcache; p.out = (unsigned short*)a->out; p.pos0_dev = a->pos0_dev;
+  p.q = a->q; p.kc = a->kcache; p.out = (unsigned short*)a->out; p.pos0_dev = a->pos0_dev;
   p.q_stride = a->q_row_stride; p.seq_stride = a->cache_seq_stride;
   p.row_stride = a->kv_row_stride > 0 ? a->kv_row_stride : a->D;
   p.head_stride = a->kv_head_stride > 0 ? a->kv_head_stride : (int64_t)a->Tmax * a->D;
+  p.vc = a->vcache;
   SX_CHECK(p.row_stride % 4 == 0 && p.head_stride % 4 == 0 && p.seq_stride % 4 == 0 && (((uintptr_t)a->kcache) & 15) == 0 &&
            (((uintptr_t)a->vcache) & 15) == 0, "sx_attention_f32: K / V strides and pointers must keep 16-B alignment");
   p.T = a->T; p.H = a->H; p.D = a->D; p.Tmax = a->Tmax; p.tiled = tiled; p.scale = a->scale; p.causal = a->causal ? 1 : 0;
+  if (a->v16) {
+    // mixed cache: V in the planes' 16-bit dtype (head_dim <= 128: the decoder's; the resamplers' fp32 views keep the fp32 form)
+    SX_CHECK(a->v16 == 1 && a->D <= 128 && p.row_stride % 8 == 0 && p.head_stride % 8 == 0 && p.seq_stride % 8 == 0,
+             "sx_attention_f32: a 16-bit V cache needs head_dim <= 128 and 16-B aligned rows");
+    if (a->T > 8) {
+      const dim3 grid((a->T + 7) / 8, a->H, a->G);
+      if (dt == SX_BF16) hipLaunchKernelGGL((attn_f32_kernel<BF16, 8, 1, true>), grid, dim3(256), 0, ST, p);
+      else hipLaunchKernelGGL((attn_f32_kernel<F16, 8, 1, true>), grid, dim3(256), 0, ST, p);
+    } else {
+      const dim3 grid((a->T + 3) / 4, a->H, a->G);
+      if (dt == SX_BF16) hipLaunchKernelGGL((attn_f32_kernel<BF16, 4, 1, true>), grid, dim3(256), 0, ST, p);
+      else hipLaunchKernelGGL((attn_f32_kernel<F16, 4, 1, true>), grid, dim3(256), 0, ST, p);
+    }
+    SX_HIP_LAUNCH_CHECK();
+    return SX_OK;
+  }
   if (a->D > 128) {             // two 8-dim chunks per lane (the LLM-side resamplers' head_dim 160): 4 rows per workgroup
     const dim3 grid((a->T + 3) / 4, a->H, a->G);
     if (dt == SX_BF16) hipLaunchKernelGGL((attn_f32_kernel<BF16, 4, 2>), grid, dim3(256), 0, ST, p);

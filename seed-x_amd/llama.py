@@ -14,11 +14,13 @@ logits, past_key_values, hidden_states with the LAST entry = post-final-norm sta
     weights are streamed from HBM once per step for all G tokens (the reference is batch 1 only, seed_x.py:191)
   * ``precise`` (default on; ``SX_LLM_PRECISE=0`` or ``precise=False`` for the plain 16-bit flow): fp32-grade activations — every GEMM
     A operand travels as two 16-bit planes x = hi + lo (the 16-bit checkpoint weights are exact and stream once), q / k / v, RoPE, the
-    KV cache and attention stay fp32 (csrc/precise.hip). 40 layers at 13B dims: logits within 1e-3 of the reference evaluated in fp32 (2.3e-3 without;
+    K cache and attention stay fp32 (csrc/precise.hip; v is stored in 16 bits in fp16 models: the mixed cache). 40 layers at 13B dims:
+    logits 5.6e-4 / 5.9e-4 (prefill / decode; 2.9e-5 with the all-fp32 cache) from the reference evaluated in fp32, asserted at 1e-3 (2.3e-3 without;
     the per-site budget is tools/llm_error_budget.py). Measured cost (profiles/r5_llm_precise_ab.log): + 1.8 % of a
     headline step — the LLM phases themselves + 49 % (462 → 688 ms: prefill 2.3x, token step 6.0 → 7.7 ms at 16 sequences).
-    MEMORY: the KV cache is fp32 in this mode — L·G·heads·Tmax·hd·4 B each for K and V = 6.7 GB per sequence at 13B dims with
-    Tmax = 4096 (pass ``max_cache_len``: the cache is sized from it, 0.84 GB per sequence at 512) — and the decode-tile copy of the
+    MEMORY: the KV cache is fp32 for K and — round 6, fp16 models — 16-bit for V ("mixed" cache, ``kv_v16``; bf16 models and
+    ``kv_v16=False`` keep fp32 V) — L·G·heads·Tmax·hd·(4 + 2 | 4) B = 5.0 | 6.7 GB per sequence at 13B dims with
+    Tmax = 4096 (pass ``max_cache_len``: the cache is sized from it, 0.63 | 0.84 GB per sequence at 512) — and the decode-tile copy of the
     weights (+ 25.7 GB at 13B) exists for every batch size, not only G >= 5; ``memory_footprint()`` returns the figures before
     anything is allocated, ``_pack`` logs them. The ``past_key_values`` views ``forward`` returns are fp32 in this mode (the reference
     returns the model dtype; they are views of the module's own cache and only meant to be handed back to ``forward``).
@@ -121,7 +123,7 @@ class CausalLMOutputWithPast(dict):
 
 
 class LlamaForCausalLM:
-    def __init__(self, config, max_cache_len=None, max_batch=1, comm=None, precise=None):
+    def __init__(self, config, max_cache_len=None, max_batch=1, comm=None, precise=None, kv_v16=None):
         self.config = config if not isinstance(config, dict) else LlamaConfigLite(**config)
         c = self.config
         self.H, self.nh, self.L = c.hidden_size, c.num_attention_heads, c.num_hidden_layers
@@ -148,6 +150,13 @@ class LlamaForCausalLM:
                     "mode (1e-3 contract; at most 16 sequences: the skinny GEMM's second operand block carries the lo plane). Use "
                     "max_batch <= 16 for the contract's tolerance.", self.G)
         self.precise = bool(precise)
+        # precise mode's "mixed" KV cache (round 6): k fp32, v in the model's 16-bit dtype — three quarters of the fp32 cache's bytes
+        # (the cache is a third of what a token step moves at 1.5k tokens of context). It costs parity where the round-5 mode had a
+        # factor 35 to spare: 40-layer logits 2.9e-5 → 5.6e-4 prefill / 5.9e-4 decode in fp16 (profiles/r6_fulldepth.log; asserted at
+        # 1e-3). Default: ON for fp16 models, OFF for bf16 (a bf16 v carries 8 mantissa bits: 2.3e-3 on the miniature decoder, outside the
+        # contract) — decided in _pack once the dtype is known; ``kv_v16=False`` / ``SX_LLM_V16=0`` keep the all-fp32 cache.
+        self._kv_v16_arg = kv_v16
+        self.kv_v16 = False
         assert not self.precise or self.G <= 16, "precise mode: at most 16 lock-step sequences (the second operand block is the lo plane)"
         # Decode attention (tools/bench_decode_attention_ab.py, 16 sequences x 40 heads, ms per token of the graph-replayed step):
         # three launches (RoPE + append, split-KV attention, combine) with 8 / 2 / 1 KV splits 6.70 / 6.46 / 6.52; ONE launch
@@ -168,7 +177,7 @@ class LlamaForCausalLM:
         per_layer = (3 * self.H_l * self.H + self.H * self.H_l + 2 * self.I_l * self.H + self.H * self.I_l) * 2
         w = self.L * per_layer + (self.V + self.V_l) * self.H * 2
         tiles = self.L * per_layer + self.V_l * self.H * 2 if (self.G >= 5 or self.precise) else 0
-        kv = 2 * self.L * self.G * self.nh_l * self.Tmax * self.hd * (4 if self.precise else 2)
+        kv = self.L * self.G * self.nh_l * self.Tmax * self.hd * ((4 + (2 if self.kv_v16 else 4)) if self.precise else 4)
         return {"weights": w, "decode_tiles": tiles, "kv_cache": kv, "total": w + tiles + kv}
 
     # ---- reference-compatible plumbing ---------------------------------------------------------------------
@@ -254,12 +263,15 @@ class LlamaForCausalLM:
         if self.device is None or self.device.type != "cuda":
             raise RuntimeError("LlamaForCausalLM runs on the GPU only")
         sd, dev, dt = self._sd, self.device, self.dtype
+        want_v16 = self._kv_v16_arg if self._kv_v16_arg is not None else \
+            (os.environ.get("SX_LLM_V16", "1") != "0" and dt == torch.float16)
+        self.kv_v16 = bool(want_v16) and self.precise and self.hd <= 128 and self.hd % 8 == 0
         fp = self.memory_footprint()
         free = torch.cuda.mem_get_info(dev)[0] + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)   # + the allocator's cached blocks
         logging.getLogger("seedx_amd").info(
             "LlamaForCausalLM._pack (%s, %d sequences, Tmax %d): weights %.1f GB + decode tiles %.1f GB + KV cache %.1f GB (%s)",
             "precise" if self.precise else "plain 16-bit", self.G, self.Tmax, fp["weights"] / 1e9, fp["decode_tiles"] / 1e9,
-            fp["kv_cache"] / 1e9, "fp32" if self.precise else "16-bit")
+            fp["kv_cache"] / 1e9, ("k fp32 + v 16-bit" if self.kv_v16 else "fp32") if self.precise else "16-bit")
         if fp["total"] > free:
             raise RuntimeError(
                 f"LlamaForCausalLM: {fp['total'] / 1e9:.1f} GB needed ({fp['weights'] / 1e9:.1f} weights + {fp['decode_tiles'] / 1e9:.1f} decode "
@@ -345,7 +357,7 @@ class LlamaForCausalLM:
         G = self.G
         P["kc"] = torch.zeros((self.L, G, self.nh_l, self.Tmax, self.hd), dtype=torch.float32 if self.precise else dt,
                               device=dev)                                                          # this rank's heads
-        P["vc"] = torch.zeros_like(P["kc"])
+        P["vc"] = torch.zeros_like(P["kc"], dtype=dt) if self.kv_v16 else torch.zeros_like(P["kc"])
         # device-resident loop state, one entry per sequence
         P["pos"] = torch.zeros(G, dtype=torch.int32, device=dev)         # position of the next input token
         P["ctx"] = torch.ones(G, dtype=torch.int32, device=dev)          # pos + 1 (keys visible to that token)

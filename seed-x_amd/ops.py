@@ -367,7 +367,8 @@ def groupnorm(x, gamma, beta, groups, eps, silu, out_dtype, want_raw=False, x2=N
               stats=None):
     """x: fp32 [B, HW, C] (NHWC). Returns y (16-bit) and optionally a 16-bit raw copy of x.
     stats: GnStats filled by x's producer (``ready``): only the apply pass runs (single rank, no x2).
-    planes: y (and raw) come out as bf16 [B, HW, 3C] rows [hi | hi | lo] (split_bf16 role "a") instead.
+    planes: True / 3: y (and raw) come out as bf16 [B, HW, 3C] rows [hi | hi | lo] (split_bf16 role "a") instead; 2: as fp16
+    [B, HW, 2C] rows [hi | lo] (split16's layout: the operand of a conv whose fp16 weight rows are duplicated per tap).
     x2: optional second fp32 [B, HW, C2] tensor — the op then runs over the channel concatenation [x | x2] (never built).
     comm / hw_total: x holds only this rank's pixel rows of images with hw_total rows (seqpar.py): the fp64 statistics are
     all-reduced over the ranks between the statistics pass and the apply pass."""
@@ -378,7 +379,9 @@ def groupnorm(x, gamma, beta, groups, eps, silu, out_dtype, want_raw=False, x2=N
     if x2 is not None:
         assert x2.dtype == torch.float32 and x2.is_contiguous() and x2.shape[:2] == (B, HW)
         Cc = C1 + x2.shape[2]
-    if planes:
+    if planes == 2:
+        out_dtype, code, cols = torch.float16, _lib.SX_F16X2, 2 * Cc
+    elif planes:
         out_dtype, code, cols = torch.bfloat16, _lib.SX_BF16X3, 3 * Cc
     else:
         code, cols = _DT[out_dtype], Cc
@@ -511,12 +514,14 @@ def rmsnorm_planes(x, gamma, eps, dtype, tiled=False, want_f32=False, want_plane
 
 
 def rope_kv_append_f32(qkv, kcache, vcache, cos_tab, sin_tab, pos_dev, G, T, H, D, table_dtype):
-    """qkv fp32 [G*T, 3HD] (q rotated in place); fp32 caches [G, H, Tmax, D]; pos_dev int32 [G]."""
+    """qkv fp32 [G*T, 3HD] (q rotated in place); caches [G, H, Tmax, D]: k fp32, v fp32 or — the mixed cache — the model's 16-bit dtype
+    (= table_dtype); pos_dev int32 [G]."""
     assert qkv.dtype == torch.float32 and qkv.is_contiguous() and qkv.shape == (G * T, 3 * H * D)
-    assert kcache.dtype == torch.float32 and vcache.dtype == torch.float32 and kcache.dim() == 4 and kcache.shape[0] == G \
+    assert kcache.dtype == torch.float32 and vcache.dtype in (torch.float32, table_dtype) and kcache.dim() == 4 and kcache.shape[0] == G \
         and kcache[0].is_contiguous() and vcache.stride() == kcache.stride()
-    check(_lib.load().sx_rope_kv_append_f32(_p(qkv), _p(kcache), _p(vcache), _p(cos_tab), _p(sin_tab), _p(pos_dev), G, T, H, D,
-                                            kcache.shape[2], kcache.stride(0), _DT[table_dtype], _stream()), "sx_rope_kv_append_f32")
+    fn = "sx_rope_kv_append_f32" if vcache.dtype == torch.float32 else "sx_rope_kv_append_f32_v16"
+    check(getattr(_lib.load(), fn)(_p(qkv), _p(kcache), _p(vcache), _p(cos_tab), _p(sin_tab), _p(pos_dev), G, T, H, D,
+                                   kcache.shape[2], kcache.stride(0), _DT[table_dtype], _stream()), fn)
 
 
 def attention_f32(qkv, kcache, vcache, pos_dev, G, T, H, D, scale, dtype, tiled=False):
@@ -524,11 +529,13 @@ def attention_f32(qkv, kcache, vcache, pos_dev, G, T, H, D, scale, dtype, tiled=
     head rows at the front of qkv's rows. Returns the planes of the context [G*T, H*D] (see split16)."""
     assert qkv.dtype == torch.float32 and qkv.is_contiguous() and qkv.shape[0] == G * T and qkv.shape[1] >= H * D
     assert kcache.dtype == torch.float32 and kcache.shape[0] == G and kcache.shape[1] == H and kcache.shape[3] == D
+    assert vcache.dtype in (torch.float32, dtype) and vcache.stride() == kcache.stride()
     ret, buf, code = _planes_out(G * T, H * D, dtype, qkv.device, tiled)
     a = _lib.AttnF32Args()
     a.q, a.kcache, a.vcache, a.out, a.pos0_dev = _p(qkv), _p(kcache), _p(vcache), _p(buf), _p(pos_dev)
     a.q_row_stride, a.cache_seq_stride = qkv.stride(0), kcache.stride(0)
     a.G, a.T, a.H, a.D, a.Tmax, a.dtype, a.scale, a.causal = G, T, H, D, kcache.shape[2], code, float(scale), 1
+    a.v16 = 0 if vcache.dtype == torch.float32 else 1
     check(_lib.load().sx_attention_f32(C.byref(a), _stream()), "sx_attention_f32")
     return ret
 

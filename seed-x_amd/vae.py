@@ -15,6 +15,12 @@ Design: NHWC end to end, fp32 residual stream, fp32 accumulation, MFMA operands 
   [hi | lo | hi] per tap, all three products accumulate in the fp32 MFMA accumulators. 16 mantissa bits per operand, fp32's
   exponent range (the fp16 overflow that forces the reference into fp32 cannot occur). Selected exactly when the reference would upcast
   (dtype fp16 and ``config.force_upcast``), or by ``.to(dtype=torch.float32)``, or ``precision="fp32"``.
+  Round 6: an fp16 VAE's parameters ARE fp16 values (``.to(dtype=torch.float16)`` rounded them; ``upcast_vae`` only widens them, and
+  ``_pack`` does the same rounding), so a weight is ONE exact fp16 plane: the 3x3 convs behind a GroupNorm (+ SiLU: bounded outputs)
+  — resnet conv1 / conv2, conv_out, 73 % of the decoder's conv time — take their activations as two fp16 planes [hi | lo]
+  (GroupNorm output mode SX_F16X2) against weight rows duplicated per tap: A·W = Ah·W + Al·W, TWO products instead of three and 22
+  activation mantissa bits instead of 16. The up-sampler convs read the un-normalised stream (the values that overflow fp16 in this
+  VAE), the 1x1 shortcuts the raw block input, attention multiplies two activations: they keep the three bf16 planes.
 * ``fast`` — single 16-bit operands of ``dtype`` (what a bf16 VAE is in the reference; ``precision="fast"`` forces it for
   fp16 too, ≈1.3e-3 rel-L2 from the fp32 result at 1024 px with fp16 operands). 3×3 convolutions = the implicit-GEMM kernel (nearest-2× upsample fused into the conv's gather), GroupNorm+SiLU
 kernels feed it 16-bit operands. The mid block's single 512-wide attention head over (H/8)·(W/8) pixels does not fit the
@@ -228,8 +234,18 @@ class AutoencoderKL:
         sd, dev, dt, c = self._sd, self.device, self.operand_dtype, self.config
         split = self.split
 
+        rounded = self.dtype == torch.float16      # `.to(dtype=torch.float16)` rounds every parameter; the reference's upcast_vae widens THOSE
+
         def f32(k):
-            return sd[k].detach().to(dev, torch.float32).contiguous()
+            t = sd[k].detach().to(dev, torch.float32)
+            return (t.to(torch.float16).float() if rounded else t).contiguous()
+
+        two = split and rounded and os.environ.get("SX_VAE_F16X2", "1") != "0"     # two fp16 activation planes x one exact fp16 weight plane
+
+        def conv16x2(k):
+            """[Co, Ci, 3, 3] exact-in-fp16 weights → fp16 [Co, 9 * 2Ci]: per tap [W | W] against activations [hi | lo]."""
+            w = conv32(k).reshape(-1, 9, sd[k].shape[1]).to(torch.float16)
+            return torch.cat([w, w], dim=2).reshape(w.shape[0], -1).contiguous()
 
         def opnd(w32, taps=1, role="w"):
             """fp32 [N, taps*C] on the device → MFMA operand rows: 16-bit as is, or (fp32-grade mode) bf16 [N, taps*3C] with
@@ -253,10 +269,17 @@ class AutoencoderKL:
             return opnd(wp, taps=taps)
 
         def resnet(n):
-            r = dict(n1=(f32(n + ".norm1.weight"), f32(n + ".norm1.bias")), w1=conv16(n + ".conv1.weight"),
+            short = n + ".conv_shortcut.weight" in sd
+            # p1 / p2: operand planes of conv1 / conv2 (3 = bf16 [hi | hi | lo], 2 = fp16 [hi | lo], 1 = plain). A block with a 1x1
+            # shortcut hands norm1's RAW input to it in the same format as the normalised one: that block's conv1 stays at 3 planes
+            p1 = (2 if (two and not short) else 3) if split else 1
+            p2 = (2 if two else 3) if split else 1
+            r = dict(n1=(f32(n + ".norm1.weight"), f32(n + ".norm1.bias")),
+                     w1=conv16x2(n + ".conv1.weight") if p1 == 2 else conv16(n + ".conv1.weight"),
                      b1=f32(n + ".conv1.bias"), n2=(f32(n + ".norm2.weight"), f32(n + ".norm2.bias")),
-                     w2=conv16(n + ".conv2.weight"), b2=f32(n + ".conv2.bias"))
-            if n + ".conv_shortcut.weight" in sd:
+                     w2=conv16x2(n + ".conv2.weight") if p2 == 2 else conv16(n + ".conv2.weight"), b2=f32(n + ".conv2.bias"),
+                     p1=p1, p2=p2)
+            if short:
                 r["ws"], r["bs"] = lin16(n + ".conv_shortcut.weight"), f32(n + ".conv_shortcut.bias")
             return r
 
@@ -287,7 +310,14 @@ class AutoencoderKL:
         wo = conv32("decoder.conv_out.weight")
         bo = torch.zeros(16, dtype=torch.float32, device=dev)
         bo[:wo.shape[0]] = f32("decoder.conv_out.bias")
-        P["conv_out"] = (padded(wo, 16, wo.shape[1], taps=9), bo)
+        if two:
+            w16 = torch.zeros(16, 9, wo.shape[1] // 9, dtype=torch.float16, device=dev)
+            w16[:wo.shape[0]] = wo.reshape(wo.shape[0], 9, -1).to(torch.float16)
+            P["conv_out"] = (torch.cat([w16, w16], dim=2).reshape(16, -1).contiguous(), bo)
+        else:
+            P["conv_out"] = (padded(wo, 16, wo.shape[1], taps=9), bo)
+        P["p_out"] = (2 if two else 3) if split else 1
+        P["two"] = two
         if self.has_encoder:
             E = {}
             ci = c.in_channels
@@ -326,31 +356,40 @@ class AutoencoderKL:
         """fp32 activation [..., C] → MFMA operand ([..., C] 16-bit, or [..., 3C] bf16 planes)."""
         return ops.split_bf16(x32, role) if self.split else ops.cast(x32, self.operand_dtype)
 
-    def _gn(self, x, gb, silu, want_raw=False, stats=None):
+    def _gn(self, x, gb, silu, want_raw=False, stats=None, planes=3):
         """GroupNorm(+SiLU) of the fp32 stream → operand (and optionally the un-normalised x as an operand).
-        stats: ops.GnStats accumulated by the conv that produced x (its statistics pass is then skipped)."""
+        stats: ops.GnStats accumulated by the conv that produced x (its statistics pass is then skipped).
+        planes (fp32-grade mode): 3 = bf16 [hi | hi | lo], 2 = fp16 [hi | lo] (the consumer's weights are one exact fp16 plane)."""
         G = self.config.norm_num_groups
         if not self.split:
             return ops.groupnorm(x, gb[0], gb[1], G, EPS, silu, self.operand_dtype, want_raw=want_raw, stats=stats)
-        return ops.groupnorm(x, gb[0], gb[1], G, EPS, silu, None, want_raw=want_raw, planes=True, stats=stats)
+        return ops.groupnorm(x, gb[0], gb[1], G, EPS, silu, None, want_raw=want_raw, planes=planes, stats=stats)
+
+    def _conv(self, planes, *a, **kw):
+        """ops.conv3x3 with the bench's FLOP accounting told how many operand planes this launch carries."""
+        old, ops.OPERAND_PLANES = ops.OPERAND_PLANES, planes
+        try:
+            return ops.conv3x3(*a, **kw)
+        finally:
+            ops.OPERAND_PLANES = old
 
     def _resnet(self, r, x, H, W):
         """x: fp32 [1, HW, Ci] → fp32 [1, HW, Co]  (ResnetBlock2D with temb=None [ext])."""
         f32 = torch.float32
         Ci = x.shape[-1]
         if "ws" in r:
-            h, raw = self._gn(x, r["n1"], True, want_raw=True)
+            h, raw = self._gn(x, r["n1"], True, want_raw=True, planes=r["p1"])
         else:
-            h = self._gn(x, r["n1"], True)
+            h = self._gn(x, r["n1"], True, planes=r["p1"])
         # norm2's statistics ride on conv1's epilogue where conv1 runs on a ping-pong tile (Cout >= 256; ops.GnStats)
         st = None
         if r["w1"].shape[0] >= 256 and (H * W) % 256 == 0:
             st = ops.GnStats(torch.zeros((1, self.config.norm_num_groups, 2), dtype=torch.float64, device=x.device),
                              self.config.norm_num_groups, H * W)
-        h = ops.conv3x3(h.view(1, H, W, -1), r["w1"], bias=r["b1"], out_dtype=f32, gn=st)
-        h = self._gn(h, r["n2"], True, stats=st)
+        h = self._conv(r["p1"], h.view(1, H, W, -1), r["w1"], bias=r["b1"], out_dtype=f32, gn=st)
+        h = self._gn(h, r["n2"], True, stats=st, planes=r["p2"])
         sc = ops.gemm(raw.view(H * W, -1), r["ws"], bias=r["bs"], out_dtype=f32) if "ws" in r else x.view(-1, Ci)
-        return ops.conv3x3(h.view(1, H, W, -1), r["w2"], bias=r["b2"], residual=sc, out_dtype=f32)
+        return self._conv(r["p2"], h.view(1, H, W, -1), r["w2"], bias=r["b2"], residual=sc, out_dtype=f32)
 
     def _mid_attention(self, m, x, q_chunk=2048):
         """Attention(heads=1, dim_head=C, residual_connection=True) over the HW pixels of ONE image. x: fp32 [1, HW, C].
@@ -411,9 +450,9 @@ class AutoencoderKL:
             if blk["up"] is not None:
                 x = ops.conv3x3(self._A(x).view(1, H, W, -1), blk["up"][0], bias=blk["up"][1], upsample=True, out_dtype=f32)
                 H, W = 2 * H, 2 * W
-        hN = self._gn(x, P["norm_out"], True)
-        y = ops.conv3x3(hN.view(1, H, W, -1), P["conv_out"][0], bias=P["conv_out"][1], out_dtype=f32,
-                        n_valid=4)                                                   # [1, HW, 4]: RGB + one zero column
+        hN = self._gn(x, P["norm_out"], True, planes=P["p_out"])
+        y = self._conv(P["p_out"], hN.view(1, H, W, -1), P["conv_out"][0], bias=P["conv_out"][1], out_dtype=f32,
+                       n_valid=4)                                                    # [1, HW, 4]: RGB + one zero column
         return ops.nhwc_to_nchw(y, c.out_channels, H, W)
 
     @torch.no_grad()

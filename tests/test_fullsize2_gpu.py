@@ -110,11 +110,15 @@ def test_vae_full_config_1024px(dev):
     g = torch.Generator().manual_seed(31)
     z = torch.randn(1, 4, 128, 128, generator=g)
     img = torch.rand(1, 3, 1024, 1024, generator=g) * 2 - 1
+    h16 = lambda sd: {k: (v.to(torch.float16).to(v.dtype) if v.is_floating_point() else v) for k, v in sd.items()}
     with torch.no_grad():
-        ref = rv.vae_decode(sd_d, A, z.to(dev))
-        ref_e = rv.vae_encode_mode(sd_e, A, img.to(dev))
-    # fp16 + force_upcast = what the reference does (its pipeline upcasts the VAE to fp32): two bf16 planes per operand
+        # the fp16 VAE's parameters are fp16 values (`.to(dtype=torch.float16)`, eval_text2img_seed_x_i.py:61; upcast_vae only widens
+        # them): the oracle is evaluated on those for the fp16 rows, on the fp32 values for bf16's 2e-2
+        ref16, ref16_e = rv.vae_decode(h16(sd_d), A, z.to(dev)), rv.vae_encode_mode(h16(sd_e), A, img.to(dev))
+        ref32, ref32_e = rv.vae_decode(sd_d, A, z.to(dev)), rv.vae_encode_mode(sd_e, A, img.to(dev))
+    # fp16 + force_upcast = what the reference does (its pipeline upcasts the VAE to fp32): fp32-grade operand planes
     for dt, prec, tol in ((torch.float16, None, 1e-4), (torch.float16, "fast", 3e-3), (torch.bfloat16, None, 2e-2)):
+        ref, ref_e = (ref16, ref16_e) if dt == torch.float16 else (ref32, ref32_e)
         vae = AutoencoderKL(block_out_channels=A["block_out_channels"], layers_per_block=A["layers_per_block"])
         vae.load_state_dict(dict(sd_d, **sd_e))
         vae.to(dev, dt, precision=prec)

@@ -41,7 +41,8 @@ def test_rmsnorm_fold_model_level(dev, dt, H, nh, I, L, precise, monkeypatch):
     runs = {}
     for fold in ("1", "0"):
         monkeypatch.setenv("SX_RMS_FOLD", fold)
-        llm = LlamaForCausalLM(dict(cfg), max_cache_len=64, max_batch=G, precise=precise)
+        # (kv_v16=False: this test pins the FOLD's arithmetic at 1e-4; the fp16 default's mixed KV cache — v in 16 bits — sits at 3e-4)
+        llm = LlamaForCausalLM(dict(cfg), max_cache_len=64, max_batch=G, precise=precise, kv_v16=False)
         llm.load_state_dict(dict(sd))
         llm.eval().to(dev, dtype=dt)
         P = llm._pack()

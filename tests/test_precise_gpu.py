@@ -332,8 +332,9 @@ def test_llm_precise_vs_fp32_oracle_and_paths_agree(dev, dt):
     x = torch.randn(1, 37, cfg["hidden_size"], generator=torch.Generator().manual_seed(6)) * 0.5
     logits_ref, _, hn_ref = restated.llama_forward(sd, cfg, x, table_dtype=dt)
     tol = 2e-4 if dt == torch.float16 else 1.5e-3
-    llm = _llm(dev, dt, sd, cfg)
-    assert llm.precise and llm._pack()["kc"].dtype == torch.float32 and llm._P["precise_tiled"]
+    llm = _llm(dev, dt, sd, cfg, kv_v16=False)                      # the all-fp32 cache (the default for bf16; fp16 defaults to the mixed cache)
+    assert llm.precise and llm._pack()["kc"].dtype == torch.float32 and llm._P["vc"].dtype == torch.float32 and llm._P["precise_tiled"]
+    assert _llm(dev, dt, sd, cfg)._pack()["vc"].dtype == (dt if dt == torch.float16 else torch.float32)
     out = llm(inputs_embeds=x.to(dev), output_hidden_states=True)
     e_l, e_h = relerr(out["logits"][0], logits_ref[0]), relerr(out["hidden_states"][-1], hn_ref)
     print(f"precise mini llm {dt}: logits (all positions) {e_l:.2e}, states {e_h:.2e}")
@@ -353,7 +354,7 @@ def test_llm_precise_vs_fp32_oracle_and_paths_agree(dev, dt):
     img_ids = torch.arange(400, 466, dtype=torch.int32, device=dev)
     runs = {}
     for name, G, use_graph in (("single", 1, False), ("batch eager", 16, False), ("batch graph", 16, True)):
-        m = llm if G == 1 else _llm(dev, dt, sd, cfg, max_batch=16)
+        m = llm if G == 1 else _llm(dev, dt, sd, cfg, max_batch=16, kv_v16=False)
         assert m.precise
         m.reset()
         xs = [x[0, :20 + (0 if G == 1 else (g % 3))].to(dev) for g in range(G)]      # ragged prompts in the batch
@@ -388,7 +389,7 @@ def test_llm_precise_non_tiled_shapes_take_the_gemm(dev):
     sd = {k: v.to(dt).float() for k, v in weights.llama_sd(cfg).items()}
     x = torch.randn(1, 12, 128, generator=torch.Generator().manual_seed(8)) * 0.5
     logits_ref, _, _ = restated.llama_forward(sd, cfg, x, table_dtype=dt)
-    llm = _llm(dev, dt, sd, cfg)
+    llm = _llm(dev, dt, sd, cfg, kv_v16=False)
     assert llm.precise and not llm._pack()["precise_tiled"]
     o1 = llm(inputs_embeds=x[:, :8].to(dev), use_cache=True)
     pkv = o1.past_key_values
@@ -396,3 +397,81 @@ def test_llm_precise_non_tiled_shapes_take_the_gemm(dev):
         o = llm(inputs_embeds=x[:, t:t + 1].to(dev), past_key_values=pkv, use_cache=True, logits_positions="last")
         pkv = o.past_key_values
         assert relerr(o.logits[0, -1], logits_ref[0, t]) < 3e-4
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("G,T,H,D,pos", [(3, 1, 4, 128, [0, 17, 130]), (2, 37, 2, 128, [0, 0]), (2, 9, 3, 64, [20, 3])])
+def test_mixed_cache_rope_append_and_attention(dev, dt, G, T, H, D, pos):
+    """The mixed KV cache (round 6): k fp32, v in the model's 16-bit dtype. sx_rope_kv_append_f32_v16 writes exactly the fp32 form's k and
+    the ROUNDED v; sx_attention_f32 with v16 = 1 equals fp64 attention over that rounded v to fp32 noise (the only
+    approximation of the mode is the one rounding of v)."""
+    from seedx_amd import ops
+    Tmax = 256
+    g = torch.Generator().manual_seed(15)
+    half = D // 2
+    cos = torch.rand(Tmax, half, generator=g).to(dev) * 2 - 1
+    sin = torch.rand(Tmax, half, generator=g).to(dev) * 2 - 1
+    posd = torch.tensor(pos, dtype=torch.int32, device=dev)
+    qkv0 = (torch.randn(G * T, 3 * H * D, generator=g) * 1.5).to(dev)
+    kc32, vc32 = torch.zeros(G, H, Tmax, D, device=dev), torch.zeros(G, H, Tmax, D, device=dev)
+    kcm, vcm = torch.zeros(G, H, Tmax, D, device=dev), torch.zeros(G, H, Tmax, D, device=dev, dtype=dt)
+    q_a, q_b = qkv0.clone(), qkv0.clone()
+    ops.rope_kv_append_f32(q_a, kc32, vc32, cos, sin, posd, G, T, H, D, dt)
+    ops.rope_kv_append_f32(q_b, kcm, vcm, cos, sin, posd, G, T, H, D, dt)
+    assert torch.equal(q_a, q_b) and torch.equal(kc32, kcm) and torch.equal(vcm, vc32.to(dt))
+    # attention over a filled cache
+    kc = (torch.randn(G, H, Tmax, D, generator=g) * 1.5).to(dev)
+    v32 = torch.randn(G, H, Tmax, D, generator=g).to(dev)
+    v16 = v32.to(dt)
+    scale = 1.0 / math.sqrt(D)
+    y = ops.attention_f32(qkv0, kc, v16, posd, G, T, H, D, scale, dt)
+    ref = _attn_ref(qkv0.cpu().double()[:, :H * D].reshape(G * T, H, D), kc.cpu(), v16.float().cpu(), pos, T, scale).reshape(G * T, H * D)
+    dense = y[:, :H * D].float() + y[:, H * D:].float()
+    e = relerr(dense, ref)
+    ref32 = _attn_ref(qkv0.cpu().double()[:, :H * D].reshape(G * T, H, D), kc.cpu(), v32.cpu(), pos, T, scale).reshape(G * T, H * D)
+    print(f"mixed-cache attention {dt} G={G} T={T} H={H} D={D}: {e:.2e} vs fp64 over the rounded v; {relerr(dense, ref32):.2e} vs fp32 v")
+    assert e < (2e-6 if dt == torch.float16 else 2e-5)
+    if G * T <= 16 and (H * D) % 32 == 0:
+        yt = ops.attention_f32(qkv0, kc, v16, posd, G, T, H, D, scale, dt, tiled=True)
+        assert torch.equal(yt.dense(), dense)
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_llm_mixed_cache_vs_fp32_oracle_and_paths_agree(dev, dt):
+    """`LlamaForCausalLM(kv_v16=True)` on the miniature decoder: logits against the fp32 oracle (the v rounding is the only 16-bit
+    rounding left in the decoder), prefill == prefill + cached single-token steps, and the graph-replayed lock-step decode equals eager."""
+    cfg = weights.MINI_LLM
+    sd = {k: v.to(dt).float() for k, v in weights.llama_sd(cfg).items()}
+    x = torch.randn(1, 37, cfg["hidden_size"], generator=torch.Generator().manual_seed(6)) * 0.5
+    logits_ref, _, _ = restated.llama_forward(sd, cfg, x, table_dtype=dt)
+    llm = _llm(dev, dt, sd, cfg, kv_v16=True)
+    P = llm._pack()
+    assert llm.precise and llm.kv_v16 and P["kc"].dtype == torch.float32 and P["vc"].dtype == dt
+    out = llm(inputs_embeds=x.to(dev))
+    e_mixed = relerr(out["logits"][0], logits_ref[0])
+    e_f32 = relerr(_llm(dev, dt, sd, cfg, kv_v16=False)(inputs_embeds=x.to(dev))["logits"][0], logits_ref[0])
+    e_plain = relerr(_llm(dev, dt, sd, cfg, precise=False)(inputs_embeds=x.to(dev))["logits"][0], logits_ref[0])
+    print(f"mini llm {dt}: all-fp32 cache {e_f32:.2e}, mixed cache (v 16-bit) {e_mixed:.2e}, plain 16-bit flow {e_plain:.2e}")
+    assert e_mixed < (6e-4 if dt == torch.float16 else 5e-3) and e_mixed < 0.7 * e_plain      # (bf16: why its default stays fp32 v)
+    o1 = llm(inputs_embeds=x[:, :31].to(dev), use_cache=True)
+    pkv = o1.past_key_values
+    for t in range(31, 37):
+        o = llm(inputs_embeds=x[:, t:t + 1].to(dev), past_key_values=pkv, use_cache=True, logits_positions="last")
+        pkv = o.past_key_values
+        # (a last-bit difference between the two GEMM paths flips a few of v's 16-bit roundings: 7e-5 in bf16, whose ulp is 8x fp16's)
+        assert relerr(o.logits[0, -1], out["logits"][0, t]) < (5e-5 if dt == torch.float16 else 3e-4)
+    assert pkv[0][0].dtype == torch.float32 and pkv[0][1].dtype == dt
+    img_ids = torch.arange(400, 466, dtype=torch.int32, device=dev)
+    runs = {}
+    for name, use_graph in (("eager", False), ("graph", True)):
+        m = _llm(dev, dt, sd, cfg, max_batch=16, kv_v16=True)
+        m.reset()
+        m.forward_embeds_batch([x[0, :20 + (g % 3)].to(dev) for g in range(16)], list(range(16)))
+        m._P["cur"].fill_(7)
+        m._P["step"].fill_(0)
+        out_ids = torch.full((16, 8), -1, dtype=torch.int32, device=dev)
+        hid = torch.zeros((16, 8, cfg["hidden_size"]), device=dev)
+        for _ in range(6):
+            m.decode_step(img_ids, out_ids, hid, use_graph=use_graph)
+        runs[name] = (out_ids.clone(), hid.clone())
+    assert torch.equal(runs["eager"][0], runs["graph"][0]) and torch.equal(runs["eager"][1], runs["graph"][1])

@@ -16,6 +16,13 @@ def relerr(a, b):
     return ((a - b).norm() / b.norm()).item()
 
 
+def _as_loaded(sd, dtype):
+    """What the module's parameters are after the reference's `.to(dtype=…)` (eval_text2img_seed_x_i.py:61): an fp16 VAE holds
+    fp16-rounded values — its pipeline's upcast_vae() (pipeline…:569-571) only widens THOSE for the fp32 decode, and so does the HIP
+    module's pack step. The oracle is evaluated on the same values ("same inputs")."""
+    return {k: (v.to(torch.float16).to(v.dtype) if dtype == torch.float16 and v.is_floating_point() else v) for k, v in sd.items()}
+
+
 def _build(cfg, sd, dev, dtype, precision=None):
     from seedx_amd.vae import AutoencoderKL
     m = AutoencoderKL(block_out_channels=cfg["block_out_channels"], layers_per_block=cfg["layers_per_block"],
@@ -61,18 +68,45 @@ def test_groupnorm_writes_planes_directly(dev, C, silu):
     assert torch.equal(y3, ops.split_bf16(y32)) and torch.equal(raw3, ops.split_bf16(x))
 
 
+@pytest.mark.parametrize("C,silu", [(64, True), (320, False)])
+def test_groupnorm_writes_fp16_plane_pairs_and_two_product_conv(dev, C, silu):
+    """SX_F16X2 output of GroupNorm == the fp32 output put through sx_split16 (bit for bit; rows [hi | lo]), same for the raw copy; and a
+    3x3 conv of those planes against per-tap duplicated fp16 weights [W | W] equals the fp64 conv of (fp32 activation, fp16 weight) to
+    fp32-accumulation noise — two MFMA products instead of the bf16 form's three."""
+    from seedx_amd import ops
+    g = torch.Generator().manual_seed(28)
+    x = (torch.randn(2, 24 * 24, C, generator=g) * 3 + 1).to(dev)
+    ga, be = torch.randn(C, generator=g).to(dev), torch.randn(C, generator=g).to(dev)
+    y32 = ops.groupnorm(x, ga, be, 32, 1e-6, silu, torch.float32)
+    y2, raw2 = ops.groupnorm(x, ga, be, 32, 1e-6, silu, None, want_raw=True, planes=2)
+    assert y2.shape == (2, 576, 2 * C) and y2.dtype == torch.float16
+    assert torch.equal(y2.view(-1, 2 * C), ops.split16(y32.view(-1, C), torch.float16))
+    assert torch.equal(raw2.view(-1, 2 * C), ops.split16(x.view(-1, C), torch.float16))
+    if C % 64 == 0:
+        Co = 128
+        w = (torch.randn(Co, C, 3, 3, generator=g) / (3 * C ** 0.5)).to(torch.float16).to(dev)
+        wt = w.permute(0, 2, 3, 1).reshape(Co, 9, C)
+        out = ops.conv3x3(y2.view(2, 24, 24, 2 * C), torch.cat([wt, wt], dim=2).reshape(Co, -1).contiguous(), out_dtype=torch.float32)
+        ref = torch.nn.functional.conv2d(y32.view(2, 24, 24, C).permute(0, 3, 1, 2).double(), w.double(), padding=1)
+        e = relerr(out.view(2, 24, 24, Co).permute(0, 3, 1, 2), ref)
+        print(f"two-fp16-plane 3x3 conv vs fp64: {e:.2e}")
+        assert e < 2e-6
+
+
 @pytest.mark.parametrize("dtype,precision,tol", MODES, ids=IDS)
 def test_vae_decode_mini_vs_oracle(dev, dtype, precision, tol):
     cfg = rv.MINI_VAE
     sd = rv.vae_sd(cfg)
     g = torch.Generator().manual_seed(21)
     z = torch.randn(2, 4, 16, 16, generator=g)
-    ref = rv.vae_decode(sd, cfg, z)
+    ref = rv.vae_decode(_as_loaded(sd, dtype), cfg, z)
     m = _build(cfg, sd, dev, dtype, precision)
     out = m.decode(z.to(dev), return_dict=False)[0]
     e = relerr(out, ref)
-    print(f"mini VAE decode {dtype} precision={precision} (split={m.split}): rel-L2 vs oracle {e:.2e} (ref std {ref.std():.3f})")
+    print(f"mini VAE decode {dtype} precision={precision} (split={m.split}, fp16x2 convs={m._P['two']}): rel-L2 vs oracle {e:.2e} "
+          f"(ref std {ref.std():.3f})")
     assert m.split == (tol == 1e-4)
+    assert m._P["two"] == (dtype == torch.float16 and m.split)        # fp16 parameters are exact fp16 planes: the two-product convs
     assert out.shape == ref.shape == (2, 3, 32, 32) and e < tol
     assert m.decode(z.to(dev)).sample.shape == ref.shape
     assert m.config.scaling_factor == cfg["scaling_factor"] and m.dtype == dtype
@@ -85,7 +119,7 @@ def test_vae_decode_full_config_vs_oracle(dev):
     sd = rv.vae_sd(cfg)
     g = torch.Generator().manual_seed(22)
     z = torch.randn(1, 4, 16, 16, generator=g)
-    ref = rv.vae_decode(sd, cfg, z)
+    ref = rv.vae_decode(_as_loaded(sd, torch.float16), cfg, z)
     for precision, tol in ((None, 1e-4), ("fast", 3e-3)):
         m = _build(cfg, sd, dev, torch.float16, precision)
         out = m.decode(z.to(dev), return_dict=False)[0]
@@ -101,7 +135,7 @@ def test_vae_encode_mode_mini_vs_oracle(dev, dtype, precision, tol):
     sd = dict(rv.vae_sd(cfg), **rv.vae_encoder_sd(cfg))
     g = torch.Generator().manual_seed(24)
     img = torch.randn(2, 3, 32, 32, generator=g).clamp(-1, 1)
-    ref = rv.vae_encode_mode(sd, cfg, img)
+    ref = rv.vae_encode_mode(_as_loaded(sd, dtype), cfg, img)
     m = _build(cfg, sd, dev, dtype, precision)
     out = m.encode(img.to(dev)).latent_dist.mode()
     e = relerr(out, ref)
@@ -117,7 +151,7 @@ def test_vae_encode_full_config_vs_oracle(dev):
     sd = dict(rv.vae_sd(cfg), **rv.vae_encoder_sd(cfg))
     g = torch.Generator().manual_seed(25)
     img = torch.randn(1, 3, 128, 128, generator=g).clamp(-1, 1)
-    ref = rv.vae_encode_mode(sd, cfg, img)
+    ref = rv.vae_encode_mode(_as_loaded(sd, torch.float16), cfg, img)
     for precision, tol in ((None, 1e-4), ("fast", 3e-3)):
         m = _build(cfg, sd, dev, torch.float16, precision)
         out = m.encode(img.to(dev)).latent_dist.mode()
