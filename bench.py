@@ -657,7 +657,7 @@ def measure_roofline(w):
     # traffic: bytes per launch from rocprofv3 --pmc passes of THIS command (tools/bench_pmc_traffic.py; eager launches).
     # Only quoted when the stored profile was taken with the GEMM sources as they are now, at this batch size / config.
     traffic, tnote, tscope = None, "no PMC profile taken with the current GEMM kernels at this batch size / dtype / config", None
-    for name in ("r5_unet_pmc_traffic.json", "r4_unet_pmc_traffic.json"):
+    for name in ("r6_unet_pmc_traffic.json", "r5_unet_pmc_traffic.json"):
         try:
             prof = json.load(open(os.path.join(ROOT, "profiles", name)))
             if prof.get("batch_per_gpu") == BATCH and w.a.config == 0 and prof.get("kernel_source_sha") == _kernel_source_sha() \
@@ -1022,14 +1022,16 @@ def main(argv=None):
                 rec["cpu_baseline"] = cpu_baseline(a.config, full_config1=(a.cpu_baseline == "full" and a.config == 1))
                 # the un-extrapolated CPU figure (BASELINE config 1 end to end on the host cores) is measured once per
                 # round by `bench.py --config 1 --cpu-baseline full` (≈ 1-2 min of CPU) and quoted here from its committed line
-                f1 = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r5_bench_config1_cpu_full.json")
+                f1 = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r6_bench_config1_cpu_full.json")
+                if not os.path.exists(f1):
+                    f1 = f1.replace("r6_", "r5_")
                 if a.config == 0 and "error" not in rec["cpu_baseline"] and os.path.exists(f1):
                     c1 = json.load(open(f1))
                     cb = c1.get("cpu_baseline", {})
                     if "value" in cb:
                         rec["cpu_baseline"]["config1_unextrapolated"] = {
                             "cpu_value": cb["value"], "unit": cb.get("unit"), "cores": cb.get("cores"), "gpu_value": c1.get("value"),
-                            "sample": cb.get("sample"), "file": "profiles/r5_bench_config1_cpu_full.json"}
+                            "sample": cb.get("sample"), "file": "profiles/" + os.path.basename(f1)}
                         rec["cpu_baseline"]["sample"] += ("; un-extrapolated companion (BASELINE config 1, ViT-G forward of 2 crops + ONE "
                                                           "UNet CFG-2 step, %s cores): CPU %.4g vs GPU %.4g gens/s"
                                                           % (cb.get("cores"), cb["value"], c1.get("value") or float("nan")))

@@ -5,12 +5,13 @@
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
 DT=${1:-fp16}
+RN=${2:-r6}      # round tag of the output files
 cd /tmp && export TMPDIR=/tmp
 B="python $R/tools/unet_eager_steps.py --steps 2 --dtype $DT"
 rm -rf /tmp/pf /tmp/pw
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pf -- $B --alg-json /tmp/alg.json > $O/r5_unet_pmc_fetch.log 2>&1; echo "fetch rc=$?"
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/pw -- $B > $O/r5_unet_pmc_write.log 2>&1; echo "write rc=$?"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pf -- $B --alg-json /tmp/alg.json > $O/${RN}_unet_pmc_fetch.log 2>&1; echo "fetch rc=$?"
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/pw -- $B > $O/${RN}_unet_pmc_write.log 2>&1; echo "write rc=$?"
 cd $R
-python tools/bench_pmc_traffic.py /tmp/pf /tmp/pw /tmp/alg.json r5 $O/r5_gemm_traffic_by_shape.txt > $O/r5_unet_pmc_traffic.json 2> $O/r5_pmc.err
-head -3 /tmp/pf/*/*counter_collection.csv | cut -c1-600 > $O/r5_pmc_csv_head.txt
-cut -c1-1500 $O/r5_unet_pmc_traffic.json; tail -3 $O/r5_pmc.err; cat $O/r5_gemm_traffic_by_shape.txt
+python tools/bench_pmc_traffic.py /tmp/pf /tmp/pw /tmp/alg.json $RN $O/${RN}_gemm_traffic_by_shape.txt > $O/${RN}_unet_pmc_traffic.json 2> $O/${RN}_pmc.err
+head -3 /tmp/pf/*/*counter_collection.csv | cut -c1-600 > $O/${RN}_pmc_csv_head.txt
+cut -c1-1500 $O/${RN}_unet_pmc_traffic.json; tail -3 $O/${RN}_pmc.err; cat $O/${RN}_gemm_traffic_by_shape.txt
