@@ -395,6 +395,9 @@ typedef struct sx_attn_f32_args {
   int32_t v16;              /* 0: fp32 V (default); 1: V is 16-bit, in the planes' dtype (head_dim <= 128): the mixed cache          */
 } sx_attn_f32_args;
 int sx_attention_f32(const sx_attn_f32_args* args, void* stream);
+/* tuning / test hook: 1 (default) = causal chunks above 8 tokens at head_dim 128 run on the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32)
+ * flash kernel; 0 = the VALU kernels everywhere (the bit-reference of its test, and the A/B) */
+int sx_attention_f32_variant(int v);
 /* strided 2-D copy of fp32 rows: dst[r][dst_off + c] = src[r][c]  (channel concat of skip connections) */
 int sx_copy2d_f32(const float* src, int64_t src_ld, float* dst, int64_t dst_ld, int64_t rows, int cols,
                   void* stream);

@@ -129,6 +129,7 @@ SIGNATURES = {
     "sx_rope_kv_append_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64, c_i32, c_vp],
     "sx_rope_kv_append_f32_v16": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64, c_i32, c_vp],
     "sx_attention_f32": [C.POINTER(AttnF32Args), c_vp],
+    "sx_attention_f32_variant": [c_i32],
     "sx_copy2d_f32": [c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_vp],
     "sx_add_f32": [c_vp, c_vp, c_vp, c_i64, c_vp],
     "sx_patchify": [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp],

@@ -305,6 +305,135 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const AttnF32P p) {
   }
 }
 
+// ---- the same attention on the matrix pipe, for chunks above 8 tokens (prefill, the forced image chunk) ------------------------------
+// v_mfma_f32_32x32x2_f32 multiplies fp32 operands exactly and accumulates in fp32 — the arithmetic of the VALU kernel above at the fp32
+// MFMA rate (64 FLOP / clk / SIMD = the whole fp32 vector rate in one instruction stream that leaves the VALU free for the softmax).
+// The VALU kernel is O(T^2) FMA work on the vector pipe: 495 us per launch at T = 165 (84 launches per headline step), quadratic from
+// there (BASELINE config 5 prefills 1.5k tokens).
+//   wave = 32 query rows x all visible keys, flash-style over 32-key tiles; workgroup = 4 waves = 128 query rows of one (head, sequence).
+//   S^T[key][q] = K · Q^T: the contraction index is split by LANE HALF, d = 64 (lane >> 5) + step — so a lane's 64 operand values are 256
+//     CONTIGUOUS bytes of its own row, for Q (held in registers for the whole pass, pre-scaled) and for the K tile (16-byte loads straight
+//     from the cache, no LDS: a wave's tile is its own);
+//   softmax per query column: a lane holds 16 of the column's 32 scores, its partner lane ^ 32 the others (one exchange for the max, one
+//     for the sum);
+//   O^T[d][q] += V^T · P^T: step t contracts the t-th key of each lane half (keys 8 (t >> 2) + 4 half + (t & 3): exactly the S^T rows
+//     the half holds, so P feeds the B operand without moving), the A operand is V[key][4 (lane & 31) + block .. ]: one 16-byte (fp32) or
+//     8-byte (16-bit v, the mixed cache) load per step; output row index r of block b is head dim 4 r + b, so a lane ends with 16 groups of
+//     4 CONSECUTIVE head dims of its query row → 8-byte plane stores.
+// D = 128 only (the decoder's head_dim); everything else keeps the VALU kernel.
+typedef float f32x16v_t __attribute__((ext_vector_type(16)));
+template <typename TT, bool V16>
+__global__ __launch_bounds__(256) void attn_f32_mfma_kernel(const AttnF32P p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int D = 128;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int h = blockIdx.y, g = blockIdx.z;
+  const int half = lane >> 5, l32 = lane & 31;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  if (q0 >= p.T) return;                                       // (no barriers in this kernel)
+  int pos0 = p.pos0_dev[g];
+  if (pos0 < 0) pos0 = 0;
+  const int qi = q0 + l32;                                      // this lane's query row (column of S^T / O^T)
+  const bool qok = qi < p.T;
+  const int qc = qok ? qi : p.T - 1;
+  // Q operand: 64 contiguous floats of the lane's row, pre-scaled
+  float qv[64];
+  {
+    const float* qr = p.q + (size_t)((size_t)g * p.T + qc) * p.q_stride + (size_t)h * D + half * 64;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const f32x4_t a = *(const f32x4_t*)(qr + 4 * e);
+      qv[4 * e] = a[0] * p.scale; qv[4 * e + 1] = a[1] * p.scale; qv[4 * e + 2] = a[2] * p.scale; qv[4 * e + 3] = a[3] * p.scale;
+    }
+  }
+  const float* kh = p.kc + (size_t)g * p.seq_stride + (size_t)h * p.head_stride;
+  const size_t vbase = (size_t)g * p.seq_stride + (size_t)h * p.head_stride;
+  f32x16v_t o[4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) o[b][j] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  const int q_last = min(p.T, q0 + 32) - 1;
+  const int kend = min(p.Tmax, pos0 + q_last + 1);              // keys 0 .. kend - 1 are visible to the wave's last row
+  const int vis = pos0 + qi;                                    // last key this lane's row may see
+  for (int k0 = 0; k0 < kend; k0 += 32) {
+    // ---- S^T tile = K[k0 .. k0+31] · Q^T ----
+    const int kr_ = min(k0 + l32, p.Tmax - 1);
+    const float* kr = kh + (size_t)kr_ * p.row_stride + half * 64;
+    f32x16v_t sacc;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) sacc[j] = 0.f;
+    f32x4_t kq[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) kq[e] = *(const f32x4_t*)(kr + 4 * e);
+#pragma unroll
+    for (int e = 0; e < 16; ++e)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kq[e][c], qv[4 * e + c], sacc, 0, 0, 0);
+    // ---- online softmax of the lane's column (16 local keys + the partner's 16) ----
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int key = k0 + (j >> 2) * 8 + half * 4 + (j & 3);
+      sacc[j] = (key <= vis && key < kend) ? sacc[j] : -INFINITY;
+      mx = fmaxf(mx, sacc[j]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = (m_new == -INFINITY) ? 1.f : __expf(m_run - m_new);      // exp(-inf) = 0 on the first visible tile
+    float ls = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const float pr = (sacc[j] == -INFINITY) ? 0.f : __expf(sacc[j] - m_new);
+      sacc[j] = pr;
+      ls += pr;
+    }
+    ls += __shfl_xor(ls, 32, 64);
+    l_run = l_run * alpha + ls;
+    m_run = m_new;
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) o[b][j] *= alpha;
+    // ---- O^T += V^T · P^T ----
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int key = min(k0 + (t >> 2) * 8 + half * 4 + (t & 3), p.Tmax - 1);
+      const size_t vo = vbase + (size_t)key * p.row_stride + 4 * l32;
+      float vv[4];
+      if constexpr (V16) {
+        const u32x2_t w = *(const u32x2_t*)((const unsigned short*)p.vc + vo);
+        vv[0] = TT::to_f32((unsigned short)(w[0] & 0xffffu)); vv[1] = TT::to_f32((unsigned short)(w[0] >> 16));
+        vv[2] = TT::to_f32((unsigned short)(w[1] & 0xffffu)); vv[3] = TT::to_f32((unsigned short)(w[1] >> 16));
+      } else {
+        const f32x4_t w = *(const f32x4_t*)((const float*)p.vc + vo);
+        vv[0] = w[0]; vv[1] = w[1]; vv[2] = w[2]; vv[3] = w[3];
+      }
+#pragma unroll
+      for (int b = 0; b < 4; ++b) o[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[b], sacc[t], o[b], 0, 0, 0);
+    }
+  }
+  // ---- normalise, split into planes, store: lane = query row qi, register j of block b = head dim 4 r_j + b ----
+  if (!qok) return;
+  const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+  const int cols = p.H * D;
+  unsigned short* orow = p.out + (size_t)((size_t)g * p.T + qi) * 2 * cols + (size_t)h * D;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int r = (j >> 2) * 8 + half * 4 + (j & 3);
+    unsigned short hi[4], lo[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) split1<TT>(o[b][j] * inv, hi[b], lo[b]);
+    u32x2_t wh, wl;
+    wh[0] = (unsigned)hi[0] | ((unsigned)hi[1] << 16); wh[1] = (unsigned)hi[2] | ((unsigned)hi[3] << 16);
+    wl[0] = (unsigned)lo[0] | ((unsigned)lo[1] << 16); wl[1] = (unsigned)lo[2] | ((unsigned)lo[3] << 16);
+    *(u32x2_t*)(orow + 4 * r) = wh;
+    *(u32x2_t*)(orow + cols + 4 * r) = wl;
+  }
+#endif
+}
+
 static dim3 gs_grid(int64_t n) {
   int64_t b = (n + 255) / 256;
   if (b > 65535 * 4) b = 65535 * 4;
@@ -376,6 +505,13 @@ extern "C" int sx_rope_kv_append_f32_v16(float* qkv, float* kcache, void* vcache
   return rope_kv_f32_impl(qkv, kcache, vcache16, 1, cos_tab, sin_tab, pos0_dev, G, T, H, D, Tmax, cache_seq_stride, table_dtype, stream);
 }
 
+static int g_attn_f32_mfma = 1;    // 0: chunks above 8 tokens keep the VALU kernel (A/B and the bit-reference of the tests)
+extern "C" int sx_attention_f32_variant(int v) {
+  SX_CHECK(v == 0 || v == 1, "sx_attention_f32_variant: 0 (VALU kernels only) or 1 (fp32 MFMA kernel for chunks above 8 tokens)");
+  g_attn_f32_mfma = v;
+  return SX_OK;
+}
+
 extern "C" int sx_attention_f32(const sx_attn_f32_args* a, void* stream) {
   SX_CHECK(a && a->q && a->kcache && a->vcache && a->out && (a->pos0_dev || !a->causal), "sx_attention_f32: null pointer");
   const int tiled = (a->dtype & SX_TILED16) ? 1 : 0, dt = a->dtype & 0xff;
@@ -393,6 +529,22 @@ extern "C" int sx_attention_f32(const sx_attn_f32_args* a, void* stream) {
   SX_CHECK(p.row_stride % 4 == 0 && p.head_stride % 4 == 0 && p.seq_stride % 4 == 0 && (((uintptr_t)a->kcache) & 15) == 0 &&
            (((uintptr_t)a->vcache) & 15) == 0, "sx_attention_f32: K / V strides and pointers must keep 16-B alignment");
   p.T = a->T; p.H = a->H; p.D = a->D; p.Tmax = a->Tmax; p.tiled = tiled; p.scale = a->scale; p.causal = a->causal ? 1 : 0;
+  const bool mfma = g_attn_f32_mfma && a->causal && a->T > 8 && a->D == 128 && !tiled && (((uintptr_t)a->out) & 7) == 0 &&
+                    p.row_stride % 4 == 0 && a->q_row_stride % 4 == 0;
+  if (mfma) {
+    p.vc = a->vcache;
+    const dim3 grid((a->T + 127) / 128, a->H, a->G);
+    if (a->v16) {
+      SX_CHECK(p.row_stride % 8 == 0 && p.head_stride % 8 == 0 && p.seq_stride % 8 == 0, "sx_attention_f32: 16-bit V rows must be 16-B aligned");
+      if (dt == SX_BF16) hipLaunchKernelGGL((attn_f32_mfma_kernel<BF16, true>), grid, dim3(256), 0, ST, p);
+      else hipLaunchKernelGGL((attn_f32_mfma_kernel<F16, true>), grid, dim3(256), 0, ST, p);
+    } else {
+      if (dt == SX_BF16) hipLaunchKernelGGL((attn_f32_mfma_kernel<BF16, false>), grid, dim3(256), 0, ST, p);
+      else hipLaunchKernelGGL((attn_f32_mfma_kernel<F16, false>), grid, dim3(256), 0, ST, p);
+    }
+    SX_HIP_LAUNCH_CHECK();
+    return SX_OK;
+  }
   if (a->v16) {
     // mixed cache: V in the planes' 16-bit dtype (head_dim <= 128: the decoder's; the resamplers' fp32 views keep the fp32 form)
     SX_CHECK(a->v16 == 1 && a->D <= 128 && p.row_stride % 8 == 0 && p.head_stride % 8 == 0 && p.seq_stride % 8 == 0,
@@ -401,6 +553,10 @@ extern "C" int sx_attention_f32(const sx_attn_f32_args* a, void* stream) {
       const dim3 grid((a->T + 7) / 8, a->H, a->G);
       if (dt == SX_BF16) hipLaunchKernelGGL((attn_f32_kernel<BF16, 8, 1, true>), grid, dim3(256), 0, ST, p);
       else hipLaunchKernelGGL((attn_f32_kernel<F16, 8, 1, true>), grid, dim3(256), 0, ST, p);
+    } else if (a->T == 1) {       // the decode step: ONE query row per workgroup (QB = 4 computes four rows' dot products per key for one valid row)
+      const dim3 grid(1, a->H, a->G);
+      if (dt == SX_BF16) hipLaunchKernelGGL((attn_f32_kernel<BF16, 1, 1, true>), grid, dim3(256), 0, ST, p);
+      else hipLaunchKernelGGL((attn_f32_kernel<F16, 1, 1, true>), grid, dim3(256), 0, ST, p);
     } else {
       const dim3 grid((a->T + 3) / 4, a->H, a->G);
       if (dt == SX_BF16) hipLaunchKernelGGL((attn_f32_kernel<BF16, 4, 1, true>), grid, dim3(256), 0, ST, p);
@@ -417,6 +573,10 @@ extern "C" int sx_attention_f32(const sx_attn_f32_args* a, void* stream) {
     const dim3 grid((a->T + 7) / 8, a->H, a->G);
     if (dt == SX_BF16) hipLaunchKernelGGL((attn_f32_kernel<BF16, 8, 1>), grid, dim3(256), 0, ST, p);
     else hipLaunchKernelGGL((attn_f32_kernel<F16, 8, 1>), grid, dim3(256), 0, ST, p);
+  } else if (a->T == 1) {
+    const dim3 grid(1, a->H, a->G);
+    if (dt == SX_BF16) hipLaunchKernelGGL((attn_f32_kernel<BF16, 1, 1>), grid, dim3(256), 0, ST, p);
+    else hipLaunchKernelGGL((attn_f32_kernel<F16, 1, 1>), grid, dim3(256), 0, ST, p);
   } else {
     const dim3 grid((a->T + 3) / 4, a->H, a->G);
     if (dt == SX_BF16) hipLaunchKernelGGL((attn_f32_kernel<BF16, 4, 1>), grid, dim3(256), 0, ST, p);

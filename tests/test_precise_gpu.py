@@ -475,3 +475,35 @@ def test_llm_mixed_cache_vs_fp32_oracle_and_paths_agree(dev, dt):
             m.decode_step(img_ids, out_ids, hid, use_graph=use_graph)
         runs[name] = (out_ids.clone(), hid.clone())
     assert torch.equal(runs["eager"][0], runs["graph"][0]) and torch.equal(runs["eager"][1], runs["graph"][1])
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("v16", [False, True])
+@pytest.mark.parametrize("G,T,H,pos", [(2, 9, 2, [0, 40]), (3, 37, 2, [0, 5, 130]), (1, 165, 3, [0]), (2, 70, 1, [61, 0]), (1, 300, 2, [200])])
+def test_attention_f32_mfma_kernel(dev, dt, v16, G, T, H, pos):
+    """Causal chunks above 8 tokens at head_dim 128 run the exact-fp32 MFMA flash kernel (v_mfma_f32_32x32x2_f32):
+    against fp64 attention (2e-6, the VALU kernel's bound) and against the VALU kernel itself (sx_attention_f32_variant(0)) — ragged T
+    (not a multiple of 32), chunks that start deep in the cache, partial last key tiles, fp32 and 16-bit (mixed-cache) v."""
+    from seedx_amd import _lib, ops
+    lib = _lib.load()
+    D, Tmax = 128, 512
+    g = torch.Generator().manual_seed(25)
+    qkv = (torch.randn(G * T, 3 * H * D, generator=g) * 1.5).to(dev)
+    kc = (torch.randn(G, H, Tmax, D, generator=g) * 1.5).to(dev)
+    v32 = torch.randn(G, H, Tmax, D, generator=g).to(dev)
+    vc = v32.to(dt) if v16 else v32
+    posd = torch.tensor(pos, dtype=torch.int32, device=dev)
+    scale = 1.0 / math.sqrt(D)
+    ref = _attn_ref(qkv.cpu().double()[:, :H * D].reshape(G * T, H, D), kc.cpu(), vc.float().cpu(), pos, T, scale).reshape(G * T, H * D)
+    try:
+        assert lib.sx_attention_f32_variant(1) == 0
+        y = ops.attention_f32(qkv, kc, vc, posd, G, T, H, D, scale, dt)
+        assert lib.sx_attention_f32_variant(0) == 0
+        y0 = ops.attention_f32(qkv, kc, vc, posd, G, T, H, D, scale, dt)
+    finally:
+        lib.sx_attention_f32_variant(1)
+    dense, dense0 = y[:, :H * D].float() + y[:, H * D:].float(), y0[:, :H * D].float() + y0[:, H * D:].float()
+    e, e0, ee = relerr(dense, ref), relerr(dense0, ref), relerr(dense, dense0)
+    print(f"attention_f32 MFMA {dt} v16={v16} G={G} T={T} H={H} pos={pos}: vs fp64 {e:.2e} (VALU kernel {e0:.2e}), MFMA vs VALU {ee:.2e}")
+    tol = 2e-6 if dt == torch.float16 else 2e-5
+    assert e < tol and ee < tol
