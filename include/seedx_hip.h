@@ -393,6 +393,8 @@ typedef struct sx_attn_f32_args {
   float scale;
   int32_t causal;           /* 1: row t sees keys 0 .. pos0[g] + t; 0: all Tmax keys                                               */
   int32_t v16;              /* 0: fp32 V (default); 1: V is 16-bit, in the planes' dtype (head_dim <= 128): the mixed cache          */
+  int32_t nsplit;           /* T == 1 only: > 1 spreads the keys of every (head, sequence) over nsplit workgroups + a combine launch   */
+  float* scratch;           /* nsplit > 1: fp32 [G][H][nsplit][D + 2] partial results                                                */
 } sx_attn_f32_args;
 int sx_attention_f32(const sx_attn_f32_args* args, void* stream);
 /* tuning / test hook: 1 (default) = causal chunks above 8 tokens at head_dim 128 run on the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32)

@@ -157,16 +157,23 @@ struct AttnF32P {
   long long q_stride, seq_stride, row_stride, head_stride;   // K / V element strides: sequence, key row, head
   int T, H, D, Tmax, tiled, causal;
   float scale;
+  float* part;             // SPLIT kernels: partial results [G][H][nsplit][D + 2] = (unnormalised sum over the split's keys, running max, sum)
+  int nsplit;
 };
 
 // QB query rows per workgroup: 4 for the decode step and short chunks, 8 for prefill (every key row is loaded once per QB rows: the
 // K / V re-reads from L2 halve — 1.5k-token prompts, BASELINE config 5). DC = 8-dim chunks per lane: 1 covers D <= 128 (16 lanes x 8),
 // 2 covers D <= 256 (lane dl owns dims [8 dl, 8 dl + 8) and [128 + 8 dl, 128 + 8 dl + 8): the LLM-side resamplers' head_dim 160).
-template <typename TT, int QB, int DC, bool V16 = false>
+// SPLIT (round 6; T = 1, QB = 1): blockIdx.x is a KEY split, not a query block — a decode step of few sequences (BASELINE config 5:
+// 4 sequences x 40 heads = 160 workgroups on 256 CUs, each walking 1.5k keys in 94 dependent iterations) is latency-bound, not
+// byte-bound; with the keys of a head spread over nsplit workgroups the walk is nsplit times shorter and the chip is full. Every split
+// writes (sum of p v, running max, sum of p) to `part`, attn_f32_combine_kernel merges them in split order (deterministic).
+template <typename TT, int QB, int DC, bool V16 = false, bool SPLIT = false>
 __global__ __launch_bounds__(256) void attn_f32_kernel(const AttnF32P p) {
   constexpr int DW = 8 * DC, DMAX = 128 * DC;
+  static_assert(!SPLIT || (QB == 1 && DC == 1), "key splits: the single-row decode form");
   __shared__ float red[4][QB][DMAX + 4];
-  const int q0 = blockIdx.x * QB, h = blockIdx.y, g = blockIdx.z, D = p.D;
+  const int q0 = SPLIT ? 0 : blockIdx.x * QB, h = blockIdx.y, g = blockIdx.z, D = p.D;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int grp = wave * 4 + (lane >> 4), dl = lane & 15;
   bool dvalid[DC];
@@ -194,8 +201,14 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const AttnF32P p) {
   }
   const float* kh = p.kc + (size_t)g * p.seq_stride + (size_t)h * p.head_stride;
   const size_t vbase = (size_t)g * p.seq_stride + (size_t)h * p.head_stride;
-  const int kend = min(p.Tmax, pos0 + q0 + nq);       // keys 0 .. kend-1 are visible to the block's last row
-  for (int t = grp; t < kend; t += 16) {
+  int kend = min(p.Tmax, pos0 + q0 + nq);       // keys 0 .. kend-1 are visible to the block's last row
+  int kbeg = 0;
+  if constexpr (SPLIT) {                              // this split's share of the keys: chunks of a multiple of 16 keys
+    const int chunk = ((kend + p.nsplit - 1) / p.nsplit + 15) & ~15;
+    kbeg = (int)blockIdx.x * chunk;
+    kend = min(kend, kbeg + chunk);
+  }
+  for (int t = kbeg + grp; t < kend; t += 16) {
     float kf[DW], vf[DW];
 #pragma unroll
     for (int e = 0; e < DW; ++e) { kf[e] = 0.f; vf[e] = 0.f; }
@@ -289,6 +302,12 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const AttnF32P p) {
       acc = fmaf(w, red[gg][i][d], acc);
       lsum = fmaf(w, red[gg][i][DMAX + 1], lsum);
     }
+    if constexpr (SPLIT) {
+      float* pr = p.part + ((size_t)((size_t)g * p.H + h) * p.nsplit + blockIdx.x) * (D + 2);
+      pr[d] = acc;
+      if (d == 0) { pr[D] = mg; pr[D + 1] = lsum; }
+      continue;
+    }
     const float val = lsum > 0.f ? acc / lsum : 0.f;
     unsigned short hi, lo;
     split1<TT>(val, hi, lo);
@@ -302,6 +321,36 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const AttnF32P p) {
       b[0] = hi;
       b[cols] = lo;
     }
+  }
+}
+
+// merge of the key splits of one (head, sequence): thread d adds the partials in split order
+template <typename TT>
+__global__ __launch_bounds__(128) void attn_f32_combine_kernel(const AttnF32P p) {
+  const int h = blockIdx.x, g = blockIdx.y, d = threadIdx.x, D = p.D;
+  if (d >= D) return;
+  const float* pr = p.part + (size_t)((size_t)g * p.H + h) * p.nsplit * (D + 2);
+  float mg = -INFINITY;
+  for (int s = 0; s < p.nsplit; ++s) mg = fmaxf(mg, pr[(size_t)s * (D + 2) + D]);
+  float acc = 0.f, lsum = 0.f;
+  for (int s = 0; s < p.nsplit; ++s) {
+    const float ms = pr[(size_t)s * (D + 2) + D];
+    const float w = (ms == -INFINITY) ? 0.f : __expf(ms - mg);
+    acc = fmaf(w, pr[(size_t)s * (D + 2) + d], acc);
+    lsum = fmaf(w, pr[(size_t)s * (D + 2) + D + 1], lsum);
+  }
+  const float val = lsum > 0.f ? acc / lsum : 0.f;
+  unsigned short hi, lo;
+  split1<TT>(val, hi, lo);
+  const int cols = p.H * D, col = h * D + d;
+  if (p.tiled) {
+    unsigned short* b = p.out + (size_t)(col >> 5) * 512 + (size_t)g * 32 + (col & 31);
+    b[0] = hi;
+    b[(size_t)cols * 16] = lo;
+  } else {
+    unsigned short* b = p.out + (size_t)g * 2 * cols + col;
+    b[0] = hi;
+    b[cols] = lo;
   }
 }
 
@@ -529,6 +578,23 @@ extern "C" int sx_attention_f32(const sx_attn_f32_args* a, void* stream) {
   SX_CHECK(p.row_stride % 4 == 0 && p.head_stride % 4 == 0 && p.seq_stride % 4 == 0 && (((uintptr_t)a->kcache) & 15) == 0 &&
            (((uintptr_t)a->vcache) & 15) == 0, "sx_attention_f32: K / V strides and pointers must keep 16-B alignment");
   p.T = a->T; p.H = a->H; p.D = a->D; p.Tmax = a->Tmax; p.tiled = tiled; p.scale = a->scale; p.causal = a->causal ? 1 : 0;
+  p.part = a->scratch; p.nsplit = a->nsplit;
+  if (a->T == 1 && a->nsplit > 1) {
+    // the decode step of few sequences: key splits + combine (two launches)
+    SX_CHECK(a->scratch && a->causal && a->D <= 128 && a->nsplit <= 64 && (!a->v16 || (p.row_stride % 8 == 0 && p.head_stride % 8 == 0 && p.seq_stride % 8 == 0)),
+             "sx_attention_f32: key splits need scratch [G][H][nsplit][D + 2] floats, a causal T = 1 call and head_dim <= 128");
+    p.vc = a->vcache;
+    const dim3 grid(a->nsplit, a->H, a->G);
+#define SX_SPLIT_GO(TT, V16) hipLaunchKernelGGL((attn_f32_kernel<TT, 1, 1, V16, true>), grid, dim3(256), 0, ST, p)
+    if (dt == SX_BF16) { if (a->v16) SX_SPLIT_GO(BF16, true); else SX_SPLIT_GO(BF16, false); }
+    else { if (a->v16) SX_SPLIT_GO(F16, true); else SX_SPLIT_GO(F16, false); }
+#undef SX_SPLIT_GO
+    SX_HIP_LAUNCH_CHECK();
+    if (dt == SX_BF16) hipLaunchKernelGGL(attn_f32_combine_kernel<BF16>, dim3(a->H, a->G), dim3(128), 0, ST, p);
+    else hipLaunchKernelGGL(attn_f32_combine_kernel<F16>, dim3(a->H, a->G), dim3(128), 0, ST, p);
+    SX_HIP_LAUNCH_CHECK();
+    return SX_OK;
+  }
   const bool mfma = g_attn_f32_mfma && a->causal && a->T > 8 && a->D == 128 && !tiled && (((uintptr_t)a->out) & 7) == 0 &&
                     p.row_stride % 4 == 0 && a->q_row_stride % 4 == 0;
   if (mfma) {

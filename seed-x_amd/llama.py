@@ -166,6 +166,10 @@ class LlamaForCausalLM:
         # Both from the GLOBAL head count: tensor-parallel ranks split exactly like one rank (bit-identical per head).
         self.fused_decode_attention = self.G * self.nh >= 512
         self.decode_nsplit = 1 if self.fused_decode_attention else min(8, max(1, -(-1024 // (self.G * self.nh))))
+        # precise mode's fp32 decode attention: one workgroup per (head, sequence) walks ALL keys — 4 sequences x 40 heads are 160
+        # workgroups of 94 dependent iterations at 1.5k keys (BASELINE config 5: 4 of the token step's 11 ms). Below 512 workgroups the keys
+        # of a head are spread over enough splits for ~1024 (+ a combine launch); from the GLOBAL head count, like decode_nsplit.
+        self.decode_nsplit_f32 = 1 if self.G * self.nh >= 512 else min(16, max(1, -(-1024 // (self.G * self.nh))))
         self.device, self.dtype = None, torch.float16
         self._sd, self._P = None, None
         self._graph = None
@@ -364,6 +368,8 @@ class LlamaForCausalLM:
         P["step"] = torch.zeros(G, dtype=torch.int32, device=dev)        # index into out_ids / hidden buffer
         P["cur"] = torch.zeros(G, dtype=torch.int32, device=dev)         # current input token id
         P["attn_cnt"] = torch.zeros(G * self.nh_l, dtype=torch.int32, device=dev)   # arrival counters of the fused decode attention
+        P["attn_f32_part"] = torch.empty((G, self.nh_l, self.decode_nsplit_f32, self.hd + 2), dtype=torch.float32, device=dev) \
+            if (self.precise and self.decode_nsplit_f32 > 1) else None
         self._P = P
         self._sd = None
         self._graph = None
@@ -535,7 +541,8 @@ class LlamaForCausalLM:
                 h, _ = ops.rmsnorm_planes(x, lw["ln1"], eps, dt, tiled=tl)
                 qkv = lin(h, lw, "wqkv")                                              # [G, 3H] fp32
             ops.rope_kv_append_f32(qkv, P["kc"][li], P["vc"][li], P["cos"], P["sin"], P["pos"], G, 1, nh, hd, dt)
-            att = ops.attention_f32(qkv, P["kc"][li], P["vc"][li], P["pos"], G, 1, nh, hd, scale, dt, tiled=tl)
+            att = ops.attention_f32(qkv, P["kc"][li], P["vc"][li], P["pos"], G, 1, nh, hd, scale, dt, tiled=tl,
+                                    nsplit=self.decode_nsplit_f32, scratch=P["attn_f32_part"])
             if fold:
                 # residual GEMV: fp32 x, the planes of x * gamma of the NEXT norm, the rows' sums of squares; GLU epilogue: planes directly
                 x, x16, ssq = lin(att, lw, "wo", residual=x, emit_norm=True, planes_out=True, norm_gamma=lw["ln2"])

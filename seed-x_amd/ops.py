@@ -524,7 +524,7 @@ def rope_kv_append_f32(qkv, kcache, vcache, cos_tab, sin_tab, pos_dev, G, T, H, 
                                    kcache.shape[2], kcache.stride(0), _DT[table_dtype], _stream()), fn)
 
 
-def attention_f32(qkv, kcache, vcache, pos_dev, G, T, H, D, scale, dtype, tiled=False):
+def attention_f32(qkv, kcache, vcache, pos_dev, G, T, H, D, scale, dtype, tiled=False, nsplit=1, scratch=None):
     """Causal fp32 attention of a T-token chunk per sequence over the fp32 cache (row t sees keys 0 .. pos[g] + t); q = the rotated
     head rows at the front of qkv's rows. Returns the planes of the context [G*T, H*D] (see split16)."""
     assert qkv.dtype == torch.float32 and qkv.is_contiguous() and qkv.shape[0] == G * T and qkv.shape[1] >= H * D
@@ -536,6 +536,11 @@ def attention_f32(qkv, kcache, vcache, pos_dev, G, T, H, D, scale, dtype, tiled=
     a.q_row_stride, a.cache_seq_stride = qkv.stride(0), kcache.stride(0)
     a.G, a.T, a.H, a.D, a.Tmax, a.dtype, a.scale, a.causal = G, T, H, D, kcache.shape[2], code, float(scale), 1
     a.v16 = 0 if vcache.dtype == torch.float32 else 1
+    if nsplit > 1 and T == 1:         # decode step of few sequences: key splits (scratch: fp32 [G, H, nsplit, D + 2])
+        if scratch is None:
+            scratch = torch.empty((G, H, nsplit, D + 2), dtype=torch.float32, device=qkv.device)
+        assert scratch.dtype == torch.float32 and scratch.numel() >= G * H * nsplit * (D + 2)
+        a.nsplit, a.scratch = nsplit, _p(scratch)
     check(_lib.load().sx_attention_f32(C.byref(a), _stream()), "sx_attention_f32")
     return ret
 

@@ -507,3 +507,32 @@ def test_attention_f32_mfma_kernel(dev, dt, v16, G, T, H, pos):
     print(f"attention_f32 MFMA {dt} v16={v16} G={G} T={T} H={H} pos={pos}: vs fp64 {e:.2e} (VALU kernel {e0:.2e}), MFMA vs VALU {ee:.2e}")
     tol = 2e-6 if dt == torch.float16 else 2e-5
     assert e < tol and ee < tol
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("v16", [False, True])
+@pytest.mark.parametrize("G,H,D,pos,nsplit", [(4, 5, 128, [0, 17, 300, 1499], 6), (1, 3, 64, [77], 16), (3, 2, 128, [5, 31, 32], 2)])
+def test_attention_f32_decode_key_splits(dev, dt, v16, G, H, D, pos, nsplit):
+    """The precise decode step (T = 1) with the keys of every (head, sequence) spread over nsplit workgroups + the combine launch
+    (few sequences: BASELINE config 5) against fp64 and against the unsplit kernel; splits that receive no key at all (position 0 with
+    6 splits), positions on a split boundary, the tiled output layout."""
+    from seedx_amd import ops
+    Tmax = 1536
+    g = torch.Generator().manual_seed(35)
+    qkv = (torch.randn(G, 3 * H * D, generator=g) * 1.5).to(dev)
+    kc = (torch.randn(G, H, Tmax, D, generator=g) * 1.5).to(dev)
+    v32 = torch.randn(G, H, Tmax, D, generator=g).to(dev)
+    vc = v32.to(dt) if v16 else v32
+    posd = torch.tensor(pos, dtype=torch.int32, device=dev)
+    scale = 1.0 / math.sqrt(D)
+    ref = _attn_ref(qkv.cpu().double()[:, :H * D].reshape(G, H, D), kc.cpu(), vc.float().cpu(), pos, 1, scale).reshape(G, H * D)
+    y1 = ops.attention_f32(qkv, kc, vc, posd, G, 1, H, D, scale, dt)
+    ys = ops.attention_f32(qkv, kc, vc, posd, G, 1, H, D, scale, dt, nsplit=nsplit)
+    d1, ds = y1[:, :H * D].float() + y1[:, H * D:].float(), ys[:, :H * D].float() + ys[:, H * D:].float()
+    e1, es = relerr(d1, ref), relerr(ds, ref)
+    print(f"decode attention {dt} v16={v16} G={G} H={H} D={D} nsplit={nsplit}: split {es:.2e}, unsplit {e1:.2e} vs fp64")
+    tol = 2e-6 if dt == torch.float16 else 2e-5
+    assert es < tol and e1 < tol
+    if (H * D) % 32 == 0:
+        yt = ops.attention_f32(qkv, kc, vc, posd, G, 1, H, D, scale, dt, tiled=True, nsplit=nsplit)
+        assert torch.equal(yt.dense(), ds)
