@@ -981,3 +981,38 @@ def test_from_pretrained_with_peft_adapter_directory(tmp_path):
     assert torch.equal(m._sd[p + "post_attention_layernorm.weight"], base[p + "post_attention_layernorm.weight"])
     plain = LlamaForCausalLM.from_pretrained(str(bdir))
     assert torch.equal(plain._sd[p + "mlp.up_proj.weight"], base[p + "mlp.up_proj.weight"])
+
+
+def test_attn64_accumulators_are_private(tmp_path):
+    """`attn64_kernel` (csrc/attn.hip; lab-only experiment of round 6) keeps its O^T accumulators in a[0:95] behind the compiler's back:
+    every asm statement that touches them names the registers literally and clobbers all 96. That is only sound while the compiler
+    itself never allocates one of them — checked here on the ISA it generates (cross-compiles without a GPU)."""
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "seed-x_amd", "csrc", "attn.hip")
+    out = tmp_path / "attn.s"
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffast-math", "-fno-finite-math-only", "-mllvm",
+                    "-amdgpu-mfma-vgpr-form=1", "-S", "--cuda-device-only", src, "-o", str(out)], check=True, capture_output=True)
+    lines = out.read_text().splitlines()
+    kernels, cur, in_asm, bad = 0, None, False, []
+    for ln in lines:
+        m = re.match(r"^(_ZN8sxk_attn13attn64_kernel\w+):", ln)
+        if m:
+            cur, kernels = m.group(1), kernels + 1
+            continue
+        if cur is None:
+            continue
+        if "s_endpgm" in ln:
+            cur = None
+            continue
+        if "ASMSTART" in ln:
+            in_asm = True
+        elif "ASMEND" in ln:
+            in_asm = False
+        elif not in_asm:
+            for r in re.finditer(r"\ba(\d+)\b|\ba\[(\d+):\d+\]", ln.split(";")[0]):
+                if int(r.group(1) or r.group(2)) < 96:
+                    bad.append((cur, ln.strip()))
+    assert kernels >= 2, "attn64_kernel instantiations not found in the ISA"
+    assert not bad, f"compiler-generated use of a private accumulator register: {bad[:3]}"

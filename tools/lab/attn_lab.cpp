@@ -71,6 +71,10 @@ int main(int argc, char** argv) {
       SXCHECK(sx_attention(&a, nullptr));
       HCHECK(hipDeviceSynchronize());
       HCHECK(hipMemcpy(ho.data(), o, nq * 2, hipMemcpyDeviceToHost));
+      if (getenv("ATTN_LAB_PROBE")) {             // probe builds (variant 64 + 512 + ..): cycle stamps in the first 16 dwords of O
+        const uint32_t* w = (const uint32_t*)ho.data();
+        for (int wv = 0; wv < 4; ++wv) printf("   probe variant %d wave %d: DMA issue %u | compute %u | vmcnt wait %u | barrier %u cycles (sum over the KV tiles)\n", var, wv, w[wv * 4], w[wv * 4 + 1], w[wv * 4 + 2], w[wv * 4 + 3]);
+      }
       // fp64 spot check of 24 random (b, h, q) rows
       double worst = 0;
       for (int t = 0; t < 24; ++t) {
