@@ -49,22 +49,24 @@ PARITY_BOUND = {
         "ViT-G/448 features, all 48 layers, B = 2 crops": {"asserted": 1e-3, "measured": 3.2e-4, "measured_unrounded_fp32_weights": 8.1e-4,
                                                              "test": "tests/test_fulldepth_gpu.py::test_vit_g_48_layers"},
         "LLM logits (all positions) and final-norm states, all 40 layers at 13B dims: 165-token prefill, decode steps 1 / 64 / 128 "
-        "(precise mode = the default up to 16 lock-step sequences)": {
-            "asserted": 1e-3, "measured": 2.9e-5, "test": "tests/test_fulldepth_gpu.py::test_llama_13b_40_layers_prefill_and_128_decode_steps"},
+        "(precise mode = the default up to 16 lock-step sequences; fp16: mixed KV cache, k fp32 / v 16-bit)": {
+            "asserted": 1e-3, "measured": 5.6e-4, "measured_all_fp32_cache": 2.9e-5,
+            "test": "tests/test_fulldepth_gpu.py::test_llama_13b_40_layers_prefill_and_128_decode_steps, "
+                    "::test_llama_13b_40_layers_all_fp32_cache_floor (asserted 1e-4)"},
         "SDXL UNet latents, 2.57 B parameters at 128x128: one forward 4-ch CFG-2 / 8-ch Bc = 3; 50-step CFG-7.5 loop at steps 1 / 10 / 25 / 50": {
             "asserted": 1e-3, "measured": 8.6e-4, "test": "tests/test_fullsize_gpu.py::test_unet_full_sdxl_forward, "
             "tests/test_fullsize2_gpu.py::test_unet_full_8ch_bc3_forward, ::test_full_size_50_step_t2i_loop_drift"},
         "config-0 generation at full size and depth, every stage against the oracle stage on the SAME inputs (ViT | resamplers + LLM | "
         "ResamplerXLV2 + 50 UNet steps | VAE), every module on the weights a 16-bit checkpoint holds": {
-            "asserted": 1e-3, "measured": [3.1e-4, 2.1e-4, 5.5e-4, 4.3e-4], "measured_unrounded_fp32_weights": [8.3e-4, 6.2e-4, 9.0e-4, 4.3e-4],
+            "asserted": 1e-3, "measured": [3.1e-4, 3.4e-4, 5.5e-4, 6.9e-6], "measured_unrounded_fp32_weights": [8.3e-4, 6.2e-4, 9.0e-4, 4.3e-4],
                                                   "test": "tests/test_fulldepth_gpu.py::test_config0_one_generation_end_to_end"},
-        "same generation, oracle chain on its OWN intermediates (the stages' errors compound)": {"asserted": 2.5e-3, "measured": 5.5e-4,
+        "same generation, oracle chain on its OWN intermediates (the stages' errors compound)": {"asserted": 2.5e-3, "measured": 5.6e-4,
                                                                                                "test": "same"},
-        "SDXL VAE decode / encode at 1024 px (fp32-grade mode)": {"asserted": 1e-4, "measured": 2.0e-5,
+        "SDXL VAE decode / encode at 1024 px (fp32-grade mode: two fp16 activation planes x the checkpoint's exact fp16 weights)": {"asserted": 1e-4, "measured": 1.4e-5,
                                                                   "test": "tests/test_fullsize2_gpu.py::test_vae_full_config_1024px"},
         "lock-step batches above 16 sequences run the LLM's plain 16-bit flow (logged by llama.py; BASELINE config 2's `value` is the "
         "16-sequence precise run, the 32-sequence plain run its companion `value_plain16_batch32`)": {
-            "asserted": 3e-3, "measured": 2.3e-3, "test": "tests/test_fulldepth_gpu.py::test_llama_13b_40_layers_plain16_flow",
+            "asserted": 3e-3, "measured": 2.0e-3, "test": "tests/test_fulldepth_gpu.py::test_llama_13b_40_layers_plain16_flow",
             "note": "40 layers; 7.5e-4 at 2 layers (tests/test_fullsize_gpu.py)"}},
     "bf16": {"rel_l2_vs_fp32_oracle": 1.2e-2, "after_50_unet_steps": 2.5e-2,
              "note": "bf16 eps = 7.8e-3: north_star's 1e-3 is not reachable with one bf16 plane per MFMA operand — the ViT / UNet operands are "
@@ -918,7 +920,8 @@ def main(argv=None):
         # what actually ran (the model's own flag, not the command line): ADVICE r5
         _llm = getattr(getattr(w, "agent", None), "llm", None)
         llm_mode = None if _llm is None else (
-            "precise (fp32-grade activations: two 16-bit operand planes, fp32 q / k / v / KV cache / attention; 40-layer logits asserted at 1e-3)"
+            ("precise (fp32-grade activations: two 16-bit operand planes, fp32 q / k / RoPE / attention; KV cache: k fp32, v %s; 40-layer "
+             "logits asserted at 1e-3)" % ("16-bit (mixed cache)" if getattr(_llm, "kv_v16", False) else "fp32"))
             if _llm.precise else "plain 16-bit (one rounding per MFMA operand, 16-bit KV cache; 40-layer logits asserted at 3e-3)")
         roof = phases = None
         if rank == 0 and gpu and not a.no_roofline:
@@ -973,7 +976,7 @@ def main(argv=None):
                 sync()
                 dt3 = time.perf_counter() - t1
                 plain32 = {"value": 3 * 32 / dt3, "unit": "gens/s", "batch_per_gpu": 32, "ms_per_step": dt3 / 3 * 1e3, "steps": 3, "warmup": 1,
-                           "llm_mode": "plain 16-bit", "parity_bound": {"asserted": 3e-3, "measured": 2.3e-3,
+                           "llm_mode": "plain 16-bit", "parity_bound": {"asserted": 3e-3, "measured": 2.0e-3,
                            "test": "tests/test_fulldepth_gpu.py::test_llama_13b_40_layers_plain16_flow"}}
                 w3 = None
                 BATCH = a.batch
@@ -996,7 +999,7 @@ def main(argv=None):
                           "parity_bound": PARITY_BOUND.get(a.dtype) if gpu else None,
                           "parallelism": "replica x%d (independent generations, no data-path collective)" % world,
                           "batch_per_gpu": a.batch, "request_pipelining": bool(a.overlap),
-                          "vae": ("none" if not USE_VAE else {"fp32": "fp32-grade (two bf16 planes per operand, fp32 accumulation)",
+                          "vae": ("none" if not USE_VAE else {"fp32": "fp32-grade (fp16: two fp16 activation planes x exact fp16 weights; bf16: three bf16 plane products; fp32 accumulation)",
                                                               "fast": "single 16-bit operands"}.get(VAE_PRECISION, "auto"))},
                "flops_per_generation": flops0 if second is not None else (w.flops() if w is not None else None), "generations_per_step": a.batch}
         if gpu and a.config == 2 and plain32 is not None:
