@@ -395,6 +395,14 @@ typedef struct sx_attn_f32_args {
   int32_t v16;              /* 0: fp32 V (default); 1: V is 16-bit, in the planes' dtype (head_dim <= 128): the mixed cache          */
   int32_t nsplit;           /* T == 1 only: > 1 spreads the keys of every (head, sequence) over nsplit workgroups + a combine launch   */
   float* scratch;           /* nsplit > 1: fp32 [G][H][nsplit][D + 2] partial results                                                */
+  /* T == 1, causal, D == 128 only — RoPE + KV append fused into the step (modeling_llama_xformer.py:141-149,204-244 in ONE launch
+   * per layer): rope_cos != NULL means q is the UNROTATED row, k_new / v_new are the new token's rows (row stride q_row_stride: the
+   * qkv buffer's + H*D and + 2*H*D), and the launch appends the rotated k and v (rounded when v16) to kcache / vcache at pos0[g] —
+   * the two cache pointers are written through in this form. NULL (default) = sx_rope_kv_append_f32* ran before. */
+  const float* rope_cos;    /* [Tmax][D/2] fp32 (rounded to the planes' dtype inside, like sx_rope_kv_append_f32)                    */
+  const float* rope_sin;
+  const float* k_new;
+  const float* v_new;
 } sx_attn_f32_args;
 int sx_attention_f32(const sx_attn_f32_args* args, void* stream);
 /* tuning / test hook: 1 (default) = causal chunks above 8 tokens at head_dim 128 run on the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32)

@@ -45,7 +45,8 @@ class AttnF32Args(C.Structure):
     _fields_ = [("q", c_vp), ("kcache", c_vp), ("vcache", c_vp), ("out", c_vp), ("pos0_dev", c_vp),
                 ("q_row_stride", c_i64), ("cache_seq_stride", c_i64), ("kv_row_stride", c_i64), ("kv_head_stride", c_i64),
                 ("G", c_i32), ("T", c_i32), ("H", c_i32), ("D", c_i32), ("Tmax", c_i32), ("dtype", c_i32),
-                ("scale", c_f32), ("causal", c_i32), ("v16", c_i32), ("nsplit", c_i32), ("scratch", c_vp)]
+                ("scale", c_f32), ("causal", c_i32), ("v16", c_i32), ("nsplit", c_i32), ("scratch", c_vp),
+                ("rope_cos", c_vp), ("rope_sin", c_vp), ("k_new", c_vp), ("v_new", c_vp)]
 
 
 class OneshotArgs(C.Structure):

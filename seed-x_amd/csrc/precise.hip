@@ -159,6 +159,14 @@ struct AttnF32P {
   float scale;
   float* part;             // SPLIT kernels: partial results [G][H][nsplit][D + 2] = (unnormalised sum over the split's keys, running max, sum)
   int nsplit;
+  // T = 1 with RoPE fused in (round 6): q is the UNROTATED row of the qkv buffer, knew / vnew the new token's k / v rows (same row stride
+  // as q), cos_t / sin_t the [Tmax][D/2] fp32 tables. The workgroup (the split that owns key pos0[g]) rotates q and k, appends k / v to
+  // the cache — what rope_kv_f32_kernel does in a launch of its own — and attends over keys 0 .. pos0 - 1 from the cache plus the new
+  // key from registers. nullptr = q is rotated and the cache already holds the token.
+  const float* cos_t;
+  const float* sin_t;
+  const float* knew;
+  const float* vnew;
 };
 
 // QB query rows per workgroup: 4 for the decode step and short chunks, 8 for prefill (every key row is loaded once per QB rows: the
@@ -203,10 +211,58 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const AttnF32P p) {
   const size_t vbase = (size_t)g * p.seq_stride + (size_t)h * p.head_stride;
   int kend = min(p.Tmax, pos0 + q0 + nq);       // keys 0 .. kend-1 are visible to the block's last row
   int kbeg = 0;
+  int chunk = kend;
   if constexpr (SPLIT) {                              // this split's share of the keys: chunks of a multiple of 16 keys
-    const int chunk = ((kend + p.nsplit - 1) / p.nsplit + 15) & ~15;
+    chunk = ((kend + p.nsplit - 1) / p.nsplit + 15) & ~15;
     kbeg = (int)blockIdx.x * chunk;
     kend = min(kend, kbeg + chunk);
+  }
+  // ---- RoPE fused into the T = 1 launch (D = 128: lane dl holds dims 8 dl .. 8 dl + 7, its rotation partner lane dl ^ 8 the other half) ----
+  bool own_new = false;                               // this workgroup attends to the NEW key (from registers) and appends it
+  float knew[8], vnew[8];
+  if constexpr (QB == 1 && DC == 1) {
+    if (p.cos_t != nullptr) {
+      const int praw = p.pos0_dev[g];
+      const bool pos_ok = praw >= 0 && praw < p.Tmax;
+      const int pt = pos_ok ? praw : 0, half = D >> 1;
+      const int jb = (dl & 7) * 8;
+      float cs[8], sn[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {                   // tables rounded to the model dtype like the reference's cast (rope_kv_f32_kernel)
+        cs[e] = TT::to_f32(TT::from_f32(p.cos_t[(size_t)pt * half + jb + e]));
+        sn[e] = TT::to_f32(TT::from_f32(p.sin_t[(size_t)pt * half + jb + e]));
+      }
+      const size_t rbase = (size_t)g * p.q_stride + (size_t)h * D;
+      const float* qo = p.q + rbase + dl * 8;
+      const float* qp = p.q + rbase + (dl ^ 8) * 8;
+      const float* ko = p.knew + rbase + dl * 8;
+      const float* kp = p.knew + rbase + (dl ^ 8) * 8;
+      const float* vo = p.vnew + rbase + dl * 8;
+      const float sg = (dl < 8) ? -1.0f : 1.0f;       // first half: x1 c - x2 s; second half: x2 c + x1 s
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        qv[0][e] = (qo[e] * cs[e] + sg * (qp[e] * sn[e])) * p.scale;
+        knew[e] = ko[e] * cs[e] + sg * (kp[e] * sn[e]);
+        vnew[e] = V16 ? TT::to_f32(TT::from_f32(vo[e])) : vo[e];
+      }
+      own_new = pos_ok && (SPLIT ? (praw / chunk == (int)blockIdx.x) : true);
+      if (own_new && grp == 0) {                      // append: one 16-lane group covers the 128 dims
+        float* kd = const_cast<float*>(kh) + (size_t)praw * p.row_stride + dl * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) kd[e] = knew[e];
+        const size_t vo_c = vbase + (size_t)praw * p.row_stride + dl * 8;
+        if constexpr (V16) {
+          unsigned short* vd = (unsigned short*)const_cast<void*>(p.vc) + vo_c;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) vd[e] = TT::from_f32(vo[e]);
+        } else {
+          float* vd = (float*)const_cast<void*>(p.vc) + vo_c;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) vd[e] = vo[e];
+        }
+      }
+      if (pos_ok) kend = min(kend, praw);             // the cache rows below pos; the new key comes from registers
+    }
   }
   for (int t = kbeg + grp; t < kend; t += 16) {
     float kf[DW], vf[DW];
@@ -253,6 +309,24 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const AttnF32P p) {
         for (int e = 0; e < DW; ++e) o[i][e] = fmaf(pr, vf[e], o[i][e] * alpha);
         m_run[i] = m_new;
       }
+    }
+  }
+  if constexpr (QB == 1 && DC == 1) {
+    if (own_new && grp == 0) {                        // the new token's own key / value, straight from the registers
+      float s = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s = fmaf(knew[e], qv[0][e], s);
+      s += __shfl_xor(s, 1, 64);
+      s += __shfl_xor(s, 2, 64);
+      s += __shfl_xor(s, 4, 64);
+      s += __shfl_xor(s, 8, 64);
+      const float m_new = fmaxf(m_run[0], s);
+      const float alpha = __expf(m_run[0] - m_new);
+      const float pr = __expf(s - m_new);
+      l_run[0] = l_run[0] * alpha + pr;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[0][e] = fmaf(pr, vnew[e], o[0][e] * alpha);
+      m_run[0] = m_new;
     }
   }
   // the four 16-lane groups of a wave first (xor-16 / xor-32 butterflies: the same order in every lane), then the four waves through LDS
@@ -579,6 +653,12 @@ extern "C" int sx_attention_f32(const sx_attn_f32_args* a, void* stream) {
            (((uintptr_t)a->vcache) & 15) == 0, "sx_attention_f32: K / V strides and pointers must keep 16-B alignment");
   p.T = a->T; p.H = a->H; p.D = a->D; p.Tmax = a->Tmax; p.tiled = tiled; p.scale = a->scale; p.causal = a->causal ? 1 : 0;
   p.part = a->scratch; p.nsplit = a->nsplit;
+  p.cos_t = a->rope_cos; p.sin_t = a->rope_sin; p.knew = a->k_new; p.vnew = a->v_new;
+  if (a->rope_cos) {
+    SX_CHECK(a->T == 1 && a->causal && a->D == 128 && a->rope_sin && a->k_new && a->v_new && a->kv_row_stride <= 0 + (int64_t)a->D,
+             "sx_attention_f32: the fused RoPE form is the T = 1 causal step at head_dim 128 over the cache layout (rope_sin, k_new, v_new set)");
+    SX_CHECK((((uintptr_t)a->k_new) & 15) == 0 && (((uintptr_t)a->v_new) & 15) == 0, "sx_attention_f32: k_new / v_new alignment");
+  }
   if (a->T == 1 && a->nsplit > 1) {
     // the decode step of few sequences: key splits + combine (two launches)
     SX_CHECK(a->scratch && a->causal && a->D <= 128 && a->nsplit <= 64 && (!a->v16 || (p.row_stride % 8 == 0 && p.head_stride % 8 == 0 && p.seq_stride % 8 == 0)),

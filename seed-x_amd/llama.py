@@ -532,6 +532,7 @@ class LlamaForCausalLM:
                                 w_tiles20=lw.get(k + "_t20") if dtl else None, out_dtype=f32, **kw)
             return ops.gemm(xp, lw[k], a_planes=2, out_dtype=f32, **kw)
         fold = P["rms_fold_precise"]
+        fuse_rope = hd == 128 and os.environ.get("SX_LLM_FUSE_ROPE", "1") != "0"
         x16 = ssq = None
         nl = len(P["layers"])
         for li, lw in enumerate(P["layers"]):
@@ -540,9 +541,13 @@ class LlamaForCausalLM:
             else:
                 h, _ = ops.rmsnorm_planes(x, lw["ln1"], eps, dt, tiled=tl)
                 qkv = lin(h, lw, "wqkv")                                              # [G, 3H] fp32
-            ops.rope_kv_append_f32(qkv, P["kc"][li], P["vc"][li], P["cos"], P["sin"], P["pos"], G, 1, nh, hd, dt)
-            att = ops.attention_f32(qkv, P["kc"][li], P["vc"][li], P["pos"], G, 1, nh, hd, scale, dt, tiled=tl,
-                                    nsplit=self.decode_nsplit_f32, scratch=P["attn_f32_part"])
+            if fuse_rope:           # RoPE + KV append inside the attention launch (one graph node per layer instead of two)
+                att = ops.attention_f32(qkv, P["kc"][li], P["vc"][li], P["pos"], G, 1, nh, hd, scale, dt, tiled=tl,
+                                        nsplit=self.decode_nsplit_f32, scratch=P["attn_f32_part"], rope=(P["cos"], P["sin"]))
+            else:
+                ops.rope_kv_append_f32(qkv, P["kc"][li], P["vc"][li], P["cos"], P["sin"], P["pos"], G, 1, nh, hd, dt)
+                att = ops.attention_f32(qkv, P["kc"][li], P["vc"][li], P["pos"], G, 1, nh, hd, scale, dt, tiled=tl,
+                                        nsplit=self.decode_nsplit_f32, scratch=P["attn_f32_part"])
             if fold:
                 # residual GEMV: fp32 x, the planes of x * gamma of the NEXT norm, the rows' sums of squares; GLU epilogue: planes directly
                 x, x16, ssq = lin(att, lw, "wo", residual=x, emit_norm=True, planes_out=True, norm_gamma=lw["ln2"])

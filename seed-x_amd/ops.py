@@ -524,9 +524,11 @@ def rope_kv_append_f32(qkv, kcache, vcache, cos_tab, sin_tab, pos_dev, G, T, H, 
                                    kcache.shape[2], kcache.stride(0), _DT[table_dtype], _stream()), fn)
 
 
-def attention_f32(qkv, kcache, vcache, pos_dev, G, T, H, D, scale, dtype, tiled=False, nsplit=1, scratch=None):
+def attention_f32(qkv, kcache, vcache, pos_dev, G, T, H, D, scale, dtype, tiled=False, nsplit=1, scratch=None, rope=None):
     """Causal fp32 attention of a T-token chunk per sequence over the fp32 cache (row t sees keys 0 .. pos[g] + t); q = the rotated
-    head rows at the front of qkv's rows. Returns the planes of the context [G*T, H*D] (see split16)."""
+    head rows at the front of qkv's rows. Returns the planes of the context [G*T, H*D] (see split16).
+    rope=(cos, sin) (T == 1, D == 128): qkv holds the UNROTATED q | k | v rows of the new token; the launch rotates q and k, appends k / v
+    to the caches at pos[g] and attends — rope_kv_append_f32 + attention_f32 in one launch per layer."""
     assert qkv.dtype == torch.float32 and qkv.is_contiguous() and qkv.shape[0] == G * T and qkv.shape[1] >= H * D
     assert kcache.dtype == torch.float32 and kcache.shape[0] == G and kcache.shape[1] == H and kcache.shape[3] == D
     assert vcache.dtype in (torch.float32, dtype) and vcache.stride() == kcache.stride()
@@ -541,6 +543,11 @@ def attention_f32(qkv, kcache, vcache, pos_dev, G, T, H, D, scale, dtype, tiled=
             scratch = torch.empty((G, H, nsplit, D + 2), dtype=torch.float32, device=qkv.device)
         assert scratch.dtype == torch.float32 and scratch.numel() >= G * H * nsplit * (D + 2)
         a.nsplit, a.scratch = nsplit, _p(scratch)
+    if rope is not None:
+        assert T == 1 and D == 128 and qkv.shape[1] == 3 * H * D
+        cos, sin = rope
+        a.rope_cos, a.rope_sin = _p(cos), _p(sin)
+        a.k_new, a.v_new = qkv.data_ptr() + 4 * H * D, qkv.data_ptr() + 8 * H * D
     check(_lib.load().sx_attention_f32(C.byref(a), _stream()), "sx_attention_f32")
     return ret
 

@@ -536,3 +536,48 @@ def test_attention_f32_decode_key_splits(dev, dt, v16, G, H, D, pos, nsplit):
     if (H * D) % 32 == 0:
         yt = ops.attention_f32(qkv, kc, vc, posd, G, 1, H, D, scale, dt, tiled=True, nsplit=nsplit)
         assert torch.equal(yt.dense(), ds)
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("v16", [False, True])
+@pytest.mark.parametrize("G,H,pos,nsplit", [(4, 5, [0, 17, 300, 1499], 1), (4, 5, [0, 17, 300, 1499], 6), (2, 3, [31, 32], 2), (16, 40, None, 1),
+                                            (2, 2, [1535, 1536], 4)])
+def test_attention_f32_fused_rope_and_append(dev, dt, v16, G, H, pos, nsplit):
+    """The decode step's RoPE + KV append fused into the T = 1 fp32 attention launch (sx_attn_f32_args.rope_cos ...) against the two-launch
+    form (sx_rope_kv_append_f32[_v16] then sx_attention_f32): the same context planes to fp32 rounding, the same cache rows (k to one ulp
+    of the rotation's fma contraction, v bit-equal), every other cache row untouched; key splits; position 0; a position past the cache
+    (nothing written, the row attends to the whole cache like the two-launch form)."""
+    from seedx_amd import ops
+    D, Tmax = 128, 1536
+    g = torch.Generator().manual_seed(36)
+    if pos is None:
+        pos = [int(x) for x in torch.randint(0, 400, (G,), generator=g)]
+    qkv0 = (torch.randn(G, 3 * H * D, generator=g) * 1.5).to(dev)
+    kc0 = (torch.randn(G, H, Tmax, D, generator=g) * 1.5).to(dev)
+    v32 = torch.randn(G, H, Tmax, D, generator=g).to(dev)
+    vc0 = v32.to(dt) if v16 else v32
+    inv = 1.0 / (10000.0 ** (torch.arange(0, D, 2).float() / D))
+    ang = torch.arange(Tmax).float()[:, None] * inv[None]
+    cos, sin = ang.cos().to(dev).contiguous(), ang.sin().to(dev).contiguous()
+    posd = torch.tensor(pos, dtype=torch.int32, device=dev)
+    scale = 1.0 / math.sqrt(D)
+    qa, ka, va = qkv0.clone(), kc0.clone(), vc0.clone()
+    ops.rope_kv_append_f32(qa, ka, va, cos, sin, posd, G, 1, H, D, dt)
+    ya = ops.attention_f32(qa, ka, va, posd, G, 1, H, D, scale, dt, nsplit=nsplit)
+    qb, kb, vb = qkv0.clone(), kc0.clone(), vc0.clone()
+    yb = ops.attention_f32(qb, kb, vb, posd, G, 1, H, D, scale, dt, nsplit=nsplit, rope=(cos, sin))
+    assert torch.equal(qb, qkv0), "the fused form leaves the qkv buffer alone"
+    da, db = ya[:, :H * D].float() + ya[:, H * D:].float(), yb[:, :H * D].float() + yb[:, H * D:].float()
+    e = relerr(db, da)
+    ek = (kb - ka).abs().max().item() / ka.abs().max().item()
+    print(f"fused rope {dt} v16={v16} G={G} H={H} nsplit={nsplit}: context fused vs two launches {e:.2e}, k rows {ek:.2e}, v rows equal {torch.equal(vb, va)}")
+    assert e < 2e-6 and ek < 2e-7 and torch.equal(vb, va)
+    for gi, pp in enumerate(pos):            # rows other than pos are untouched; a position past the cache writes nothing
+        m = torch.ones(Tmax, dtype=torch.bool, device=dev)
+        if pp < Tmax:
+            m[pp] = False
+        assert torch.equal(kb[gi][:, m], kc0[gi][:, m]) and torch.equal(vb[gi][:, m], vc0[gi][:, m])
+    yt = ops.attention_f32(qkv0.clone(), kc0.clone(), vc0.clone(), posd, G, 1, H, D, scale, dt, tiled=True, nsplit=nsplit, rope=(cos, sin)) \
+        if G <= 16 and (H * D) % 32 == 0 else None
+    if yt is not None:
+        assert torch.equal(yt.dense(), db)
