@@ -154,9 +154,12 @@ __global__ __launch_bounds__(NWV * 64) void gemm_skinny_kernel(const GemvP p) {
   const int S = gridDim.y;                                           // split-K workgroups per row group (1 = none)
   const int nsl = NWV * S, sl = blockIdx.y * NWV + wave;             // k slices: split-K workgroups x waves
   const int ks0 = sl * nks / nsl, ks1 = (sl + 1) * nks / nsl;
+  // x blocks: RB row blocks of 16 activation rows each, times the operand planes — planes2 (fp32-grade activations, x = hi + lo): blocks
+  // 0 .. RB-1 = the hi plane's row blocks, RB .. 2 RB - 1 = the lo plane's (MB = 2: 16 rows; MB = 4, round 6: 17..32 rows)
+  const int RB = p.planes2 ? MB / 2 : MB;
   bool mvalid[MB];
 #pragma unroll
-  for (int b = 0; b < MB; ++b) mvalid[b] = r + 16 * b < p.M;
+  for (int b = 0; b < MB; ++b) mvalid[b] = r + 16 * (b % RB) < p.M;
   // row-major x: a load instruction touches 16 rows 2K bytes apart — for K = 5120 that stride is a multiple of 16 cache
   // lines, so all 16 rows (and every wave on the chip, in step) hit the same L2 channel. Tiled x: the same instruction reads
   // one contiguous 1-KB tile, consecutive k-steps are consecutive tiles.
@@ -198,7 +201,7 @@ __global__ __launch_bounds__(NWV * 64) void gemm_skinny_kernel(const GemvP p) {
     const int per = p.ssq_parts >> 4;                                   // parts % 64 == 0 (host-checked) → per % 4 == 0
 #pragma unroll
     for (int b = 0; b < MB; ++b) {
-      if (b > 0 && p.planes2) break;                                    // block 1 is the lo plane of the same rows: no list of its own
+      if (b >= RB) break;                                               // the lo plane's blocks are the same rows: no list of their own
       const f32x4_t* src = (const f32x4_t*)(p.ssq_in + (size_t)(r + 16 * b) * p.ssq_parts + (size_t)(wave * 4 + g) * per);
       float s0 = 0.f;
 #pragma unroll 5
@@ -213,7 +216,7 @@ __global__ __launch_bounds__(NWV * 64) void gemm_skinny_kernel(const GemvP p) {
     __syncthreads();
 #pragma unroll
     for (int b = 0; b < MB; ++b) {
-      if (b > 0 && p.planes2) break;
+      if (b >= RB) break;
       float tot = 0.f;
 #pragma unroll
       for (int w = 0; w < NWV; ++w) tot += ssq_red[w][r + 16 * b];
@@ -354,9 +357,11 @@ __global__ __launch_bounds__(NWV * 64) void gemm_skinny_kernel(const GemvP p) {
         }
     if (lane == 0) __hip_atomic_store(p.ws_cnt + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  if (MB == 2 && p.planes2) {   // hi-plane + lo-plane products: one activation, rows 0..M-1 (mvalid[1] is false: block 1 stores nothing)
+  if (MB >= 2 && p.planes2) {   // hi-plane + lo-plane products of the same rows: row block rb = blocks rb and RB + rb
 #pragma unroll
-    for (int q = 0; q < R; ++q) v[q][0] += v[q][MB - 1];
+    for (int q = 0; q < R; ++q)
+#pragma unroll
+      for (int b = 0; b < MB / 2; ++b) v[q][b] += v[q][MB / 2 + b];
   }
   if (p.ssq_in) {
 #pragma unroll
@@ -364,13 +369,16 @@ __global__ __launch_bounds__(NWV * 64) void gemm_skinny_kernel(const GemvP p) {
 #pragma unroll
       for (int b = 0; b < MB; ++b)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[q][b][e] *= rstd_fold[b];
+        for (int e = 0; e < 4; ++e)
+          if (b < RB) v[q][b][e] *= rstd_fold[b];
   }
   const int ncols = p.glu ? p.N / 2 : p.N;
 #pragma unroll
+  const size_t lo_off = (size_t)ncols * 16 * (size_t)((p.M + 15) >> 4);   // planes out: the lo plane follows the hi plane's row blocks
   for (int b = 0; b < MB; ++b) {
+    if (b >= RB) break;
     float ssq_l = 0.f;
-    const int m = r + 16 * b;                               // activation row; 16-bit tiles: block b of [MB][ncols/32][16][32]
+    const int m = r + 16 * b;                               // activation row; 16-bit tiles: block b of [RB][ncols/32][16][32]
     const size_t tblk = (size_t)b * (size_t)ncols * 16;
 #pragma unroll
     for (int q = 0; q < (R == 2 ? 2 : 1); ++q) {
@@ -397,7 +405,7 @@ __global__ __launch_bounds__(NWV * 64) void gemm_skinny_kernel(const GemvP p) {
         else { w2[0] = pack2<F16>(o[0], o[1]); w2[1] = pack2<F16>(o[2], o[3]); }
         unsigned short* yt = (unsigned short*)p.y + tblk + (size_t)(col >> 5) * 512 + (size_t)r * 32 + (col & 31);
         *(u32x2_t*)yt = w2;
-        if (p.out_planes) *(u32x2_t*)(yt + (size_t)ncols * 16) = lo_plane(o, w2, p.out_dtype == SX_BF16);   // block 1 = o - hi
+        if (p.out_planes) *(u32x2_t*)(yt + lo_off) = lo_plane(o, w2, p.out_dtype == SX_BF16);   // lo plane = o - hi
       } else if (p.out_dtype == SX_F32) {
         *(f32x4_t*)((float*)p.y + off) = o;
         if (p.x16_out) {     // folded RMSNorm, producer side: the new residual stream also as the next GEMV's 16-bit operand tiles
@@ -409,7 +417,7 @@ __global__ __launch_bounds__(NWV * 64) void gemm_skinny_kernel(const GemvP p) {
           else { w2[0] = pack2<F16>(og[0], og[1]); w2[1] = pack2<F16>(og[2], og[3]); }
           unsigned short* xt = p.x16_out + tblk + (size_t)(col >> 5) * 512 + (size_t)r * 32 + (col & 31);
           *(u32x2_t*)xt = w2;
-          if (p.out_planes) *(u32x2_t*)(xt + (size_t)ncols * 16) = lo_plane(og, w2, std::is_same<TT, BF16>::value);
+          if (p.out_planes) *(u32x2_t*)(xt + lo_off) = lo_plane(og, w2, std::is_same<TT, BF16>::value);
           ssq_l += o[0] * o[0] + o[1] * o[1] + o[2] * o[2] + o[3] * o[3];
         }
       } else {
@@ -419,7 +427,7 @@ __global__ __launch_bounds__(NWV * 64) void gemm_skinny_kernel(const GemvP p) {
         *(u32x2_t*)((unsigned short*)p.y + off) = w2;
       }
     }
-    if (p.ssq_out && !(b > 0 && p.planes2)) {           // (whole wave: rows >= M contribute zeros and are never read)
+    if (p.ssq_out) {                                     // (whole wave: rows >= M contribute zeros and are never read)
       ssq_l += __shfl_xor(ssq_l, 16, 64);
       ssq_l += __shfl_xor(ssq_l, 32, 64);
       if (g == 0) p.ssq_out[(size_t)m * gridDim.x + blockIdx.x] = ssq_l;      // [16 MB][parts]
@@ -953,10 +961,10 @@ extern "C" int sx_gemv(const sx_gemv_args* a, void* stream) {
   SX_CHECK(a->x_planes >= 0 && a->x_planes <= 2, "sx_gemv: x_planes=%d", a->x_planes);
   const bool planes2 = a->x_planes == 2;
   p.planes2 = planes2 ? 1 : 0;
-  SX_CHECK(!planes2 || (a->M <= 16 && a->x_layout == 1), "sx_gemv: x_planes = 2 needs M <= 16 and tiled x (two blocks: hi, lo)");
+  SX_CHECK(!planes2 || a->x_layout == 1, "sx_gemv: x_planes = 2 needs tiled x ([2 planes][row blocks][K/32][16][32])");
   p.out_planes = a->out_planes ? 1 : 0;
   p.x16_gamma = a->x16_gamma;
-  SX_CHECK(!p.out_planes || (a->M <= 16 && (p.y_tiled || a->x16_out)), "sx_gemv: out_planes needs M <= 16 and a tiled 16-bit output (SX_TILED16 or x16_out)");
+  SX_CHECK(!p.out_planes || p.y_tiled || a->x16_out, "sx_gemv: out_planes needs a tiled 16-bit output (SX_TILED16 or x16_out)");
   SX_CHECK(!a->x16_gamma || (a->x16_out && (((uintptr_t)a->x16_gamma) & 15) == 0), "sx_gemv: x16_gamma belongs to x16_out (16-B aligned fp32 [N])");
   SX_CHECK(a->w_layout >= 0 && a->w_layout <= 2, "sx_gemv: w_layout must be 0 (row-major), 1 (decode tiles) or 2 (20-row decode tiles)");
   SX_CHECK(a->w_layout != 2 || (!a->glu && a->N % 20 == 0 && a->N % 32 == 0), "sx_gemv: w_layout 2 needs N %% 20 == 0, N %% 32 == 0, no GLU");
@@ -980,13 +988,17 @@ extern "C" int sx_gemv(const sx_gemv_args* a, void* stream) {
       else if (g_skinny_var[2] == 0 && a->K >= 8192) while (S < 8 && gx * S < 1024 && (a->K / 64) / (2 * S * 4) >= 4) S *= 2;
       const uint64_t cnt_bytes = 16384;    // fixed, so launches of different N can share one workspace (their partial regions
                                            // may overlap — launches are serial — but never reach the counters)
-      if (S > 1 && (gx > 4096 || cnt_bytes + (uint64_t)S * (a->M > 16 || planes2 ? 32 : 16) * a->N * 4 > a->workspace_bytes)) S = 1;   // too small: no split
+      if (S > 1 && (gx > 4096 || cnt_bytes + (uint64_t)S * (a->M > 16 ? (planes2 ? 64 : 32) : (planes2 ? 32 : 16)) * a->N * 4 > a->workspace_bytes)) S = 1;   // too small: no split
       p.ws_cnt = (unsigned*)a->workspace;
       p.ws_part = (float*)((char*)a->workspace + cnt_bytes);
     }
     const dim3 grid(gx, S);
 #define SX_SK_GO(TT)                                                                                          \
-    if (a->M > 16 || planes2) {                                                                                \
+    if (a->M > 16 && planes2) {    /* round 6: 17..32 fp32-grade rows = four operand blocks per weight fragment */      \
+      if (tail20) hipLaunchKernelGGL((gemm_skinny_kernel<TT, 2, 4, 1, true, 4>), grid, dim3(256), 0, ST, p);      \
+      else if (r2) hipLaunchKernelGGL((gemm_skinny_kernel<TT, 2, 4, 1, false, 4>), grid, dim3(256), 0, ST, p);    \
+      else hipLaunchKernelGGL((gemm_skinny_kernel<TT, 1, 4, 2, false, 4>), grid, dim3(256), 0, ST, p);            \
+    } else if (a->M > 16 || planes2) {                                                                                \
       if (g_skinny_var[1] == 1) {       /* lab: 4 k-steps per round (256 VGPRs + AGPR copies, one wave per SIMD) */ \
         if (tail20) hipLaunchKernelGGL((gemm_skinny_kernel<TT, 2, 4, 4, true, 2>), grid, dim3(256), 0, ST, p);   \
         else if (r2) hipLaunchKernelGGL((gemm_skinny_kernel<TT, 2, 4, 4, false, 2>), grid, dim3(256), 0, ST, p); \
