@@ -373,8 +373,8 @@ __global__ __launch_bounds__(NWV * 64) void gemm_skinny_kernel(const GemvP p) {
           if (b < RB) v[q][b][e] *= rstd_fold[b];
   }
   const int ncols = p.glu ? p.N / 2 : p.N;
-#pragma unroll
   const size_t lo_off = (size_t)ncols * 16 * (size_t)((p.M + 15) >> 4);   // planes out: the lo plane follows the hi plane's row blocks
+#pragma unroll
   for (int b = 0; b < MB; ++b) {
     if (b >= RB) break;
     float ssq_l = 0.f;

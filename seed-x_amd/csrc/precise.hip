@@ -25,7 +25,8 @@ __device__ __forceinline__ void split1(float x, unsigned short& hi, unsigned sho
 
 // 8 consecutive columns c8 .. c8+7 of activation row `row` → the two planes.
 //   tiled == 0: out[row][2*cols] = [hi(cols) | lo(cols)]                                   (A operand of sx_gemm, a_planes = 2)
-//   tiled == 1: operand tiles [2][cols/32][16][32], block 0 = hi, block 1 = lo, row < 16  (x operand of sx_gemv, x_planes = 2)
+//   tiled == nrb >= 1: operand tiles [2 planes][nrb row blocks][cols/32][16][32], hi plane first, row < 16 nrb (x operand of sx_gemv,
+//                      x_planes = 2; nrb = 1: <= 16 rows, nrb = 2 (round 6): 17..32 lock-step sequences)
 template <typename TT>
 __device__ __forceinline__ void store_planes8(unsigned short* out, int tiled, int row, int cols, int c8, const float* v) {
   u32x4_t h, l;
@@ -38,9 +39,9 @@ __device__ __forceinline__ void store_planes8(unsigned short* out, int tiled, in
     l[e] = (unsigned)l0 | ((unsigned)l1 << 16);
   }
   if (tiled) {
-    unsigned short* b = out + (size_t)(c8 >> 5) * 512 + (size_t)row * 32 + (c8 & 31);
+    unsigned short* b = out + ((size_t)(row >> 4) * (size_t)(cols >> 5) + (size_t)(c8 >> 5)) * 512 + (size_t)(row & 15) * 32 + (c8 & 31);
     *(u32x4_t*)b = h;
-    *(u32x4_t*)(b + (size_t)cols * 16) = l;
+    *(u32x4_t*)(b + (size_t)cols * 16 * (size_t)tiled) = l;
   } else {
     unsigned short* b = out + (size_t)row * 2 * cols + c8;
     *(u32x4_t*)b = h;
@@ -387,9 +388,10 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const AttnF32P p) {
     split1<TT>(val, hi, lo);
     const int cols = p.H * D, col = h * D + d;
     if (p.tiled) {
-      unsigned short* b = p.out + (size_t)(col >> 5) * 512 + (size_t)(g * p.T + q0 + i) * 32 + (col & 31);
+      const int row = g * p.T + q0 + i;
+      unsigned short* b = p.out + ((size_t)(row >> 4) * (size_t)(cols >> 5) + (size_t)(col >> 5)) * 512 + (size_t)(row & 15) * 32 + (col & 31);
       b[0] = hi;
-      b[(size_t)cols * 16] = lo;
+      b[(size_t)cols * 16 * (size_t)p.tiled] = lo;
     } else {
       unsigned short* b = p.out + (size_t)((size_t)g * p.T + q0 + i) * 2 * cols + col;
       b[0] = hi;
@@ -418,9 +420,9 @@ __global__ __launch_bounds__(128) void attn_f32_combine_kernel(const AttnF32P p)
   split1<TT>(val, hi, lo);
   const int cols = p.H * D, col = h * D + d;
   if (p.tiled) {
-    unsigned short* b = p.out + (size_t)(col >> 5) * 512 + (size_t)g * 32 + (col & 31);
+    unsigned short* b = p.out + ((size_t)(g >> 4) * (size_t)(cols >> 5) + (size_t)(col >> 5)) * 512 + (size_t)(g & 15) * 32 + (col & 31);
     b[0] = hi;
-    b[(size_t)cols * 16] = lo;
+    b[(size_t)cols * 16 * (size_t)p.tiled] = lo;
   } else {
     unsigned short* b = p.out + (size_t)g * 2 * cols + col;
     b[0] = hi;
@@ -571,11 +573,11 @@ using namespace sxk_precise;
 
 extern "C" int sx_split16(const float* x, int64_t ldx, void* out, int rows, int cols, int dtype, void* stream) {
   SX_CHECK(x && out, "sx_split16: null pointer");
-  const int tiled = (dtype & SX_TILED16) ? 1 : 0, dt = dtype & 0xff;
+  const int tiled = (dtype & SX_TILED16) ? (rows + 15) / 16 : 0, dt = dtype & 0xff;     // = the tiled layout's row blocks
   SX_CHECK(dt == SX_F16 || dt == SX_BF16, "sx_split16: dtype");
   SX_CHECK(rows >= 1 && cols >= 8 && cols % 8 == 0 && ldx >= cols && ldx % 4 == 0 && (((uintptr_t)x) & 15) == 0 && (((uintptr_t)out) & 15) == 0,
            "sx_split16: rows=%d cols=%d ldx=%lld (cols %% 8, 16-B aligned rows)", rows, cols, (long long)ldx);
-  SX_CHECK(!tiled || (rows <= 16 && cols % 32 == 0), "sx_split16: operand tiles hold <= 16 rows of cols %% 32 == 0");
+  SX_CHECK(!tiled || (rows <= 32 && cols % 32 == 0), "sx_split16: operand tiles hold <= 32 rows of cols %% 32 == 0");
   const int64_t n = (int64_t)rows * (cols / 8);
   if (dt == SX_BF16) hipLaunchKernelGGL(split16_kernel<BF16>, gs_grid(n), dim3(256), 0, ST, x, (long long)ldx, (unsigned short*)out, rows, cols, tiled);
   else hipLaunchKernelGGL(split16_kernel<F16>, gs_grid(n), dim3(256), 0, ST, x, (long long)ldx, (unsigned short*)out, rows, cols, tiled);
@@ -586,11 +588,11 @@ extern "C" int sx_split16(const float* x, int64_t ldx, void* out, int rows, int 
 extern "C" int sx_rmsnorm_planes(const float* x, const float* gamma, float* y32, void* out16, int rows, int cols, float eps, int dtype,
                                  void* stream) {
   SX_CHECK(x && gamma && (y32 || out16), "sx_rmsnorm_planes: null pointer");
-  const int tiled = (dtype & SX_TILED16) ? 1 : 0, dt = dtype & 0xff;
+  const int tiled = (dtype & SX_TILED16) ? (rows + 15) / 16 : 0, dt = dtype & 0xff;
   SX_CHECK(dt == SX_F16 || dt == SX_BF16, "sx_rmsnorm_planes: dtype");
   SX_CHECK(rows >= 1 && cols >= 8 && cols % 8 == 0 && (((uintptr_t)x) & 15) == 0 && (((uintptr_t)gamma) & 15) == 0,
            "sx_rmsnorm_planes: rows=%d cols=%d (cols %% 8, 16-B aligned)", rows, cols);
-  SX_CHECK(!tiled || !out16 || (rows <= 16 && cols % 32 == 0), "sx_rmsnorm_planes: operand tiles hold <= 16 rows of cols %% 32 == 0");
+  SX_CHECK(!tiled || !out16 || (rows <= 32 && cols % 32 == 0), "sx_rmsnorm_planes: operand tiles hold <= 32 rows of cols %% 32 == 0");
   if (dt == SX_BF16)
     hipLaunchKernelGGL(rmsnorm_planes_kernel<BF16>, dim3(rows), dim3(256), 0, ST, x, gamma, y32, (unsigned short*)out16, cols, eps, tiled);
   else
@@ -637,12 +639,12 @@ extern "C" int sx_attention_f32_variant(int v) {
 
 extern "C" int sx_attention_f32(const sx_attn_f32_args* a, void* stream) {
   SX_CHECK(a && a->q && a->kcache && a->vcache && a->out && (a->pos0_dev || !a->causal), "sx_attention_f32: null pointer");
-  const int tiled = (a->dtype & SX_TILED16) ? 1 : 0, dt = a->dtype & 0xff;
+  const int tiled = (a->dtype & SX_TILED16) ? (int)(((int64_t)a->G * a->T + 15) / 16) : 0, dt = a->dtype & 0xff;   // row blocks of the tiled output
   SX_CHECK(dt == SX_F16 || dt == SX_BF16, "sx_attention_f32: dtype (of the output planes)");
   SX_CHECK(a->D % 8 == 0 && a->D >= 8 && a->D <= 256, "sx_attention_f32: head_dim %d (multiple of 8, <= 256)", a->D);
   SX_CHECK(a->G >= 1 && a->T >= 1 && a->H >= 1 && a->Tmax >= 1, "sx_attention_f32: G/T/H/Tmax");
   SX_CHECK(a->q_row_stride >= (int64_t)a->H * a->D && a->q_row_stride % 4 == 0 && (((uintptr_t)a->q) & 15) == 0, "sx_attention_f32: q_row_stride");
-  SX_CHECK(!tiled || ((int64_t)a->G * a->T <= 16 && (a->H * a->D) % 32 == 0), "sx_attention_f32: operand tiles hold <= 16 rows, H*D %% 32 == 0");
+  SX_CHECK(!tiled || ((int64_t)a->G * a->T <= 32 && (a->H * a->D) % 32 == 0), "sx_attention_f32: operand tiles hold <= 32 rows, H*D %% 32 == 0");
   AttnF32P p;
   p.q = a->q; p.kc = a->kcache; p.out = (unsigned short*)a->out; p.pos0_dev = a->pos0_dev;
   p.q_stride = a->q_row_stride; p.seq_stride = a->cache_seq_stride;

@@ -138,17 +138,17 @@ class LlamaForCausalLM:
         self.Tmax = max_cache_len or c.max_position_embeddings
         self.G = int(max_batch)
         assert 1 <= self.G <= 32, "lock-step batch is limited to 32 sequences (two 16-row operand blocks of sx_gemv)"
-        # fp32-grade activations (module docstring). The skinny GEMM's second operand block carries the lo plane, so the lock-step
-        # batch of the precise mode ends at 16 sequences; larger batches (config 2's 32) run the plain 16-bit flow.
+        # fp32-grade activations (module docstring). Up to 16 sequences the skinny GEMM's two operand blocks are the hi and lo planes; 17..32
+        # sequences (round 6) run four blocks per weight fragment ([2 planes][2 row blocks], gemm_skinny_kernel<.., MB = 4>): the weights
+        # still stream once. SX_LLM_PRECISE32=0 keeps round 5's behaviour (plain 16-bit flow above 16 sequences, logged).
         if precise is None:
             want = os.environ.get("SX_LLM_PRECISE", "1") != "0"
-            precise = want and self.G <= 16
+            precise = want and (self.G <= 16 or os.environ.get("SX_LLM_PRECISE32", "1") != "0")
             if want and not precise:      # never a silent change of numerics
                 logging.getLogger("seedx_amd").warning(
                     "LlamaForCausalLM(max_batch=%d): more than 16 lock-step sequences run the PLAIN 16-bit flow (one rounding per MFMA "
-                    "operand, 16-bit KV cache: logits 2.3e-3 from the fp32 reference at 40 layers, asserted at 3e-3) instead of the precise "
-                    "mode (1e-3 contract; at most 16 sequences: the skinny GEMM's second operand block carries the lo plane). Use "
-                    "max_batch <= 16 for the contract's tolerance.", self.G)
+                    "operand, 16-bit KV cache: logits 2.0e-3 from the fp32 reference at 40 layers, asserted at 3e-3) instead of the precise "
+                    "mode (1e-3 contract) because SX_LLM_PRECISE32=0.", self.G)
         self.precise = bool(precise)
         # precise mode's "mixed" KV cache (round 6): k fp32, v in the model's 16-bit dtype — three quarters of the fp32 cache's bytes
         # (the cache is a third of what a token step moves at 1.5k tokens of context). It costs parity where the round-5 mode had a
@@ -157,7 +157,6 @@ class LlamaForCausalLM:
         # contract) — decided in _pack once the dtype is known; ``kv_v16=False`` / ``SX_LLM_V16=0`` keep the all-fp32 cache.
         self._kv_v16_arg = kv_v16
         self.kv_v16 = False
-        assert not self.precise or self.G <= 16, "precise mode: at most 16 lock-step sequences (the second operand block is the lo plane)"
         # Decode attention (tools/bench_decode_attention_ab.py, 16 sequences x 40 heads, ms per token of the graph-replayed step):
         # three launches (RoPE + append, split-KV attention, combine) with 8 / 2 / 1 KV splits 6.70 / 6.46 / 6.52; ONE launch
         # (sx_attn_decode_fused, bit-identical) with 8 splits 6.80 — its arrival-counter tail costs more than two graph
@@ -345,7 +344,7 @@ class LlamaForCausalLM:
         assert P["rms_fold"] or not fold or not any(lw["wgu_t"] is not None for lw in P["layers"]), \
             "folded decode tiles without the tiled decode path"
         # split-K scratch of the skinny GEMM: counters + 8 partial [16, H] blocks (include/seedx_hip.h: sx_gemv_args.workspace)
-        P["gemv_ws"] = torch.zeros(16384 + 8 * 16 * (2 if self.precise else (self.G + 15) // 16) * self.H * 4, dtype=torch.uint8,
+        P["gemv_ws"] = torch.zeros(16384 + 8 * 16 * ((2 if self.precise else 1) * ((self.G + 15) // 16)) * self.H * 4, dtype=torch.uint8,
                                    device=dev) if P["decode_tiled"] else None
         # precise decode step on the skinny GEMM (operand tiles, two planes): every projection shape must satisfy its MFMA path
         P["precise_tiled"] = all(k % 64 == 0 and k >= 256 for k in (self.H, self.H_l, self.I_l)) and \

@@ -238,9 +238,10 @@ class Tiled16:
     __slots__ = ("t", "rows", "cols", "planes")
 
     def __init__(self, rows, cols, dtype, device, planes=1):
-        """planes = 2 (rows <= 16): block 0 = hi plane, block 1 = lo plane of an fp32-grade activation (sx_gemv x_planes = 2)."""
-        assert rows <= 32 and cols % 32 == 0 and planes in (1, 2) and (planes == 1 or rows <= 16)
-        nb = 2 if planes == 2 else (rows + 15) // 16
+        """planes = 2: [2 planes][row blocks][cols/32][16][32] — the hi plane's row blocks, then the lo plane's, of an fp32-grade activation
+        (sx_gemv x_planes = 2; 17..32 rows = two row blocks per plane, round 6)."""
+        assert rows <= 32 and cols % 32 == 0 and planes in (1, 2)
+        nb = planes * ((rows + 15) // 16)
         self.t, self.rows, self.cols, self.planes = torch.empty((nb, cols // 32, 16, 32), dtype=dtype, device=device), rows, cols, planes
 
     @property
@@ -252,7 +253,8 @@ class Tiled16:
         nb = self.t.shape[0]
         d = self.t.permute(0, 2, 1, 3).reshape(nb * 16, self.cols)
         if self.planes == 2:
-            return d[:self.rows].float() + d[16:16 + self.rows].float()
+            half = (nb // 2) * 16
+            return d[:self.rows].float() + d[half:half + self.rows].float()
         return d[:self.rows].contiguous()
 
 
@@ -299,7 +301,7 @@ def gemv(x, w, residual=None, act=None, glu=False, out_dtype=None, w_tiles=None,
     if y_tiled:
         args.out_dtype |= _lib.SX_TILED16
     if planes_out:
-        assert M <= 16 and (y_tiled or emit_norm)
+        assert y_tiled or emit_norm
         args.out_planes = 1
     if w_tiles is not None and (xt or y_tiled or M >= 5) and K % 64 == 0 and K >= 256 and N % 32 == 0:
         assert w_tiles.shape == w.shape and w_tiles.dtype == w.dtype and w_tiles.is_contiguous()
@@ -573,7 +575,7 @@ def linear_planes(x32, w, w_tiles=None, **kw):
     """epilogue(x32 @ w^T) with x32 fp32 carried as two 16-bit planes: <= 16 rows on the weight-streaming skinny GEMM, else the MFMA GEMM."""
     M, K = x32.shape
     N = w.shape[0]
-    if M <= 16 and K % 64 == 0 and K >= 256 and N % 32 == 0:
+    if M <= 32 and K % 64 == 0 and K >= 256 and N % 32 == 0:
         return gemv(split16(x32, w.dtype, tiled=True), w, w_tiles=w_tiles, **kw)
     return gemm(split16(x32, w.dtype), w, a_planes=2, **kw)
 
