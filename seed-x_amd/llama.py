@@ -24,7 +24,8 @@ logits, past_key_values, hidden_states with the LAST entry = post-final-norm sta
     weights (+ 25.7 GB at 13B) exists for every batch size, not only G >= 5; ``memory_footprint()`` returns the figures before
     anything is allocated, ``_pack`` logs them. The ``past_key_values`` views ``forward`` returns are fp32 in this mode (the reference
     returns the model dtype; they are views of the module's own cache and only meant to be handed back to ``forward``).
-    Lock-step batches above 16 sequences run the plain 16-bit flow (2.3e-3 at 40 layers) — logged once at construction
+    Lock-step batches of 17..32 sequences stay in precise mode (round 6: four operand blocks per weight fragment, 10.9 ms per 32-sequence
+    token step); ``SX_LLM_PRECISE32=0`` sends them to the plain 16-bit flow instead (2.0e-3 at 40 layers) — logged once at construction
   * ``comm`` with world > 1: Megatron tensor parallelism (parallel.py) — this rank owns nh/tp heads (their q/k/v rows, KV
     cache and o_proj columns), I/tp FFN rows (gate/up rows, down_proj columns) and Vpad/tp lm_head rows; the fp32
     residual stream is all-reduced after o_proj and down_proj (rank 0's GEMM epilogue adds the residual), the logits are
