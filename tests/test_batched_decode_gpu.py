@@ -56,10 +56,12 @@ def test_generate_batch_equals_single_runs(dev):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-def test_generate_batch_above_16_sequences(dev, dtype):
+@pytest.mark.parametrize("precise", [False, True])
+def test_generate_batch_above_16_sequences(dev, dtype, precise):
     """20 lock-step sequences: the decode step's skinny GEMMs run two 16-row operand blocks per weight fragment (sx_gemv M = 17..32,
-    tiled activations [2][K/32][16][32]) — same tokens as single-request runs, hidden states within the 16-bit noise (the G >= 5
-    path is MFMA, the single-request path VALU: another summation order)."""
+    tiled activations [2][K/32][16][32]; precise mode, round 6: FOUR blocks = two planes x two row blocks) — same tokens as
+    single-request runs, hidden states within the 16-bit noise in the plain flow (the G >= 5 path is MFMA, the single-request path VALU:
+    another summation order) and within fp32 accumulation noise in precise mode."""
     cfg, vit_dim = weights.MINI_LLM, 128
     sd_llm = weights.llama_sd(cfg)
     sd_agent = weights.agent_sd(cfg, vit_dim, in_grid=4, out_grid=4)
@@ -73,11 +75,12 @@ def test_generate_batch_above_16_sequences(dev, dtype):
                          embeds_cmp_mask=torch.tensor([True]), ids_cmp_mask=mask, patch_positions=torch.tensor([[0.5, 0.5]])))
     tok = StubTokenizer()
     kw = dict(num_img_gen_tokens=16, max_new_tokens=26, eos_token_id=None, force_image_at=3)
-    agent = _agent(dev, dtype, sd_llm, sd_agent, cfg, vit_dim, 20)
-    assert agent.llm._pack()["decode_tiled"] and not agent.llm.precise       # above 16 sequences: the plain 16-bit flow
+    agent = _agent(dev, dtype, sd_llm, sd_agent, cfg, vit_dim, 20, precise=precise)
+    assert agent.llm._pack()["decode_tiled"] and agent.llm.precise == precise
+    assert _agent(dev, dtype, sd_llm, sd_agent, cfg, vit_dim, 20).llm.precise      # the default above 16 sequences is the precise mode now
     batch = agent.generate_batch(tok, reqs, **kw)
-    single = _agent(dev, dtype, sd_llm, sd_agent, cfg, vit_dim, 1, precise=False)   # like with like (the precise default differs by the 16-bit noise)
-    tol = 3e-3 if dtype == torch.float16 else 2.4e-2
+    single = _agent(dev, dtype, sd_llm, sd_agent, cfg, vit_dim, 1, precise=precise)   # like with like
+    tol = (3e-3 if dtype == torch.float16 else 2.4e-2) if not precise else (2e-4 if dtype == torch.float16 else 2e-3)
     same = 0
     for r in (0, 7, 15, 16, 19):                       # rows of both operand blocks
         one = single.generate_batch(tok, [reqs[r]], **kw)[0]

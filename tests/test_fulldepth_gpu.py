@@ -182,15 +182,14 @@ def test_llama_13b_40_layers_all_fp32_cache_floor(dev, llm40):
 
 
 def test_llama_13b_40_layers_plain16_flow(dev, llm40):
-    """The plain 16-bit flow (`precise=False`: one 16-bit rounding per MFMA operand, 16-bit KV cache) at FULL depth — the flow a
-    lock-step batch above 16 sequences runs (BASELINE config 2 at batch 32; llama.py logs the switch) and the row
-    "lock-step batches above 16 sequences" of bench.py's PARITY_BOUND: all-position prefill logits and 8 cached decode steps of
+    """The plain 16-bit flow (`precise=False` / SX_LLM_PRECISE=0: one 16-bit rounding per MFMA operand, 16-bit KV cache) at FULL depth — the
+    companion run of BASELINE config 2 (`value_plain16_batch32`) and the plain-flow row of bench.py's PARITY_BOUND: all-position prefill logits and 8 cached decode steps of
     the 40-layer decoder against the fp32 oracle, asserted at 3e-3 (measured 2.3e-3 in round 4; north_star's 1e-3 is met by the
     precise mode only — the test above)."""
     from seedx_amd.llama import LlamaForCausalLM
     cfg, sd, _ = llm40
-    llm = LlamaForCausalLM(dict(cfg), max_cache_len=256, max_batch=32)
-    assert not llm.precise                                   # above 16 lock-step sequences: the plain flow
+    llm = LlamaForCausalLM(dict(cfg), max_cache_len=256, max_batch=32, precise=False)
+    assert not llm.precise
     llm.load_state_dict(sd)
     llm.eval().to(dev, DT)
     llm._pack()
