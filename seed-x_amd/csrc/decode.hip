@@ -143,7 +143,7 @@ __global__ __launch_bounds__(NWV * 64) void gemm_skinny_kernel(const GemvP p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   typedef typename TT::vec8 vec8;
   static_assert(!TAIL || R == 2, "the 20-row variant is two MFMA row blocks");
-  __shared__ float red[NWV][R * MB][64][4];
+  __shared__ float red[NWV - 1][R * MB][64][4];   // waves 1 .. NWV-1 hand their partial sums to wave 0 (which keeps its own in registers)
   // the wave index as a SCALAR: everything derived from it (k range, round counts) then lives in SGPRs and the guards below
   // are scalar branches. With a VGPR-derived count the compiler predicates the guarded MFMAs through EXEC instead — and
   // MFMA ignores EXEC: the skipped k-steps' (never loaded) registers were multiplied in (found by tools/lab/gemv_lab).
@@ -299,15 +299,18 @@ __global__ __launch_bounds__(NWV * 64) void gemm_skinny_kernel(const GemvP p) {
       consume(A, rem);
     }
   }
+  if (wave != 0) {
 #pragma unroll
-  for (int q = 0; q < R; ++q)
+    for (int q = 0; q < R; ++q)
 #pragma unroll
-    for (int b = 0; b < MB; ++b)
+      for (int b = 0; b < MB; ++b)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) red[wave][q * MB + b][lane][e] = acc[q][b][e];
+        for (int e = 0; e < 4; ++e) red[wave - 1][q * MB + b][lane][e] = acc[q][b][e];
+  }
   __syncthreads();
   if (wave != 0) return;
-  // lane holds y[m = 16 b + r][n0 + q*16 + 4g + e], e = 0..3
+  // lane holds y[m = 16 b + r][n0 + q*16 + 4g + e], e = 0..3; the waves' partial sums are added in wave order (0 + w0 == w0: the same bits as
+  // when wave 0 went through LDS too)
   f32x4_t v[R][MB];
 #pragma unroll
   for (int q = 0; q < R; ++q)
@@ -315,9 +318,9 @@ __global__ __launch_bounds__(NWV * 64) void gemm_skinny_kernel(const GemvP p) {
     for (int b = 0; b < MB; ++b)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        float t = 0.f;
+        float t = acc[q][b][e];
 #pragma unroll
-        for (int w = 0; w < NWV; ++w) t += red[w][q * MB + b][lane][e];
+        for (int w = 0; w + 1 < NWV; ++w) t += red[w][q * MB + b][lane][e];
         v[q][b][e] = t;
       }
   if (S > 1) {
@@ -381,16 +384,16 @@ __global__ __launch_bounds__(NWV * 64) void gemm_skinny_kernel(const GemvP p) {
     const int m = r + 16 * b;                               // activation row; 16-bit tiles: block b of [RB][ncols/32][16][32]
     const size_t tblk = (size_t)b * (size_t)ncols * 16;
 #pragma unroll
-    for (int q = 0; q < (R == 2 ? 2 : 1); ++q) {
+    for (int q = 0; q < R; ++q) {
       if (!mvalid[b]) break;
       if (TAIL && q == 1 && g != 0) break;           // block 1 holds rows 16..19 only: output columns n0 + 16 .. n0 + 19 (lane group 0)
       f32x4_t o;
       int col;
       if (p.glu) {
-        if (q == 1) break;
-        col = blockIdx.x * 16 + 4 * g;
+        if (2 * q + 1 >= R) break;                       // GLU: row groups (2 q, 2 q + 1) = one packed [16 linear | 16 gate] group
+        col = (blockIdx.x * (R / 2) + q) * 16 + 4 * g;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = v[0][b][e] * apply_act(v[R - 1][b][e], p.act);
+        for (int e = 0; e < 4; ++e) o[e] = v[2 * q][b][e] * apply_act(v[(2 * q + 1) % R][b][e], p.act);
       } else {
         col = n0 + q * 16 + 4 * g;
 #pragma unroll
@@ -919,9 +922,10 @@ inline dim3 gs_grid(int64_t n) {
 using namespace sxk_decode;
 
 #define ST ((hipStream_t)stream)
-static int g_skinny_var[3] = {0, 0, 0};  // tuning hook (sx_gemv_tune): [2] = split-K factor (0 auto, -1 never, 2 / 4 / 8 forced)
+static int g_skinny_var[4] = {0, 0, 0, 1};   // [3] = 64-row workgroups (R = 4): 0 never, 1 where >= 200 workgroups remain (round 6), 2 wherever legal  // tuning hook (sx_gemv_tune): [2] = split-K factor (0 auto, -1 never, 2 / 4 / 8 forced)
 extern "C" int sx_gemv_tune(int key, int value) {
-  SX_CHECK((key == 2 && (value == -1 || value == 0 || value == 1 || value == 2 || value == 4 || value == 8)) || (key == 1 && (value == 0 || value == 1 || value == 2)),
+  SX_CHECK((key == 2 && (value == -1 || value == 0 || value == 1 || value == 2 || value == 4 || value == 8)) || (key == 1 && (value == 0 || value == 1 || value == 2)) ||
+               (key == 3 && value >= 0 && value <= 2),
            "sx_gemv_tune: key %d value %d", key, value);
   g_skinny_var[key] = value;
   return SX_OK;
@@ -978,7 +982,13 @@ extern "C" int sx_gemv(const sx_gemv_args* a, void* stream) {
     // MFMA skinny GEMM: R = 2 row groups per wave for GLU (one packed group) or when that still gives >= 256 blocks
     const bool tail20 = a->w_layout == 2;
     const bool r2 = !tail20 && (a->glu || a->N / 32 >= 256);
-    const int gx = tail20 ? a->N / 20 : (r2 ? a->N / 32 : a->N / 16);
+    // 64-row workgroups (R = 4, one k-step per round): every workgroup re-reads the whole x operand from L2 (64 B x K per 16-row block) —
+    // with two planes that traffic is as large as the weight stream itself and its time ADDS to it (tools/bench_skinny_shapes.py:
+    // qkv 26 / 32 / 43 us with 1 / 2 / 4 x blocks). Twice the rows per workgroup halve it; only where enough workgroups remain to fill
+    // the chip (qkv at 13B: 240, measured faster than 480 32-row ones), and not together with the RMSNorm-fold producer outputs (20-row
+    // tiles anyway)
+    const bool r4 = r2 && g_skinny_var[3] > 0 && a->N % 64 == 0 && !a->x16_out && (a->N / 64 >= (g_skinny_var[3] == 2 ? 64 : 200));
+    const int gx = tail20 ? a->N / 20 : (r4 ? a->N / 64 : (r2 ? a->N / 32 : a->N / 16));
     // split-K over workgroups when the row groups alone do not fill the chip (N = 5120: 320 workgroups on 256 CUs, the CUs
     // with two of them set the time) AND the kernel is long enough to pay for the second pass (publish, count, re-read: ~4 us
     // at the kernel's tail): tools/lab/gemv_lab — down 5120x13824 36.8 -> 33.0 us with S = 4, o 5120x5120 15.4 -> 17.6 (never)
@@ -994,10 +1004,15 @@ extern "C" int sx_gemv(const sx_gemv_args* a, void* stream) {
     }
     const dim3 grid(gx, S);
 #define SX_SK_GO(TT)                                                                                          \
-    if (a->M > 16 && planes2) {    /* round 6: 17..32 fp32-grade rows = four operand blocks per weight fragment */      \
+    if (a->M > 16 && planes2 && r4) {                                                                          \
+      hipLaunchKernelGGL((gemm_skinny_kernel<TT, 4, 4, 1, false, 4>), grid, dim3(256), 0, ST, p);              \
+    } else if (a->M > 16 && planes2) {    /* round 6: 17..32 fp32-grade rows = four operand blocks per weight fragment */      \
       if (tail20) hipLaunchKernelGGL((gemm_skinny_kernel<TT, 2, 4, 1, true, 4>), grid, dim3(256), 0, ST, p);      \
       else if (r2) hipLaunchKernelGGL((gemm_skinny_kernel<TT, 2, 4, 1, false, 4>), grid, dim3(256), 0, ST, p);    \
       else hipLaunchKernelGGL((gemm_skinny_kernel<TT, 1, 4, 2, false, 4>), grid, dim3(256), 0, ST, p);            \
+    } else if (r4) {                                                                                           \
+      if (a->M > 16 || planes2) hipLaunchKernelGGL((gemm_skinny_kernel<TT, 4, 4, 1, false, 2>), grid, dim3(256), 0, ST, p); \
+      else hipLaunchKernelGGL((gemm_skinny_kernel<TT, 4, 4, 2, false, 1>), grid, dim3(256), 0, ST, p);         \
     } else if (a->M > 16 || planes2) {                                                                                \
       if (g_skinny_var[1] == 1) {       /* lab: 4 k-steps per round (256 VGPRs + AGPR copies, one wave per SIMD) */ \
         if (tail20) hipLaunchKernelGGL((gemm_skinny_kernel<TT, 2, 4, 4, true, 2>), grid, dim3(256), 0, ST, p);   \
