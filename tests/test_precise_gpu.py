@@ -117,7 +117,8 @@ def test_gemv_two_planes(dev, dt, M):
     from seedx_amd.llama import glu_pack_rows
     g = torch.Generator().manual_seed(3 + M)
     for (N, K, glu, res, layout) in [(1536, 512, False, False, "rm"), (5120, 1024, False, True, "t20"), (5120, 5120, False, True, "t"),
-                                     (2816, 512, True, False, "t"), (640, 13824, False, True, "t")]:
+                                     (2816, 512, True, False, "t"), (640, 13824, False, True, "t"),
+                                     (15360, 512, False, False, "t"), (27648, 256, True, False, "t")]:     # 64-row workgroups (R = 4, round 6)
         x = torch.randn(M, K, generator=g).to(dev)
         w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(dev, dt)
         r = torch.randn(M, N, generator=g).to(dev) if res else None
