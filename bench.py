@@ -49,7 +49,7 @@ PARITY_BOUND = {
         "ViT-G/448 features, all 48 layers, B = 2 crops": {"asserted": 1e-3, "measured": 3.2e-4, "measured_unrounded_fp32_weights": 8.1e-4,
                                                              "test": "tests/test_fulldepth_gpu.py::test_vit_g_48_layers"},
         "LLM logits (all positions) and final-norm states, all 40 layers at 13B dims: 165-token prefill, decode steps 1 / 64 / 128 "
-        "(precise mode = the default up to 16 lock-step sequences; fp16: mixed KV cache, k fp32 / v 16-bit)": {
+        "(precise mode = the default for every lock-step batch size up to 32; fp16: mixed KV cache, k fp32 / v 16-bit)": {
             "asserted": 1e-3, "measured": 5.6e-4, "measured_all_fp32_cache": 2.9e-5,
             "test": "tests/test_fulldepth_gpu.py::test_llama_13b_40_layers_prefill_and_128_decode_steps, "
                     "::test_llama_13b_40_layers_all_fp32_cache_floor (asserted 1e-4)"},
