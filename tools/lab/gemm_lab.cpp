@@ -75,6 +75,9 @@ static void fill_bf16(std::vector<uint16_t>& h, size_t n, float scale) {
 }
 
 static void set_cfg(int cfg) {
+  // 10000 * gm + c: config c with gm tile-rows per traversal group inside an XCD's rectangle (sx_gemm_force_tile(300 + gm); 0 = default 8)
+  SXCHECK(sx_gemm_force_tile(300 + cfg / 10000));
+  cfg %= 10000;
   SXCHECK(sx_gemm_force_tile(600 + (cfg >= 2000 ? (cfg / 1000 - 1) : 0)));   // 2000 + c: config 1000 + c with tune mask 1 (A/B of epilogue variants)
   if (cfg >= 2000) cfg = 1000 + cfg % 1000;
   if (cfg >= 1000) {
@@ -601,6 +604,15 @@ int main(int argc, char** argv) {
     bad += run_case({"geglu", 32768, 10240, 1280, 1, 1, 0, 0, 1, 0, 0, 0, 0, 0, 1, 0, 4, {1000, 2000}}, rounds, scale);
     bad += run_case({"c640_geglu", 131072, 5120, 640, 1, 1, 0, 0, 1, 0, 0, 0, 0, 0, 1, 0, 4, {1000, 2000}}, rounds, scale);
     bad += run_case({"llm_gateup", 2640, 27648, 5120, 1, 2, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 4, {1000, 2000}}, rounds, scale);
+    printf("%s: %d failing checks\n", bad ? "LAB FAILED" : "LAB OK", bad);
+    return bad ? 1 : 0;
+  }
+  if (suite == "gm") {     // tile traversal: which operand panel stays L2-resident across an XCD's consecutive rounds (raster part)
+    int bad = 0;
+    bad += run_case({"geglu", 32768, 10240, 1280, 1, 1, 0, 0, 1, 0, 0, 0, 0, 0, 1, 0, 4, {1000, 41000, 21000, 161000, 321000}}, rounds, scale);
+    bad += run_case({"qkv", 32768, 3840, 1280, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 5, {1100, 41100, 21100, 161100}}, rounds, scale);
+    bad += run_case({"ff2_res", 32768, 1280, 5120, 0, 0, 1, 1, 1, 0, 0, 0, 0, 0, 1, 0, 5, {1100, 41100, 21100, 161100}}, rounds, scale);
+    bad += run_case({"c640_geglu", 131072, 5120, 640, 1, 1, 0, 0, 1, 0, 0, 0, 0, 0, 1, 0, 4, {1000, 41000, 21000, 161000}}, rounds, scale);
     printf("%s: %d failing checks\n", bad ? "LAB FAILED" : "LAB OK", bad);
     return bad ? 1 : 0;
   }
