@@ -170,12 +170,13 @@ typedef struct sx_gemv_args {
   const float* row_ssq_in;
   int32_t ssq_in_parts, ssq_dim;
   float ssq_eps;
-  int32_t x_planes;    /* 0 / 1: x is one 16-bit activation. 2 (M <= 16, x_layout 1, MFMA path at any M >= 1): x holds the two planes of an
-                        * fp32-grade activation as two 16-row operand blocks [2][K/32][16][32] (block 0 = hi, block 1 = lo; sx_split16 /
-                        * sx_rmsnorm_planes / sx_attention_f32 with SX_TILED16): every weight fragment feeds two MFMAs and the two
-                        * partial results are added ahead of the epilogue — the weights stream once, y = epi((hi + lo) W^T) */
-  int32_t out_planes;  /* 1 (M <= 16): the tiled 16-bit output (SX_TILED16) or x16_out is written as two planes [2][cols/32][16][32]
-                        * (block 0 = rn16(v), block 1 = rn16(v - block 0)): the next sx_gemv's x with x_planes = 2, without a sx_split16 launch */
+  int32_t x_planes;    /* 0 / 1: x is one 16-bit activation. 2 (x_layout 1, MFMA path at any M >= 1): x holds the two planes of an
+                        * fp32-grade activation as operand blocks [2 planes][RB][K/32][16][32], RB = ceil(M / 16) row blocks of 16 rows —
+                        * the hi plane's row blocks, then the lo plane's (sx_split16 / sx_rmsnorm_planes / sx_attention_f32 with
+                        * SX_TILED16): every weight fragment feeds 2 RB MFMAs (M <= 16: two, M = 17..32, round 6: four) and the lo
+                        * products are added to the hi products ahead of the epilogue — the weights stream once, y = epi((hi + lo) W^T) */
+  int32_t out_planes;  /* 1: the tiled 16-bit output (SX_TILED16) or x16_out is written as two planes [2][RB][cols/32][16][32]
+                        * (hi = rn16(v), lo = rn16(v - hi)): the next sx_gemv's x with x_planes = 2, without a sx_split16 launch */
   const float* x16_gamma; /* optional fp32 [N] with x16_out: x16_out holds o * gamma (the NEXT LlamaRMSNorm's weight applied on the
                         * activation side, so that the next projection keeps its exact checkpoint weights and only scales by rstd from
                         * row_ssq_in — the RMSNorm fold of the precise mode; row_ssq_out is still the sum of squares of o itself) */
@@ -355,8 +356,9 @@ int sx_split_bf16(const float* x, void* out, int64_t rows, int cols, int role, v
  * fp32-grade activations of the Llama decoder (LlamaForCausalLM(precise=True); csrc/precise.hip): a 16-bit checkpoint's weights
  * are exact, so logits within 1e-3 of the fp32 reference at 40 layers only need more mantissa on the ACTIVATION side:
  * GEMM A operands travel as two 16-bit planes x = hi + lo (hi = rn16(x), lo = rn16(x - hi)), q / k / v and the KV cache stay fp32.
- * `dtype` below = SX_F16 / SX_BF16 of the planes; | SX_TILED16 → operand tiles [2][cols/32][16][32] (block 0 = hi, block 1 = lo,
- * rows <= 16: the x operand of sx_gemv with x_planes = 2) instead of rows [rows][2*cols] = [hi | lo] (sx_gemm with a_planes = 2).
+ * `dtype` below = SX_F16 / SX_BF16 of the planes; | SX_TILED16 → operand tiles [2 planes][ceil(rows / 16)][cols/32][16][32] (the hi
+ * plane's row blocks, then the lo plane's; rows <= 32: the x operand of sx_gemv with x_planes = 2) instead of rows [rows][2*cols] =
+ * [hi | lo] (sx_gemm with a_planes = 2).
  * ------------------------------------------------------------------------------------------------ */
 /* fp32 x[rows][cols] (row stride ldx) → the two planes. cols % 8 == 0 (tiles: cols % 32 == 0). */
 int sx_split16(const float* x, int64_t ldx, void* out, int rows, int cols, int dtype, void* stream);
