@@ -1016,3 +1016,37 @@ def test_attn64_accumulators_are_private(tmp_path):
                     bad.append((cur, ln.strip()))
     assert kernels >= 2, "attn64_kernel instantiations not found in the ISA"
     assert not bad, f"compiler-generated use of a private accumulator register: {bad[:3]}"
+
+
+def test_llm_mode_selection_and_memory_footprint(monkeypatch):
+    """Host logic of LlamaForCausalLM's numerics modes (no GPU): precise mode is the default for EVERY lock-step batch size up to 32 (round 6:
+    four operand blocks above 16 sequences), SX_LLM_PRECISE32=0 sends 17..32 sequences to the plain flow, SX_LLM_PRECISE=0 / precise=False
+    everything; the fp32 decode attention's key splits follow the GLOBAL (sequence, head) count; memory_footprint() prices weights, decode
+    tiles and the KV cache of the chosen mode before anything is allocated."""
+    from seedx_amd.llama import LlamaForCausalLM
+    cfg = dict(hidden_size=5120, intermediate_size=13824, num_hidden_layers=40, num_attention_heads=40, vocab_size=32330,
+               rms_norm_eps=1e-5, max_position_embeddings=4096)
+    monkeypatch.delenv("SX_LLM_PRECISE", raising=False)
+    monkeypatch.delenv("SX_LLM_PRECISE32", raising=False)
+    for G in (1, 16, 17, 32):
+        assert LlamaForCausalLM(dict(cfg), max_cache_len=64, max_batch=G).precise
+    monkeypatch.setenv("SX_LLM_PRECISE32", "0")
+    assert LlamaForCausalLM(dict(cfg), max_cache_len=64, max_batch=16).precise
+    assert not LlamaForCausalLM(dict(cfg), max_cache_len=64, max_batch=17).precise
+    monkeypatch.delenv("SX_LLM_PRECISE32")
+    monkeypatch.setenv("SX_LLM_PRECISE", "0")
+    assert not LlamaForCausalLM(dict(cfg), max_cache_len=64, max_batch=4).precise
+    monkeypatch.delenv("SX_LLM_PRECISE")
+    assert not LlamaForCausalLM(dict(cfg), max_cache_len=64, max_batch=4, precise=False).precise
+    # key splits of the T = 1 fp32 attention: ~1024 workgroups, none from 512 (sequence, head) pairs
+    assert [LlamaForCausalLM(dict(cfg), max_cache_len=64, max_batch=G).decode_nsplit_f32 for G in (1, 4, 12, 13, 32)] == [16, 7, 3, 1, 1]
+    # footprint at 13B dims, 16 sequences, 1024-token cache: 26 GB of weights, as much again in decode tiles, cache by mode
+    m = LlamaForCausalLM(dict(cfg), max_cache_len=1024, max_batch=16)
+    fp = m.memory_footprint()                          # kv_v16 is decided at pack time (dtype): the constructor's figure is the all-fp32 cache
+    per_layer = (3 * 5120 * 5120 + 5120 * 5120 + 2 * 13824 * 5120 + 5120 * 13824) * 2
+    assert fp["weights"] == 40 * per_layer + (32330 + m.V_l) * 5120 * 2 and fp["decode_tiles"] == 40 * per_layer + m.V_l * 5120 * 2
+    assert fp["kv_cache"] == 40 * 16 * 40 * 1024 * 128 * 8 and fp["total"] == fp["weights"] + fp["decode_tiles"] + fp["kv_cache"]
+    m.kv_v16 = True
+    assert m.memory_footprint()["kv_cache"] == 40 * 16 * 40 * 1024 * 128 * 6
+    plain = LlamaForCausalLM(dict(cfg), max_cache_len=1024, max_batch=4, precise=False)
+    assert plain.memory_footprint()["decode_tiles"] == 0 and plain.memory_footprint()["kv_cache"] == 40 * 4 * 40 * 1024 * 128 * 4
